@@ -1,0 +1,418 @@
+"""CPU oracle for the SRBD convex-MPC QP hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this file.  The product path (``g1_locomotion_amd``) never does; it fails loudly when
+the HIP library is missing.
+
+PARITY UNPINNED.  The reference's implementation of this path lives in the un-vendored
+submodule ``g1_mpc`` -> github.com/ioloizou/srbd_mpc (``/root/reference/.gitmodules:1-3``,
+branch hint ``walking-demo`` at ``README.md:90-91``, pinned SHA unrecoverable) and is absent
+from the snapshot; its QP solver (OSQP, per BASELINE.json) is not installed.  The reference
+holds no test, fixture or golden vector for this path.  This file therefore restates the
+*published* algorithms (single-rigid-body convex MPC, Di Carlo et al. IROS 2018; OSQP's ADMM,
+Stellato et al. 2020, Algorithm 1) and anchors every convention that IS evidenced on the
+reference's own call sites:
+
+  state  x = [roll pitch yaw | com | omega | v_com | g]   g1_mujoco_sim/src/run_simulation.py:73-77
+                                                          g1_mujoco_sim/src/ros_run_simulation.py:199-211
+  input  u = [f_Lheel f_Ltoe f_Rheel f_Rtoe] (world xyz)  g1_mujoco_sim/src/ros_run_simulation.py:65,214-215
+                                                          g1_mujoco_sim/src/wbid.py:296-297
+  update(contact_horizon, c_horizon, p_com_horizon, x_current, one_rollout) -> (u_opt0, x_opt1)
+                                                          g1_mujoco_sim/src/run_simulation.py:94-106,111
+  gravity state = -9.80665                                g1_mujoco_sim/src/ros_run_simulation.py:58
+  dt = 0.04                                               g1_mujoco_sim/src/run_simulation.py:169
+  torso inertia diag(8.20564e-2, 8.05015e-2, 0.32353e-2)  g1_mujoco_sim/src/wbid.py:261-266
+  mass = sum of <mass> in g1_description/g1_23dof.urdf = 34.13385728 (model.getMass(), wbid.py:291)
+  mu = 0.8, fz in [10, 1000] N stance / 0 swing           g1_mujoco_sim/src/wbid.py:17,123-124
+                                                          g1_mujoco_sim/src/ros_run_simulation.py:235-244
+
+Everything else (weights, discretisation, row ordering, ADMM constants) is this build's own
+documented choice -- see DESIGN.md section "Problem specification".
+
+The ADMM below (``admm_solve``) is the algorithm the HIP kernels implement, operation for
+operation.  ``solve_reference`` is an *independent* high-accuracy solver (active-set KKT
+solve + verification) used to pin the QP optimum; ``kkt_residuals`` is solver independent.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, asdict
+import numpy as np
+
+NX = 13          # state size (12 dynamic + gravity)
+NU = 12          # input size (4 contact points x 3)
+NC = 4           # contact points
+ROWS_PER_CONTACT = 5
+INF = 1.0e30     # "infinite" bound, as OSQP's OSQP_INFTY
+
+# status codes shared with include/srbdqp.h
+STATUS_SOLVED = 1
+STATUS_MAX_ITER = 2
+STATUS_NUMERICAL = -1
+
+
+@dataclass
+class SrbdParams:
+    """Every constant of the path.  Mirrors ``srbdqp_config`` in include/srbdqp.h."""
+    dt: float = 0.04
+    mass: float = 34.13385728
+    inertia: tuple = (8.20564e-2, 8.05015e-2, 0.32353e-2)
+    mu: float = 0.8
+    fz_min: float = 10.0
+    fz_max: float = 1000.0
+    gravity: float = -9.80665
+    # cost: 0.5 * sum_k (x_{k+1}-xref_k)' Q (x_{k+1}-xref_k) + 0.5 * u_k' R u_k   (NOT IN TREE: own choice)
+    q_diag: tuple = (300.0, 300.0, 150.0,  400.0, 400.0, 600.0,
+                     1.0, 1.0, 1.0,  20.0, 20.0, 20.0,  0.0)
+    r_diag: float = 1.0e-4
+    # fixed variable scaling u = force_scale * u_hat (stands in for OSQP's Ruiz equilibration)
+    force_scale: float = 100.0
+    # ADMM (OSQP Algorithm 1) constants
+    rho: float = 1.0
+    rho_eq_scale: float = 1.0e3
+    sigma: float = 1.0e-6
+    alpha: float = 1.6
+    eps_abs: float = 1.0e-6
+    eps_rel: float = 1.0e-6
+    max_iter: int = 500
+    check_every: int = 5
+
+    def as_dict(self):
+        return asdict(self)
+
+
+# --------------------------------------------------------------------------------------
+# a5: SRBD linearisation
+# --------------------------------------------------------------------------------------
+def rot_z(yaw):
+    c, s = np.cos(yaw), np.sin(yaw)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+def skew(r):
+    return np.array([[0.0, -r[2], r[1]], [r[2], 0.0, -r[0]], [-r[1], r[0], 0.0]])
+
+
+def linearise(p: SrbdParams, yaw: float, r: np.ndarray):
+    """Discrete (forward-Euler) SRBD matrices for one horizon step.
+
+    yaw : linearisation yaw psi_k.   r : (4,3) lever arms c_i - p_com.
+    Returns A (13,13), B (13,12) with x_{k+1} = A x_k + B u_k.
+    """
+    Rz = rot_z(yaw)
+    Ib_inv = np.diag(1.0 / np.asarray(p.inertia, dtype=np.float64))
+    Iw_inv = Rz @ Ib_inv @ Rz.T
+    A = np.eye(NX)
+    A[0:3, 6:9] = p.dt * Rz.T          # euler-rate ~= Rz(psi)' omega
+    A[3:6, 9:12] = p.dt * np.eye(3)    # p' = v
+    A[11, 12] = p.dt                   # v_z' += g
+    B = np.zeros((NX, NU))
+    for i in range(NC):
+        B[6:9, 3 * i:3 * i + 3] = p.dt * (Iw_inv @ skew(r[i]))
+        B[9:12, 3 * i:3 * i + 3] = (p.dt / p.mass) * np.eye(3)
+    return A, B
+
+
+# --------------------------------------------------------------------------------------
+# a6: horizon condensation
+# --------------------------------------------------------------------------------------
+def condense(p: SrbdParams, yaw_hor, foot_hor, pcom_hor):
+    """A_qp (13N,13), B_qp (13N,12N):  X = A_qp x0 + B_qp U,  X = [x_1..x_N]."""
+    N = len(yaw_hor)
+    Ak, Bk = [], []
+    for k in range(N):
+        r = np.asarray(foot_hor[k], dtype=np.float64).reshape(NC, 3) - np.asarray(pcom_hor[k], dtype=np.float64)
+        A, B = linearise(p, float(yaw_hor[k]), r)
+        Ak.append(A)
+        Bk.append(B)
+    A_qp = np.zeros((NX * N, NX))
+    B_qp = np.zeros((NX * N, NU * N))
+    acc = np.eye(NX)
+    for i in range(N):
+        acc = Ak[i] @ acc
+        A_qp[NX * i:NX * (i + 1)] = acc
+        for j in range(i + 1):
+            blk = Bk[j]
+            for l in range(j + 1, i + 1):
+                blk = Ak[l] @ blk
+            B_qp[NX * i:NX * (i + 1), NU * j:NU * (j + 1)] = blk
+    return A_qp, B_qp
+
+
+# --------------------------------------------------------------------------------------
+# a7/a8: Hessian, gradient, friction-cone rows
+# --------------------------------------------------------------------------------------
+def cone_block(mu):
+    """5x3 constraint block of one contact point: rows (fx-mu fz, -fx-mu fz, fy-mu fz, -fy-mu fz, fz)."""
+    return np.array([[1.0, 0.0, -mu], [-1.0, 0.0, -mu], [0.0, 1.0, -mu], [0.0, -1.0, -mu], [0.0, 0.0, 1.0]])
+
+
+def build_qp(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None):
+    """Dense QP in SCALED variables u_hat = u / force_scale.
+
+    min 0.5 uh' P uh + q' uh   s.t.  l <= A uh <= ub
+    Returns dict(P,q,A,l,u,A_qp,B_qp).  Row 20k+5i+j = step k, contact i, cone row j.
+    """
+    x0 = np.asarray(x0, dtype=np.float64).reshape(NX)
+    x_ref = np.asarray(x_ref, dtype=np.float64)
+    N = x_ref.shape[0]
+    foot_hor = np.asarray(foot_hor, dtype=np.float64).reshape(N, NU)
+    contact_hor = np.asarray(contact_hor).reshape(N, NC)
+    if pcom_hor is None:
+        pcom_hor = x_ref[:, 3:6]
+    pcom_hor = np.asarray(pcom_hor, dtype=np.float64).reshape(N, 3)
+    A_qp, B_qp = condense(p, x_ref[:, 2], foot_hor, pcom_hor)
+    s = p.force_scale
+    Qd = np.tile(np.asarray(p.q_diag, dtype=np.float64), N)
+    Bs = B_qp * s
+    P = Bs.T @ (Qd[:, None] * Bs) + (p.r_diag * s * s) * np.eye(NU * N)
+    P = 0.5 * (P + P.T)
+    q = Bs.T @ (Qd * (A_qp @ x0 - x_ref.reshape(-1)))
+    C = cone_block(p.mu)
+    m = ROWS_PER_CONTACT * NC * N
+    A = np.zeros((m, NU * N))
+    l = np.full(m, -INF)
+    u = np.zeros(m)
+    for k in range(N):
+        for i in range(NC):
+            r0 = 20 * k + 5 * i
+            c0 = NU * k + 3 * i
+            A[r0:r0 + 5, c0:c0 + 3] = C
+            c = 1.0 if contact_hor[k, i] else 0.0
+            l[r0 + 4] = c * p.fz_min / s
+            u[r0 + 4] = c * p.fz_max / s
+    return dict(P=P, q=q, A=A, l=l, u=u, A_qp=A_qp, B_qp=B_qp)
+
+
+def rho_vector(p: SrbdParams, l, u):
+    """Per-row ADMM penalty: rho for inequalities, rho*rho_eq_scale for equalities (OSQP's rule)."""
+    rho = np.full(l.shape, p.rho)
+    rho[(u - l) < 1e-12] = p.rho * p.rho_eq_scale
+    return rho
+
+
+# --------------------------------------------------------------------------------------
+# a9: ADMM (OSQP Algorithm 1, reduced-KKT form)
+# --------------------------------------------------------------------------------------
+def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.float64, trace=None):
+    """The algorithm the HIP kernel runs, in the same order of operations.
+
+    K = P + sigma I + A' diag(rho) A is factored once (Cholesky); every iteration applies the
+    inverse.  P x is tracked by recursion (no matvec with P inside the loop).
+    Returns (x, z, y, iters, status).
+    """
+    P = P.astype(dtype); q = q.astype(dtype); A = A.astype(dtype)
+    l = l.astype(dtype); u = u.astype(dtype)
+    n, m = P.shape[0], A.shape[0]
+    rho = rho_vector(p, l, u).astype(dtype)
+    sigma, alpha = dtype(p.sigma), dtype(p.alpha)
+    K = P + sigma * np.eye(n, dtype=dtype) + (A.T * rho) @ A
+    Lc = np.linalg.cholesky(K.astype(np.float64)).astype(dtype) if dtype == np.float64 else _chol(K)
+    Linv = _tri_inv(Lc)
+    Kinv = (Linv.T @ Linv).astype(dtype)
+    x = np.zeros(n, dtype) if x_init is None else np.asarray(x_init, dtype).copy()
+    y = np.zeros(m, dtype) if y_init is None else np.asarray(y_init, dtype).copy()
+    z = np.clip(A @ x, l, u)
+    Px = P @ x
+    qn = np.max(np.abs(q))
+    status, iters = STATUS_MAX_ITER, p.max_iter
+    for k in range(1, p.max_iter + 1):
+        rhs = sigma * x - q + A.T @ (rho * z - y)
+        xt = Kinv @ rhs
+        zt = A @ xt
+        # P xt from the KKT identity: (P + sigma I) xt + A'(rho (zt - z) + y) = sigma x - q
+        Pxt = sigma * (x - xt) - q - A.T @ (rho * (zt - z) + y)
+        x = alpha * xt + (1 - alpha) * x
+        Px = alpha * Pxt + (1 - alpha) * Px
+        zh = alpha * zt + (1 - alpha) * z
+        zn = np.clip(zh + y / rho, l, u)
+        y = y + rho * (zh - zn)
+        z = zn
+        if k % p.check_every == 0 or k == p.max_iter:
+            Ax = A @ x
+            Aty = A.T @ y
+            r_prim = np.max(np.abs(Ax - z))
+            r_dual = np.max(np.abs(Px + q + Aty))
+            e_prim = p.eps_abs + p.eps_rel * max(np.max(np.abs(Ax)), np.max(np.abs(z)))
+            e_dual = p.eps_abs + p.eps_rel * max(np.max(np.abs(Px)), np.max(np.abs(Aty)), qn)
+            if trace is not None:
+                trace.append((k, float(r_prim), float(r_dual)))
+            if not np.isfinite(r_prim + r_dual):
+                status, iters = STATUS_NUMERICAL, k
+                break
+            if r_prim <= e_prim and r_dual <= e_dual:
+                status, iters = STATUS_SOLVED, k
+                break
+    return x, z, y, iters, status
+
+
+def _chol(K):
+    """Unblocked lower Cholesky in the matrix' own dtype (used for the fp32 oracle)."""
+    K = K.copy()
+    n = K.shape[0]
+    for j in range(n):
+        K[j, j] = np.sqrt(K[j, j] - np.dot(K[j, :j], K[j, :j]))
+        K[j + 1:, j] = (K[j + 1:, j] - K[j + 1:, :j] @ K[j, :j]) / K[j, j]
+    return np.tril(K)
+
+
+def _tri_inv(L):
+    n = L.shape[0]
+    W = np.zeros_like(L)
+    for j in range(n):
+        W[j, j] = 1.0 / L[j, j]
+        for i in range(j + 1, n):
+            W[i, j] = -np.dot(L[i, j:i], W[j:i, j]) / L[i, i]
+    return W
+
+
+# --------------------------------------------------------------------------------------
+# a10: update() = assemble + solve + rollout
+# --------------------------------------------------------------------------------------
+def rollout(qp, x0, u_hat, force_scale):
+    """x horizon (N+1,13): row 0 = x0, row k = predicted x_k."""
+    x0 = np.asarray(x0, dtype=np.float64).reshape(NX)
+    X = qp["A_qp"] @ x0 + (qp["B_qp"] * force_scale) @ u_hat
+    return np.vstack([x0[None, :], X.reshape(-1, NX)])
+
+
+def update(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None, warm=None, dtype=np.float64):
+    """Oracle twin of MPC.update: returns dict(u (N,12) in newtons, x (N+1,13), iters, status, ...)."""
+    qp = build_qp(p, x0, x_ref, foot_hor, contact_hor, pcom_hor)
+    xi, yi = (None, None) if warm is None else warm
+    uh, z, y, iters, status = admm_solve(p, qp["P"], qp["q"], qp["A"], qp["l"], qp["u"], xi, yi, dtype=dtype)
+    N = np.asarray(x_ref).shape[0]
+    uh64 = uh.astype(np.float64)
+    return dict(u=(uh64 * p.force_scale).reshape(N, NU), x=rollout(qp, x0, uh64, p.force_scale),
+                iters=iters, status=status, u_hat=uh64, y=y.astype(np.float64), qp=qp)
+
+
+# --------------------------------------------------------------------------------------
+# independent reference solution + solver-independent acceptance
+# --------------------------------------------------------------------------------------
+def kkt_residuals(P, q, A, l, u, x, y):
+    """Solver-independent optimality measures (all should be ~0 at the optimum)."""
+    Ax = A @ x
+    stat = np.max(np.abs(P @ x + q + A.T @ y))
+    prim = max(0.0, float(np.max(l - Ax)), float(np.max(Ax - u)))
+    yp, ym = np.maximum(y, 0), np.minimum(y, 0)
+    fin_u, fin_l = u < INF / 2, l > -INF / 2
+    comp = max(float(np.max(np.abs(yp[fin_u] * (u - Ax)[fin_u]), initial=0.0)),
+               float(np.max(np.abs(ym[fin_l] * (Ax - l)[fin_l]), initial=0.0)))
+    dual_inf = max(float(np.max(yp[~fin_u], initial=0.0)), float(np.max(-ym[~fin_l], initial=0.0)))
+    return dict(stationarity=float(stat), primal=prim, complementarity=comp, dual_sign=dual_inf)
+
+
+def solve_reference(p: SrbdParams, qp, max_outer=200):
+    """Independent high-accuracy solve: primal active-set iteration on the reduced problem
+    (inactive contacts eliminated), each step an exact KKT solve, verified by kkt_residuals.
+    Returns (x, y) in the scaled variables with KKT residuals <= ~1e-9.
+    """
+    P, q, A, l, u = qp["P"], qp["q"], qp["A"], qp["l"], qp["u"]
+    n, m = P.shape[0], A.shape[0]
+    eq_rows = np.where((u - l) < 1e-12)[0]           # fz == 0 rows of swing contacts
+    fixed = np.zeros(n, bool)
+    for r in eq_rows:
+        c = np.where(A[r] != 0)[0][0]                 # the fz column
+        fixed[c - 2:c + 1] = True                     # fx, fy, fz of that contact are all forced to 0
+    free = ~fixed
+    rows = np.array([r for r in range(m) if np.all(free[np.where(A[r] != 0)[0]])], dtype=int)
+    Pf, qf, Af, lf, uf = P[np.ix_(free, free)], q[free], A[np.ix_(rows, free)], l[rows], u[rows]
+    # start from a tight ADMM estimate of the active set
+    pt = SrbdParams(**{**p.as_dict(), "eps_abs": 1e-9, "eps_rel": 1e-9, "max_iter": 20000, "check_every": 25})
+    xf, _, yf, _, _ = admm_solve(pt, Pf, qf, Af, lf, uf)
+    Axf = Af @ xf
+    act_lo = (yf < -1e-7) & (lf > -INF / 2)
+    act_up = (yf > 1e-7)
+    for _ in range(max_outer):
+        act = np.where(act_lo | act_up)[0]
+        b = np.where(act_up[act], uf[act], lf[act])
+        Aa = Af[act]
+        na = len(act)
+        KKT = np.block([[Pf, Aa.T], [Aa, np.zeros((na, na))]])
+        sol = np.linalg.solve(KKT, np.concatenate([-qf, b]))
+        xs, lam = sol[:Pf.shape[0]], sol[Pf.shape[0]:]
+        ys = np.zeros(len(rows)); ys[act] = lam
+        Axs = Af @ xs
+        viol_lo = (Axs < lf - 1e-10) & ~act_lo
+        viol_up = (Axs > uf + 1e-10) & ~act_up
+        bad_lo = act_lo & (ys > 1e-12)
+        bad_up = act_up & (ys < -1e-12)
+        if not (viol_lo.any() or viol_up.any() or bad_lo.any() or bad_up.any()):
+            break
+        act_lo = (act_lo | viol_lo) & ~bad_lo
+        act_up = (act_up | viol_up) & ~bad_up
+    else:
+        raise RuntimeError("active-set reference did not converge")
+    x = np.zeros(n); x[free] = xs
+    y = np.zeros(m); y[rows] = ys
+    # multipliers of the eliminated contacts: recover a valid dual from stationarity
+    g = P @ x + q + A.T @ y                           # nonzero only on fixed columns
+    for r in eq_rows:
+        c = np.where(A[r] != 0)[0][0]
+        gx, gy, gz = g[c - 2], g[c - 1], g[c]
+        # rows r-4..r-1 are the cone rows (upper bound 0, multipliers >= 0), row r the equality
+        y[r - 4], y[r - 3] = max(-gx, 0.0), max(gx, 0.0)
+        y[r - 2], y[r - 1] = max(-gy, 0.0), max(gy, 0.0)
+        y[r] = -gz + p.mu * (y[r - 4] + y[r - 3] + y[r - 2] + y[r - 1])
+    return x, y
+
+
+# --------------------------------------------------------------------------------------
+# synthetic inputs; used by tests, bench.py and the golden generator
+# --------------------------------------------------------------------------------------
+COM_TARGET = np.array([5.26790425e-02, 7.44339342e-05, 5.97983255e-01])   # run_simulation.py:81
+HIP_Y = 0.064452                                                          # g1_23dof.urdf hip offset
+HEEL_X, TOE_X = -0.05, 0.12                                               # g1_23dof.urdf:285-294
+
+
+def synthetic_batch(B, N, seed, schedule="single", dt=0.04, gravity=-9.80665):
+    """Seeded inputs: x0 (B,13), x_ref (B,N,13), foot (B,N,12), contact (B,N,4) uint8.
+
+    schedule: "single" = alternating single support, switch every 6 steps, random phase & first foot
+              "double" = all four points active
+              "mixed"  = per-QP random phase gait with double-support overlap
+    """
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, NX))
+    x0[:, 0:2] = rng.uniform(-0.2, 0.2, (B, 2))
+    x0[:, 2] = rng.uniform(-np.pi, np.pi, B)
+    x0[:, 3:5] = rng.uniform(-0.1, 0.1, (B, 2))
+    x0[:, 5] = 0.598 + rng.uniform(-0.05, 0.05, B)
+    x0[:, 6:9] = rng.uniform(-0.5, 0.5, (B, 3))
+    x0[:, 9:12] = rng.uniform(-0.5, 0.5, (B, 3))
+    x0[:, 12] = gravity
+    v_ref = rng.uniform(-0.3, 0.3, (B, 2))
+    x_ref = np.zeros((B, N, NX))
+    k = np.arange(1, N + 1)[None, :]
+    x_ref[:, :, 2] = x0[:, 2:3]                                   # hold current yaw
+    x_ref[:, :, 3] = COM_TARGET[0] + v_ref[:, 0:1] * k * dt
+    x_ref[:, :, 4] = COM_TARGET[1] + v_ref[:, 1:2] * k * dt
+    x_ref[:, :, 5] = COM_TARGET[2]
+    x_ref[:, :, 9] = v_ref[:, 0:1]
+    x_ref[:, :, 10] = v_ref[:, 1:2]
+    x_ref[:, :, 12] = gravity
+    foot = np.zeros((B, N, NU))
+    fx0 = rng.uniform(-0.05, 0.05, (B, 2))
+    fy = np.stack([HIP_Y + rng.uniform(-0.02, 0.02, B), -HIP_Y + rng.uniform(-0.02, 0.02, B)], 1)
+    c, s = np.cos(x0[:, 2]), np.sin(x0[:, 2])
+    for f in range(2):
+        for h, off in enumerate((HEEL_X, TOE_X)):
+            px, py = fx0[:, f] + off, fy[:, f]
+            i = 2 * f + h
+            foot[:, :, 3 * i + 0] = (COM_TARGET[0] + c * px - s * py)[:, None]
+            foot[:, :, 3 * i + 1] = (COM_TARGET[1] + s * px + c * py)[:, None]
+            foot[:, :, 3 * i + 2] = 0.0
+    contact = np.ones((B, N, NC), np.uint8)
+    if schedule in ("single", "mixed"):
+        phase = rng.integers(0, 12, B)
+        for kk in range(N):
+            ph = (phase + kk) % 12
+            left_stance = ph < 6
+            if schedule == "single":
+                contact[:, kk, 0:2] = left_stance[:, None]
+                contact[:, kk, 2:4] = ~left_stance[:, None]
+            else:
+                ds = (ph % 6) == 0                                # one double-support step per switch
+                contact[:, kk, 0:2] = (left_stance | ds)[:, None]
+                contact[:, kk, 2:4] = (~left_stance | ds)[:, None]
+    return x0, x_ref, foot, contact
