@@ -1,0 +1,340 @@
+// srbdqp.hip -- C-ABI of the batched SRBD convex-MPC QP engine (see include/srbdqp.h) and kernel dispatch.
+// Host side: HIP runtime only (stream, workspace, events).  No CPU fallback of any kind.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "srbdqp.h"
+#include "srbdqp_common.hpp"
+#include "srbdqp_gj.hpp"
+#include "srbdqp_mfma.hpp"
+
+using srbdqp::KArgs;
+
+struct srbdqp_handle {
+    srbdqp_config cfg;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    // device workspace for the host-buffer API
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    std::string err;
+    const char* kname = "none";
+};
+
+namespace {
+
+std::string g_create_err;
+
+#define HIP_TRY(h, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return SRBDQP_E_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+bool horizon_supported(int N) { return N == 8 || N == 10 || N == 12 || N == 4; }
+
+int resolve_kernel(const srbdqp_config& c) {
+    if (c.kernel == SRBDQP_KERNEL_GJ) return SRBDQP_KERNEL_GJ;
+    if (c.kernel == SRBDQP_KERNEL_MFMA) return SRBDQP_KERNEL_MFMA;
+    return srbdqp::kMfmaReady ? SRBDQP_KERNEL_MFMA : SRBDQP_KERNEL_GJ;
+}
+
+void fill_args(const srbdqp_config& c, KArgs& a) {
+    a.max_iter = c.max_iter;
+    a.check_every = c.check_every;
+    a.dt = c.dt;
+    a.inv_mass = 1.0 / c.mass;
+    for (int i = 0; i < 3; ++i) a.iinv[i] = 1.0 / c.inertia[i];
+    a.mu = c.mu;
+    a.s = c.force_scale;
+    a.fzmin_s = c.fz_min / c.force_scale;
+    a.fzmax_s = c.fz_max / c.force_scale;
+    for (int i = 0; i < 12; ++i) a.sqrtq[i] = std::sqrt(c.q_diag[i]);
+    a.rs2 = c.r_diag * c.force_scale * c.force_scale;
+    a.rho = c.rho;
+    a.rho_eq = c.rho * c.rho_eq_scale;
+    a.sigma = c.sigma;
+    a.alpha = c.alpha;
+    a.eps_abs = c.eps_abs;
+    a.eps_rel = c.eps_rel;
+}
+
+template <int N>
+int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int variant) {
+    const dim3 grid((unsigned)a.B), block(srbdqp::kThreads);
+    if (variant == SRBDQP_KERNEL_MFMA && srbdqp::MfmaTraits<N>::supported) {
+        constexpr size_t lds = srbdqp::MfmaTraits<N>::lds_bytes;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&srbdqp::srbdqp_mfma_kernel<N>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        h->kname = srbdqp::MfmaTraits<N>::name;
+        hipLaunchKernelGGL(srbdqp::srbdqp_mfma_kernel<N>, grid, block, lds, st, a);
+    } else {
+        constexpr size_t lds = srbdqp::GjSmem<N>::bytes;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&srbdqp::srbdqp_gj_kernel<N>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        static const std::string nm = "gj_f64_n" + std::to_string(N);
+        h->kname = nm.c_str();
+        hipLaunchKernelGGL(srbdqp::srbdqp_gj_kernel<N>, grid, block, lds, st, a);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SRBDQP_OK;
+}
+
+int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
+    if (a.B <= 0) return SRBDQP_OK;
+    const int variant = (a.mode == 1) ? SRBDQP_KERNEL_GJ : resolve_kernel(h->cfg);
+    const bool timing = (h->cfg.flags & SRBDQP_FLAG_TIMING) != 0;
+    if (timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    int rc;
+    switch (h->cfg.horizon) {
+        case 4: rc = launch_n<4>(h, a, st, variant); break;
+        case 8: rc = launch_n<8>(h, a, st, variant); break;
+        case 10: rc = launch_n<10>(h, a, st, variant); break;
+        default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
+    }
+    if (rc != SRBDQP_OK) return rc;
+    if (timing) {
+        HIP_TRY(h, hipEventRecord(h->ev1, st));
+        h->ev_valid = true;
+    }
+    return SRBDQP_OK;
+}
+
+int ensure_ws(srbdqp_handle* h, size_t bytes) {
+    if (bytes <= h->ws_bytes) return SRBDQP_OK;
+    if (h->ws) { HIP_TRY(h, hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+    size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->ws), want);
+    if (e != hipSuccess) { h->err = std::string("hipMalloc workspace: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
+    h->ws_bytes = want;
+    return SRBDQP_OK;
+}
+
+struct Carver {
+    char* base; size_t off = 0;
+    explicit Carver(char* b) : base(b) {}
+    template <typename T> T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (count * sizeof(T) + 255) & ~size_t(255);
+        return p;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* srbdqp_version(void) { return "srbdqp 0.1 (gfx950, fp64)"; }
+
+int srbdqp_default_config(srbdqp_config* c) {
+    if (!c) return SRBDQP_E_INVALID;
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (int32_t)sizeof(srbdqp_config);
+    c->horizon = 10;
+    c->device = 0;
+    c->flags = 0;
+    c->kernel = SRBDQP_KERNEL_AUTO;
+    c->max_iter = 500;
+    c->check_every = 5;
+    c->dt = 0.04;
+    c->mass = 34.13385728;
+    c->inertia[0] = 8.20564e-2; c->inertia[1] = 8.05015e-2; c->inertia[2] = 0.32353e-2;
+    c->mu = 0.8;
+    c->fz_min = 10.0; c->fz_max = 1000.0;
+    const double q[13] = {300.0, 300.0, 150.0, 400.0, 400.0, 600.0, 1.0, 1.0, 1.0, 20.0, 20.0, 20.0, 0.0};
+    for (int i = 0; i < 13; ++i) c->q_diag[i] = q[i];
+    c->r_diag = 1.0e-4;
+    c->force_scale = 100.0;
+    c->rho = 1.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
+    c->eps_abs = 1.0e-6; c->eps_rel = 1.0e-6;
+    return SRBDQP_OK;
+}
+
+int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
+    if (!cfg || !out) { g_create_err = "null argument"; return SRBDQP_E_INVALID; }
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(srbdqp_config)) { g_create_err = "srbdqp_config.struct_size mismatch"; return SRBDQP_E_INVALID; }
+    if (!horizon_supported(cfg->horizon) || cfg->horizon > 10) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10})"; return SRBDQP_E_INVALID; }
+    if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) ||
+        cfg->max_iter < 1 || cfg->check_every < 1 || !(cfg->mu >= 0)) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
+    for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_err = "no usable HIP device (this engine has no CPU fallback)";
+        return SRBDQP_E_NO_DEVICE;
+    }
+    srbdqp_handle* h = new (std::nothrow) srbdqp_handle();
+    if (!h) { g_create_err = "out of host memory"; return SRBDQP_E_NOMEM; }
+    h->cfg = *cfg;
+    auto fail = [&](const char* what, hipError_t er) {
+        g_create_err = std::string(what) + ": " + hipGetErrorString(er);
+        if (h->ev0) (void)hipEventDestroy(h->ev0);
+        if (h->ev1) (void)hipEventDestroy(h->ev1);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        delete h;
+        return SRBDQP_E_HIP;
+    };
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+    *out = h;
+    return SRBDQP_OK;
+}
+
+int srbdqp_destroy(srbdqp_handle* h) {
+    if (!h) return SRBDQP_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SRBDQP_OK;
+}
+
+const char* srbdqp_last_error(const srbdqp_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+const char* srbdqp_kernel_name(const srbdqp_handle* h) { return h ? h->kname : "none"; }
+
+int srbdqp_synchronize(srbdqp_handle* h) {
+    if (!h) return SRBDQP_E_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SRBDQP_OK;
+}
+
+double srbdqp_last_kernel_ms(srbdqp_handle* h) {
+    if (!h || !h->ev_valid) return -1.0;
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref,
+                                  const double* foot, const uint8_t* contact, const double* pcom,
+                                  const double* warm_u, const double* warm_y, double* u_out, double* x_out,
+                                  double* y_out, int32_t* status, int32_t* iters, void* stream) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!x0 || !x_ref || !foot || !contact || !u_out))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    KArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_args(h->cfg, a);
+    a.x0 = x0; a.xref = x_ref; a.foot = foot; a.contact = contact; a.pcom = pcom;
+    a.warm_u = warm_u; a.warm_y = warm_y;
+    a.u_out = u_out; a.x_out = x_out; a.y_out = y_out; a.status = status; a.iters = iters;
+    a.B = B; a.mode = 0;
+    return launch(h, a, stream ? reinterpret_cast<hipStream_t>(stream) : h->stream);
+}
+
+int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,
+                           const uint8_t* contact, const double* pcom, const double* warm_u, const double* warm_y,
+                           double* u_out, double* x_out, double* y_out, int32_t* status, int32_t* iters) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!x0 || !x_ref || !foot || !contact || !u_out))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = (size_t)h->cfg.horizon, n = 12 * N, m = 20 * N, b = (size_t)B;
+    Carver sz(nullptr);
+    auto carve = [&](Carver& c, double*& dx0, double*& dxr, double*& dft, uint8_t*& dct, double*& dpc, double*& dwu,
+                     double*& dwy, double*& du, double*& dx, double*& dy, int32_t*& dst, int32_t*& dit) {
+        dx0 = c.take<double>(b * 13); dxr = c.take<double>(b * N * 13); dft = c.take<double>(b * N * 12);
+        dct = c.take<uint8_t>(b * N * 4);
+        dpc = pcom ? c.take<double>(b * N * 3) : nullptr;
+        dwu = warm_u ? c.take<double>(b * n) : nullptr;
+        dwy = warm_y ? c.take<double>(b * m) : nullptr;
+        du = c.take<double>(b * n);
+        dx = x_out ? c.take<double>(b * (N + 1) * 13) : nullptr;
+        dy = y_out ? c.take<double>(b * m) : nullptr;
+        dst = c.take<int32_t>(b); dit = c.take<int32_t>(b);
+    };
+    double *dx0, *dxr, *dft, *dpc, *dwu, *dwy, *du, *dx, *dy; uint8_t* dct; int32_t *dst, *dit;
+    carve(sz, dx0, dxr, dft, dct, dpc, dwu, dwy, du, dx, dy, dst, dit);
+    int rc = ensure_ws(h, sz.off);
+    if (rc != SRBDQP_OK) return rc;
+    Carver cv(h->ws);
+    carve(cv, dx0, dxr, dft, dct, dpc, dwu, dwy, du, dx, dy, dst, dit);
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(dx0, x0, b * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dxr, x_ref, b * N * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dft, foot, b * N * 12 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dct, contact, b * N * 4, hipMemcpyHostToDevice, st));
+    if (pcom) HIP_TRY(h, hipMemcpyAsync(dpc, pcom, b * N * 3 * 8, hipMemcpyHostToDevice, st));
+    if (warm_u) HIP_TRY(h, hipMemcpyAsync(dwu, warm_u, b * n * 8, hipMemcpyHostToDevice, st));
+    if (warm_y) HIP_TRY(h, hipMemcpyAsync(dwy, warm_y, b * m * 8, hipMemcpyHostToDevice, st));
+    rc = srbdqp_solve_batch_device_f64(h, B, dx0, dxr, dft, dct, dpc, dwu, dwy, du, dx, dy, dst, dit, st);
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(u_out, du, b * n * 8, hipMemcpyDeviceToHost, st));
+    if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, dx, b * (N + 1) * 13 * 8, hipMemcpyDeviceToHost, st));
+    if (y_out) HIP_TRY(h, hipMemcpyAsync(y_out, dy, b * m * 8, hipMemcpyDeviceToHost, st));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, dst, b * 4, hipMemcpyDeviceToHost, st));
+    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, dit, b * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return SRBDQP_OK;
+}
+
+int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,
+                        const uint8_t* contact, const double* pcom, double* P_out, double* q_out, double* l_out,
+                        double* ub_out) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!x0 || !x_ref || !foot || !contact || !P_out || !q_out || !l_out || !ub_out))) { h->err = "null pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = (size_t)h->cfg.horizon, n = 12 * N, m = 20 * N, b = (size_t)B;
+    auto carve = [&](Carver& c, double*& dx0, double*& dxr, double*& dft, uint8_t*& dct, double*& dpc, double*& dP,
+                     double*& dq, double*& dl, double*& du) {
+        dx0 = c.take<double>(b * 13); dxr = c.take<double>(b * N * 13); dft = c.take<double>(b * N * 12);
+        dct = c.take<uint8_t>(b * N * 4);
+        dpc = pcom ? c.take<double>(b * N * 3) : nullptr;
+        dP = c.take<double>(b * n * n); dq = c.take<double>(b * n); dl = c.take<double>(b * m); du = c.take<double>(b * m);
+    };
+    double *dx0, *dxr, *dft, *dpc, *dP, *dq, *dl, *du; uint8_t* dct;
+    Carver sz(nullptr);
+    carve(sz, dx0, dxr, dft, dct, dpc, dP, dq, dl, du);
+    int rc = ensure_ws(h, sz.off);
+    if (rc != SRBDQP_OK) return rc;
+    Carver cv(h->ws);
+    carve(cv, dx0, dxr, dft, dct, dpc, dP, dq, dl, du);
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(dx0, x0, b * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dxr, x_ref, b * N * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dft, foot, b * N * 12 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dct, contact, b * N * 4, hipMemcpyHostToDevice, st));
+    if (pcom) HIP_TRY(h, hipMemcpyAsync(dpc, pcom, b * N * 3 * 8, hipMemcpyHostToDevice, st));
+    KArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_args(h->cfg, a);
+    a.x0 = dx0; a.xref = dxr; a.foot = dft; a.contact = dct; a.pcom = dpc;
+    a.P_out = dP; a.q_out = dq; a.l_out = dl; a.ub_out = du;
+    a.B = B; a.mode = 1;
+    rc = launch(h, a, st);
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(P_out, dP, b * n * n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(q_out, dq, b * n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(l_out, dl, b * m * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(ub_out, du, b * m * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return SRBDQP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference's MPC object for the hot path, over the C-ABI HIP library.
+
+``MPC`` keeps the duck-typed surface the reference's callers use
+(g1_mujoco_sim/src/run_simulation.py:169-170,73-82,96,103,106):
+
+    MPC = mpc.MPC(dt=0.04); MPC.init_matrices()
+    MPC.x0[...] ; MPC.x_ref_hor[...] ; MPC.g ; MPC.HORIZON_LENGTH
+    u_opt0, x_opt1 = MPC.update(contact_horizon, c_horizon, p_com_horizon, x_current=MPC.x0, one_rollout=True)
+
+``solve()`` (named by BASELINE.json, no call site in the reference tree) is this build's assemble+solve step
+that ``update()`` calls.  ``BatchMPC`` is the same operation for B independent QPs (NumPy host arrays, or
+device pointers of HBM-resident buffers).  All compute happens in libsrbdqp.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import NX, NU, NC, SrbdqpError
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _as(a, dtype, shape, name):
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    if arr.shape != tuple(shape):
+        try:
+            arr = arr.reshape(shape)
+        except ValueError as e:
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {np.shape(a)}") from e
+    return arr
+
+
+class BatchMPC:
+    """B independent SRBD convex-MPC QPs per call.  One instance <-> one HIP stream <-> one thread."""
+
+    def __init__(self, horizon: int = 10, dt: float = 0.04, device: int = 0, kernel: int = _lib.KERNEL_AUTO,
+                 timing: bool = False, **overrides):
+        lib = _lib.load()
+        cfg = _lib.default_config()
+        cfg.horizon = int(horizon)
+        cfg.dt = float(dt)
+        cfg.device = int(device)
+        cfg.kernel = int(kernel)
+        cfg.flags = _lib.FLAG_TIMING if timing else 0
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown srbdqp_config field {k!r}")
+            if k in ("q_diag", "inertia"):
+                arr = getattr(cfg, k)
+                if len(v) != len(arr):
+                    raise ValueError(f"{k}: expected {len(arr)} values")
+                for i, x in enumerate(v):
+                    arr[i] = float(x)
+            else:
+                setattr(cfg, k, type(getattr(cfg, k))(v))
+        self.cfg = cfg
+        self._lib = lib
+        self._h = C.c_void_p()
+        rc = lib.srbdqp_create(C.byref(cfg), C.byref(self._h))
+        if rc != _lib.OK:
+            msg = lib.srbdqp_last_error(None)
+            self._h = C.c_void_p()
+            raise SrbdqpError(f"srbdqp_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.N = int(horizon)
+        self.n = NU * self.N
+        self.m = _lib.ROWS_PER_STEP * self.N
+
+    # -- lifetime ------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.srbdqp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- host-buffer API -------------------------------------------------------------------------------
+    def solve(self, x0, x_ref, foot, contact, pcom=None, warm_u=None, warm_y=None, want_x=True, want_y=False):
+        """Solve B QPs.  Returns dict(u (B,N,12) [N], x (B,N+1,13), y (B,20N), status (B,), iters (B,))."""
+        N, n, m = self.N, self.n, self.m
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B = x0.size // NX
+        x0 = _as(x0, np.float64, (B, NX), "x0")
+        x_ref = _as(x_ref, np.float64, (B, N, NX), "x_ref")
+        foot = _as(foot, np.float64, (B, N, NU), "foot")
+        contact = _as(np.asarray(contact) != 0, np.uint8, (B, N, NC), "contact")
+        pcom = None if pcom is None else _as(pcom, np.float64, (B, N, 3), "pcom")
+        warm_u = None if warm_u is None else _as(warm_u, np.float64, (B, n), "warm_u")
+        warm_y = None if warm_y is None else _as(warm_y, np.float64, (B, m), "warm_y")
+        u = np.empty((B, N, NU))
+        x = np.empty((B, N + 1, NX)) if want_x else None
+        y = np.empty((B, m)) if want_y else None
+        status = np.empty(B, np.int32)
+        iters = np.empty(B, np.int32)
+        rc = self._lib.srbdqp_solve_batch_f64(self._h, B, _ptr(x0), _ptr(x_ref), _ptr(foot), _ptr(contact), _ptr(pcom),
+                                              _ptr(warm_u), _ptr(warm_y), _ptr(u), _ptr(x), _ptr(y), _ptr(status),
+                                              _ptr(iters))
+        _lib.check(rc, self._h)
+        return dict(u=u, x=x, y=y, status=status, iters=iters)
+
+    def assemble(self, x0, x_ref, foot, contact, pcom=None):
+        """QP data in the scaled variables: dict(P (B,n,n), q (B,n), l (B,m), u (B,m))."""
+        N, n, m = self.N, self.n, self.m
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B = x0.size // NX
+        x0 = _as(x0, np.float64, (B, NX), "x0")
+        x_ref = _as(x_ref, np.float64, (B, N, NX), "x_ref")
+        foot = _as(foot, np.float64, (B, N, NU), "foot")
+        contact = _as(np.asarray(contact) != 0, np.uint8, (B, N, NC), "contact")
+        pcom = None if pcom is None else _as(pcom, np.float64, (B, N, 3), "pcom")
+        P = np.empty((B, n, n)); q = np.empty((B, n)); lo = np.empty((B, m)); hi = np.empty((B, m))
+        rc = self._lib.srbdqp_assemble_f64(self._h, B, _ptr(x0), _ptr(x_ref), _ptr(foot), _ptr(contact), _ptr(pcom),
+                                           _ptr(P), _ptr(q), _ptr(lo), _ptr(hi))
+        _lib.check(rc, self._h)
+        return dict(P=P, q=q, l=lo, u=hi)
+
+    # -- device-buffer API -----------------------------------------------------------------------------
+    def solve_device(self, B, x0, x_ref, foot, contact, u_out, x_out=0, y_out=0, status=0, iters=0, pcom=0,
+                     warm_u=0, warm_y=0, stream=0):
+        """Enqueue a solve on HBM-resident buffers.  Every argument is a raw device address (int), e.g.
+        ``tensor.data_ptr()``; 0 = absent.  ``stream`` is a hipStream_t address (0 = the handle's own stream).
+        Does not synchronise."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        rc = self._lib.srbdqp_solve_batch_device_f64(self._h, int(B), v(x0), v(x_ref), v(foot), v(contact), v(pcom),
+                                                     v(warm_u), v(warm_y), v(u_out), v(x_out), v(y_out), v(status),
+                                                     v(iters), v(stream))
+        _lib.check(rc, self._h)
+
+    def synchronize(self):
+        _lib.check(self._lib.srbdqp_synchronize(self._h), self._h)
+
+    def last_kernel_ms(self) -> float:
+        return float(self._lib.srbdqp_last_kernel_ms(self._h))
+
+    def kernel_name(self) -> str:
+        return self._lib.srbdqp_kernel_name(self._h).decode()
+
+
+class MPC:
+    """Drop-in for ``srbd_mpc.mpc.MPC`` on the hot path (run_simulation.py:169-170,73-82,96,103,106)."""
+
+    def __init__(self, dt: float = 0.04, horizon: int = 10, device: int = 0, warm_start: bool = True, **overrides):
+        self.dt = float(dt)
+        self.HORIZON_LENGTH = int(horizon)
+        self.g = -9.80665                       # ros_run_simulation.py:58
+        self.x0 = np.zeros((NX, 1))
+        self.x0[12] = self.g
+        self.x_ref_hor = np.zeros((self.HORIZON_LENGTH, NX))
+        self.x_ref_hor[:, 12] = self.g
+        self.warm_start = bool(warm_start)
+        self._device = device
+        self._overrides = overrides
+        self._engine: Optional[BatchMPC] = None
+        self._warm = None
+        self.u_opt = None                       # (N, 12) last optimal forces [N]
+        self.x_opt = None                       # (N+1, 13) last roll-out
+        self.status = 0
+        self.iters = 0
+
+    def init_matrices(self):
+        """Allocate the engine (stream + device workspace).  run_simulation.py:170."""
+        if self._engine is None:
+            self._engine = BatchMPC(horizon=self.HORIZON_LENGTH, dt=self.dt, device=self._device, **self._overrides)
+        return self
+
+    def solve(self, x_current, x_ref_hor, c_horizon, contact_horizon, p_com_horizon=None):
+        """Assemble + solve one QP on the GPU; returns (u (N,12) newtons, x (N+1,13))."""
+        if self._engine is None:
+            self.init_matrices()
+        N = self.HORIZON_LENGTH
+        x0 = np.asarray(x_current, dtype=np.float64).reshape(1, NX)
+        xr = np.asarray(x_ref_hor, dtype=np.float64).reshape(1, N, NX)
+        ft = np.asarray(c_horizon, dtype=np.float64).reshape(1, N, NU)
+        ct = np.asarray(contact_horizon).reshape(1, N, NC)
+        pc = None if p_com_horizon is None else np.asarray(p_com_horizon, dtype=np.float64).reshape(1, N, 3)
+        wu, wy = (None, None)
+        if self.warm_start and self._warm is not None:
+            wu, wy = self._warm
+        out = self._engine.solve(x0, xr, ft, ct, pcom=pc, warm_u=wu, warm_y=wy, want_x=True, want_y=self.warm_start)
+        self.status = int(out["status"][0])
+        self.iters = int(out["iters"][0])
+        self.u_opt = out["u"][0]
+        self.x_opt = out["x"][0]
+        if self.warm_start and self.status in (_lib.SOLVED, _lib.MAX_ITER):
+            # shift the plan one step: next call's u_k starts from this call's u_{k+1}
+            u_shift = np.vstack([self.u_opt[1:], self.u_opt[-1:]]).reshape(1, -1)
+            y = out["y"].reshape(N, _lib.ROWS_PER_STEP)
+            y_shift = np.vstack([y[1:], y[-1:]]).reshape(1, -1)
+            self._warm = (u_shift, y_shift)
+        else:
+            self._warm = None
+        return self.u_opt, self.x_opt
+
+    def update(self, contact_horizon: Sequence, c_horizon: Sequence, p_com_horizon, x_current=None,
+               one_rollout: bool = True):
+        """run_simulation.py:106.  Returns (u_opt0 (12,1), x_opt1) where x_opt1[1] is the next state.
+        one_rollout=True -> x_opt1 has the whole roll-out (N+1, 13); False -> only rows 0..1."""
+        x_cur = self.x0 if x_current is None else x_current
+        u, x = self.solve(x_cur, self.x_ref_hor, c_horizon, contact_horizon, p_com_horizon)
+        u_opt0 = u[0].reshape(NU, 1).copy()
+        x_opt1 = x.copy() if one_rollout else x[:2].copy()
+        return u_opt0, x_opt1
+
+    def reset_warm_start(self):
+        self._warm = None
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None

@@ -1,0 +1,145 @@
+/* srbdqp.h -- C-ABI of the MI355X-native batched SRBD convex-MPC QP engine.
+ *
+ * This is the drop-in boundary for the hot path of ioloizou/g1_locomotion: the per-control-step
+ * body of `srbd_mpc.mpc.MPC.update(...)` (reference call site
+ * g1_mujoco_sim/src/run_simulation.py:106; node `mpc_to_wbid_node`,
+ * g1_mujoco_sim/launch/mpc_wbid_simulation.launch:6).  The reference has NO FFI for this path (it is a
+ * duck-typed Python object, run_simulation.py:169-170,73-82,96,103,106), so these entry points are what a
+ * ctypes binding of that object binds; each cites the reference interface it stands behind.
+ *
+ * Conventions (all evidenced on the reference's call sites):
+ *   state  x[13] = roll pitch yaw | com xyz | omega xyz | v_com xyz | g      run_simulation.py:73-77
+ *   input  u[12] = f_Lheel f_Ltoe f_Rheel f_Rtoe, world xyz each             ros_run_simulation.py:65,214-215
+ *   arrays are C-contiguous row-major; the library keeps no caller pointer after a call returns;
+ *   one handle <-> one HIP stream <-> one calling thread at a time (the reference is single threaded,
+ *   run_simulation.py:135-153).
+ *
+ * Error convention: every function returns 0 on success, a negative SRBDQP_E_* code on failure (never
+ * throws); srbdqp_last_error() gives the text.  Per-QP solver outcome comes back in status[]/iters[].
+ * There is NO CPU fallback: if no HIP device is usable srbdqp_create fails with SRBDQP_E_NO_DEVICE.
+ */
+#ifndef SRBDQP_H
+#define SRBDQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRBDQP_NX 13
+#define SRBDQP_NU 12
+#define SRBDQP_NC 4
+#define SRBDQP_ROWS_PER_STEP 20   /* 4 contacts x (4 friction-pyramid rows + 1 normal-force row) */
+#define SRBDQP_MAX_HORIZON 12     /* fp64 kernels are instantiated for N in {8, 10, 12} */
+
+/* return codes */
+#define SRBDQP_OK 0
+#define SRBDQP_E_INVALID   (-1)   /* bad argument (null pointer, unsupported horizon, ...) */
+#define SRBDQP_E_NO_DEVICE (-2)   /* no usable HIP device: there is no CPU fallback */
+#define SRBDQP_E_HIP       (-3)   /* a HIP runtime call failed */
+#define SRBDQP_E_NOMEM     (-4)
+
+/* per-QP status[] values */
+#define SRBDQP_SOLVED    1        /* primal and dual residual below tolerance */
+#define SRBDQP_MAX_ITER  2        /* iteration cap reached; best iterate returned */
+#define SRBDQP_NUMERICAL (-1)     /* non-finite residual */
+
+/* srbdqp_config.flags */
+#define SRBDQP_FLAG_TIMING 1      /* bracket every kernel launch with HIP events (srbdqp_last_kernel_ms) */
+
+/* srbdqp_config.kernel: which implementation of the hot path runs */
+#define SRBDQP_KERNEL_AUTO  0     /* the fastest parity-green kernel */
+#define SRBDQP_KERNEL_GJ    1     /* v0: VALU assembly + in-LDS Gauss-Jordan inverse */
+#define SRBDQP_KERNEL_MFMA  2     /* v1: fp64-MFMA contraction + tiled Cholesky inverse */
+
+/* Everything `MPC.__init__(dt)` / `MPC.init_matrices()` hold (run_simulation.py:169-170).  Values the
+ * reference keeps inside the absent module are this build's documented choices. */
+typedef struct srbdqp_config {
+    int32_t struct_size;          /* = sizeof(srbdqp_config), ABI check */
+    int32_t horizon;              /* HORIZON_LENGTH (run_simulation.py:96) */
+    int32_t device;               /* HIP device ordinal */
+    int32_t flags;
+    int32_t kernel;               /* SRBDQP_KERNEL_* */
+    int32_t max_iter;
+    int32_t check_every;
+    int32_t reserved0;
+    double dt;                    /* run_simulation.py:169 */
+    double mass;                  /* wbid.py:291 model.getMass() */
+    double inertia[3];            /* wbid.py:261-266 torso inertia diagonal */
+    double mu;                    /* wbid.py:17 */
+    double fz_min, fz_max;        /* wbid.py:123-124 */
+    double q_diag[SRBDQP_NX];     /* state tracking weights */
+    double r_diag;                /* force regularisation */
+    double force_scale;           /* u = force_scale * u_hat */
+    double rho, rho_eq_scale, sigma, alpha, eps_abs, eps_rel;   /* ADMM (OSQP Algorithm 1) */
+} srbdqp_config;
+
+typedef struct srbdqp_handle srbdqp_handle;
+
+/* Fill *cfg with the defaults (N=10, dt=0.04, G1 constants, ADMM constants). */
+int srbdqp_default_config(srbdqp_config* cfg);
+
+/* ~ MPC(dt) + MPC.init_matrices() (run_simulation.py:169-170): allocate stream + workspace. */
+int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out);
+int srbdqp_destroy(srbdqp_handle* h);
+const char* srbdqp_last_error(const srbdqp_handle* h);   /* h may be NULL: last create() error */
+
+/* ~ MPC.update(contact_horizon, c_horizon, p_com_horizon, x_current, one_rollout) for B independent
+ * QPs (run_simulation.py:106).  HOST buffers; H2D/D2H copies happen inside on the handle's stream and
+ * the call returns after the results are in the output buffers.
+ *   x0      [B][13]        current state (MPC.x0, run_simulation.py:73-77)
+ *   x_ref   [B][N][13]     MPC.x_ref_hor (run_simulation.py:80-82); column 2 is the linearisation yaw
+ *   foot    [B][N][12]     c_horizon (run_simulation.py:94-97), world frame
+ *   contact [B][N][4]      contact_horizon (run_simulation.py:100-101), nonzero = in contact
+ *   pcom    [B][N][3]      p_com_horizon (run_simulation.py:103); NULL -> x_ref[:, :, 3:6]
+ *   warm_u  [B][12N]       optional warm start (newtons), NULL = cold start from 0
+ *   warm_y  [B][20N]       optional dual warm start, NULL = 0
+ *   u_out   [B][N][12]     optimal forces in newtons; u_out[b][0] is u_opt0 (run_simulation.py:111)
+ *   x_out   [B][N+1][13]   state roll-out, row 0 = x0, row 1 = x_opt1[1] (run_simulation.py:111), may be NULL
+ *   y_out   [B][20N]       dual solution (for warm starts), may be NULL
+ *   status  [B], iters[B]  per-QP outcome, may be NULL
+ */
+int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B,
+                           const double* x0, const double* x_ref, const double* foot,
+                           const uint8_t* contact, const double* pcom,
+                           const double* warm_u, const double* warm_y,
+                           double* u_out, double* x_out, double* y_out,
+                           int32_t* status, int32_t* iters);
+
+/* Same, DEVICE buffers (HBM-resident, e.g. torch tensors' data_ptr()).  Enqueued on `stream`
+ * (a hipStream_t; NULL = the handle's own stream); returns without synchronising. */
+int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B,
+                                  const double* x0, const double* x_ref, const double* foot,
+                                  const uint8_t* contact, const double* pcom,
+                                  const double* warm_u, const double* warm_y,
+                                  double* u_out, double* x_out, double* y_out,
+                                  int32_t* status, int32_t* iters, void* stream);
+
+/* ~ the QP-assembly half of MPC.update (what init_matrices() allocates: H, g, cone rows).  HOST
+ * buffers, for parity tests of linearise/condense/H/g/bounds.  Scaled variables u_hat.
+ *   P_out [B][12N][12N]   Hessian H = Bs' Q Bs + R s^2        q_out [B][12N]   gradient
+ *   l_out, ub_out [B][20N] constraint bounds (rows 20k+5i+j; +-1e30 = unbounded)
+ */
+int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B,
+                        const double* x0, const double* x_ref, const double* foot,
+                        const uint8_t* contact, const double* pcom,
+                        double* P_out, double* q_out, double* l_out, double* ub_out);
+
+/* Block until everything enqueued on the handle's stream is done. */
+int srbdqp_synchronize(srbdqp_handle* h);
+
+/* With SRBDQP_FLAG_TIMING: device time (HIP events on the launch stream) of the most recent solve's
+ * kernel launch, in milliseconds; synchronises that event.  Negative if unavailable. */
+double srbdqp_last_kernel_ms(srbdqp_handle* h);
+
+/* Name of the kernel variant the last solve launched ("gj_f64_n10", "mfma_f64_n10", ...). */
+const char* srbdqp_kernel_name(const srbdqp_handle* h);
+
+/* Library version / build string. */
+const char* srbdqp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRBDQP_H */
