@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- QP solves/sec of the SRBD convex-MPC hot path on MI355X (BASELINE.json's metric).
+
+A "step" = one pass of the hot path (linearise -> condense -> H,g,cone rows -> factor -> ADMM -> rollout) over one
+batch of synthetic QPs whose inputs are already resident in HBM.  Workload at every N: BASELINE.json configs[1]
+(B = 4096 random SRBD states per GPU, horizon 10, 2-contact alternating single support, fp64); with N > 1 ranks
+each rank owns its own 4096 QPs (weak scaling, no data-path collective) and the first-step contact forces
+u_opt0 are all-gathered over RCCL/xGMI every step, as north_star specifies.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline`: fp64 dense peak (78.6 TFLOP/s per MI355X, vector == matrix rate) against
+the ALGORITHMIC flops of SURVEY.md section 8(d), W(N, K) with K = the measured mean ADMM iteration count.
+`cpu_baseline`: oracle/srbd_oracle.c (a plain-C port of the same algorithm; the reference's own implementation is
+an absent submodule) timed on this node's host cores on a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HORIZON = 10
+BATCH_PER_GPU = 4096
+PEAK_FP64_TFLOPS = 78.6          # MI355X dense fp64 (vector == MFMA rate), SURVEY.md section 8(d)
+
+
+def algorithmic_flops(N: int, K: float) -> float:
+    """W(N, K) flops per QP."""
+    n, s, m = 12 * N, 13 * N, 20 * N
+    return (500 * N + 2 * 13 ** 3 * N + N * (N + 1) / 2 * 2 * 13 * 13 * 12 + s * n * n
+            + (2 * s * 13 + 2 * s * n) + n ** 3 / 3 + K * (2 * n * n + 10 * m))
+
+
+def algorithmic_bytes(N: int) -> int:
+    """HBM bytes per QP, fp64 (inputs + outputs)."""
+    return (13 + 13 * N + 12 * N) * 8 + 4 * N + (12 * N + 13 * (N + 1)) * 8 + 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="QPs per GPU per step (default: configs[1])")
+    ap.add_argument("--kernel", choices=["auto", "gj", "mfma"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the hot path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from g1_locomotion_amd import BatchMPC, _lib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))   # synthetic-input generator lives with the oracle
+    import srbd_oracle as orc
+
+    N, B = HORIZON, args.batch
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=1000 * 2 + rank, schedule="single")
+    dev = torch.device("cuda", local_rank)
+    d_x0 = torch.from_numpy(x0).to(dev)
+    d_xr = torch.from_numpy(xr).to(dev)
+    d_ft = torch.from_numpy(ft).to(dev)
+    d_ct = torch.from_numpy(ct).to(dev)
+    d_u = torch.empty((B, N, 12), dtype=torch.float64, device=dev)
+    d_x = torch.empty((B, N + 1, 13), dtype=torch.float64, device=dev)
+    d_st = torch.empty(B, dtype=torch.int32, device=dev)
+    d_it = torch.empty(B, dtype=torch.int32, device=dev)
+    d_u0_all = torch.empty((world, B, 12), dtype=torch.float64, device=dev) if world > 1 else None
+
+    kid = {"auto": _lib.KERNEL_AUTO, "gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA}[args.kernel]
+    eng = BatchMPC(horizon=N, device=local_rank, kernel=kid)
+    # a non-default stream: the C-ABI treats a NULL stream as "the handle's own", and the HIP events that time the
+    # kernel must sit on the stream the kernel is launched on
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+
+    def step():
+        eng.solve_device(B, d_x0.data_ptr(), d_xr.data_ptr(), d_ft.data_ptr(), d_ct.data_ptr(), d_u.data_ptr(),
+                         x_out=d_x.data_ptr(), status=d_st.data_ptr(), iters=d_it.data_ptr(), stream=stream.cuda_stream)
+
+    def exchange():
+        if dist is not None:
+            u0 = d_u[:, 0, :].contiguous()
+            dist.all_gather_into_tensor(d_u0_all.view(world * B, 12), u0)
+
+    for _ in range(args.warmup):
+        step()
+        exchange()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+        exchange()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps > 0 else float("nan")
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    iters = d_it.cpu().numpy()
+    status = d_st.cpu().numpy()
+    mean_iters = float(iters.mean())
+    solved_frac = float((status == _lib.SOLVED).mean())
+
+    if rank == 0:
+        total_qp = world * B * args.steps
+        value = total_qp / elapsed
+        flops_launch = algorithmic_flops(N, mean_iters) * B
+        achieved_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
+        hbm_gbs = algorithmic_bytes(N) * B / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "QP solves/sec, SRBD N=10 12-state/12-input",
+            "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch={B}/GPU random SRBD states, N={N}, 2-contact alternating single "
+                                   f"support friction cone, fp64; u_opt0 all-gather over RCCL when n_gpus>1",
+                       "horizon": N, "batch_per_gpu": B, "kernel": eng.kernel_name(),
+                       "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
+                       "eps_abs": eng.cfg.eps_abs, "eps_rel": eng.cfg.eps_rel},
+            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": None,
+                         "kernel": eng.kernel_name(), "kernel_ms": kernel_ms,
+                         "algorithmic_flops_per_qp": algorithmic_flops(N, mean_iters),
+                         "hbm_algorithmic_GBps": hbm_gbs, "hbm_frac_of_8TBps": hbm_gbs / 8000.0},
+        }
+        if world == 1 and not args.no_latency:
+            out["latency_batch1"] = latency_batch1(orc)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(orc, x0, xr, ft, ct)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def latency_batch1(orc, calls=2000):
+    """p50/p99 of single-QP calls through the Python MPC.update() path (ctypes + H2D + kernel + D2H)."""
+    from g1_locomotion_amd import MPC
+    x0, xr, ft, ct = orc.synthetic_batch(64, HORIZON, seed=99, schedule="single")
+    out = {}
+    for warm in (False, True):
+        mpc = MPC(dt=0.04, horizon=HORIZON, warm_start=warm)
+        mpc.init_matrices()
+        ts = []
+        for i in range(calls + 50):
+            b = i % 64
+            mpc.x_ref_hor[:] = xr[b]
+            t = time.perf_counter()
+            mpc.update(list(ct[b]), list(ft[b]), xr[b][:, 3:6], x_current=x0[b].reshape(13, 1), one_rollout=True)
+            ts.append(time.perf_counter() - t)
+        ts = np.array(ts[50:]) * 1e6
+        out["warm" if warm else "cold"] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
+        mpc.close()
+    out["note"] = "warm: x/y warm-started from the previous call of a different QP (shifted plan), cold: from zero"
+    return out
+
+
+def cpu_baseline(orc, x0, xr, ft, ct):
+    """oracle/srbd_oracle.c on this node's host cores, bounded sample of the same batch."""
+    import c_oracle
+    p = orc.SrbdParams()
+    cores = len(os.sched_getaffinity(0))
+    S1 = min(1024, x0.shape[0])
+    t = time.perf_counter()
+    c_oracle.solve_batch(p, x0[:S1], xr[:S1], ft[:S1], ct[:S1], nthreads=1)
+    t1 = time.perf_counter() - t
+    Sall = x0.shape[0]
+    t = time.perf_counter()
+    c_oracle.solve_batch(p, x0[:Sall], xr[:Sall], ft[:Sall], ct[:Sall], nthreads=cores)
+    tall = time.perf_counter() - t
+    return {"value": Sall / tall, "unit": "QP/s", "cores": cores, "kind": "port",
+            "sample": f"{Sall} QPs of the rank-0 batch on {cores} threads (plain-C port oracle/srbd_oracle.c, gcc -O3 -mavx2)",
+            "single_thread_value": S1 / t1, "single_thread_sample": f"first {S1} QPs, 1 thread",
+            "single_thread_p50_us": 1e6 * t1 / S1}
+
+
+if __name__ == "__main__":
+    main()

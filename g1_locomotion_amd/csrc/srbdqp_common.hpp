@@ -84,9 +84,9 @@ struct Smem {
 // ---------------------------------------------------------------------------------------------------------
 // a5: load inputs (coalesced), linearise every horizon step
 // ---------------------------------------------------------------------------------------------------------
-template <int N>
+template <int N, class L>
 __device__ void load_and_linearise(const KArgs& a, int b, double* sm) {
-    using S = Smem<N>;
+    using S = L;
     const int t = threadIdx.x;
     const double* gx0 = a.x0 + (size_t)b * 13;
     const double* gxr = a.xref + (size_t)b * N * 13;
@@ -137,9 +137,9 @@ __device__ void load_and_linearise(const KArgs& a, int b, double* sm) {
 }
 
 // one entry of the (unweighted) condensed input matrix: row kk of block (i, j), column cc; j <= i
-template <int N>
+template <int N, class L>
 __device__ __forceinline__ double bqp_entry(const KArgs& a, const double* sm, int i, int kk, int j, int cc) {
-    using S = Smem<N>;
+    using S = L;
     const int ax = cc % 3;
     const double* J = sm + S::o_J + j * 36;
     if (kk < 3) {
@@ -160,7 +160,7 @@ __device__ __forceinline__ double bqp_entry(const KArgs& a, const double* sm, in
 // a6: condensation.  G = Q^1/2 * s * B_qp without the (all-zero) gravity rows, packed block-lower-triangular:
 // row k = 12 i + kk holds columns 0 .. 12 (i+1) - 1 at g_row_off(i, kk).
 // ---------------------------------------------------------------------------------------------------------
-template <int N>
+template <int N, class L>
 __device__ void build_G(const KArgs& a, const double* sm, double* G) {
     const int t = threadIdx.x;
     for (int idx = t; idx < Dims<N>::gtot; idx += kThreads) {
@@ -170,14 +170,14 @@ __device__ void build_G(const KArgs& a, const double* sm, double* G) {
         const int len = 12 * (i + 1);
         const int kk = rem / len, c = rem - kk * len;
         const int j = c / 12, cc = c - 12 * j;
-        G[idx] = a.sqrtq[kk] * a.s * bqp_entry<N>(a, sm, i, kk, j, cc);
+        G[idx] = a.sqrtq[kk] * a.s * bqp_entry<N, L>(a, sm, i, kk, j, cc);
     }
 }
 
 // free response (A_qp x0) entry for predicted state x_{i+1}, dynamic component kk (0..11)
-template <int N>
+template <int N, class L>
 __device__ __forceinline__ double free_response(const KArgs& a, const double* sm, int i, int kk) {
-    using S = Smem<N>;
+    using S = L;
     const double* x0 = sm + S::o_x0;
     if (kk < 3) {
         const double* C = sm + S::o_cp + i * 9 + kk * 3;
@@ -198,14 +198,14 @@ __device__ __forceinline__ double free_response(const KArgs& a, const double* sm
 // ---------------------------------------------------------------------------------------------------------
 // a7 (gradient half): q = G' * Q^1/2 (A_qp x0 - x_ref)
 // ---------------------------------------------------------------------------------------------------------
-template <int N>
+template <int N, class L>
 __device__ void build_gradient(const KArgs& a, double* sm, const double* G) {
-    using S = Smem<N>;
+    using S = L;
     constexpr int n = Dims<N>::n;
     const int t = threadIdx.x;
     for (int k = t; k < n; k += kThreads) {
         const int i = k / 12, kk = k - 12 * i;
-        sm[S::o_eh + k] = a.sqrtq[kk] * (free_response<N>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
+        sm[S::o_eh + k] = a.sqrtq[kk] * (free_response<N, L>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
     }
     __syncthreads();
     for (int c = t; c < n; c += kThreads) {
@@ -224,9 +224,9 @@ __device__ void build_gradient(const KArgs& a, double* sm, const double* G) {
 // ---------------------------------------------------------------------------------------------------------
 struct RowInfo { int v0; int j; double lo, hi, rho; };
 
-template <int N>
+template <int N, class L>
 __device__ __forceinline__ RowInfo row_info(const KArgs& a, const double* sm, int r) {
-    using S = Smem<N>;
+    using S = L;
     const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
     RowInfo ri;
     const int k = r / 20, rr = r - 20 * k, ci = rr / 5;
@@ -260,9 +260,9 @@ __device__ __forceinline__ double apply_At_col(const double* w, int c, double mu
 }
 
 // diagonal of A' diag(rho) A for variable c
-template <int N>
+template <int N, class L>
 __device__ __forceinline__ double rho_diag(const KArgs& a, const double* sm, int c) {
-    using S = Smem<N>;
+    using S = L;
     const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
     const int k = c / 12, cc = c - 12 * k, ci = cc / 3, ax = cc - 3 * ci;
     if (ax < 2) return 2.0 * a.rho;
@@ -291,9 +291,9 @@ __device__ __forceinline__ void block_max(double (&v)[NV], double* red) {
 // a10: roll the linear model forward with the optimal forces and store u (newtons), x horizon, status.
 // xs (LDS, n doubles) holds the scaled solution u_hat.
 // ---------------------------------------------------------------------------------------------------------
-template <int N>
+template <int N, class L>
 __device__ void rollout_and_store(const KArgs& a, int b, double* sm, const double* uh, double* scratch /* >= 6N */) {
-    using S = Smem<N>;
+    using S = L;
     constexpr int n = Dims<N>::n;
     const int t = threadIdx.x;
     for (int c = t; c < n; c += kThreads) a.u_out[(size_t)b * n + c] = a.s * uh[c];
@@ -350,9 +350,9 @@ __device__ void rollout_and_store(const KArgs& a, int b, double* sm, const doubl
 // for operation.  Preconditions: xs = x^0 (scaled), xt = P x^0, q set, and a barrier has passed.
 // On return xs holds the scaled solution, ys the dual; returns the iteration count, *status_out the status.
 // ---------------------------------------------------------------------------------------------------------
-template <int N, int CH>
+template <int N, class L, int CH>
 __device__ int admm_loop(const KArgs& a, int b, double* sm, const double (&kin)[CH], int* status_out) {
-    using S = Smem<N>;
+    using S = L;
     constexpr int n = Dims<N>::n, m = Dims<N>::m, ME = Dims<N>::ME, VE = Dims<N>::VE;
     const int t = threadIdx.x;
     const int r = t >> 1, h = t & 1;
@@ -371,7 +371,7 @@ __device__ int admm_loop(const KArgs& a, int b, double* sm, const double (&kin)[
 #pragma unroll
     for (int e = 0; e < ME; ++e) {
         const int i = t + e * kThreads;
-        ri[e] = row_info<N>(a, sm, i < m ? i : 0);
+        ri[e] = row_info<N, L>(a, sm, i < m ? i : 0);
     }
     double qn[1] = {0.0};
 #pragma unroll

@@ -34,10 +34,10 @@ __global__ __launch_bounds__(kThreads) void srbdqp_gj_kernel(KArgs a) {
     double* G = sm + GS::o_G;
     double* rowbuf = sm + GS::o_row;
 
-    load_and_linearise<N>(a, b, sm);
-    build_G<N>(a, sm, G);
+    load_and_linearise<N, S>(a, b, sm);
+    build_G<N, S>(a, sm, G);
     __syncthreads();
-    build_gradient<N>(a, sm, G);
+    build_gradient<N, S>(a, sm, G);
 
     // ---- a7: Hessian fragments  P[r][c] = sum_k G[k][r] G[k][c]  (+ R s^2 on the diagonal)
     double kf[CH];
@@ -48,10 +48,13 @@ __global__ __launch_bounds__(kThreads) void srbdqp_gj_kernel(KArgs a) {
             const int i = k / 12, kk = k - 12 * i, len = 12 * (i + 1);
             const double* row = G + g_row_off(i, kk);
             const double gr = row[r];
+            // unconditional loads (a read past this row's end lands in a later row of G) + select: keeps the
+            // 60 LDS reads batched instead of one exec-masked branch per element
 #pragma unroll
             for (int cc = 0; cc < CH; ++cc) {
                 const int c = CH * h + cc;
-                if (c < len) kf[cc] = fma(gr, row[c], kf[cc]);
+                const double v = row[c];
+                kf[cc] = fma(gr, (c < len) ? v : 0.0, kf[cc]);
             }
         }
 #pragma unroll
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void srbdqp_gj_kernel(KArgs a) {
         }
         for (int c = t; c < n; c += kThreads) a.q_out[(size_t)b * n + c] = sm[S::o_q + c];
         for (int i = t; i < m; i += kThreads) {
-            const RowInfo ri = row_info<N>(a, sm, i);
+            const RowInfo ri = row_info<N, S>(a, sm, i);
             a.l_out[(size_t)b * m + i] = ri.lo;
             a.ub_out[(size_t)b * m + i] = ri.hi;
         }
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void srbdqp_gj_kernel(KArgs a) {
 
     // ---- K = P + sigma I + A' diag(rho) A, then K^-1 by n symmetric sweeps
     if (r < n) {
-        const double dg = a.sigma + rho_diag<N>(a, sm, r);
+        const double dg = a.sigma + rho_diag<N, S>(a, sm, r);
 #pragma unroll
         for (int cc = 0; cc < CH; ++cc) if (CH * h + cc == r) kf[cc] += dg;
     }
@@ -120,12 +123,12 @@ __global__ __launch_bounds__(kThreads) void srbdqp_gj_kernel(KArgs a) {
     for (int cc = 0; cc < CH; ++cc) kf[cc] = -kf[cc];
 
     int status;
-    const int iters = admm_loop<N, CH>(a, b, sm, kf, &status);
+    const int iters = admm_loop<N, S, CH>(a, b, sm, kf, &status);
     if (t == 0) {
         if (a.status) a.status[b] = status;
         if (a.iters) a.iters[b] = iters;
     }
-    rollout_and_store<N>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+    rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
 }
 
 }  // namespace srbdqp

@@ -1,8 +1,393 @@
-// srbdqp_mfma.hpp -- kernel variant v1 (fp64 MFMA contraction + tiled Cholesky inverse).  Placeholder until built.
+// srbdqp_mfma.hpp -- kernel variant v1 ("mfma"): the condensed-QP hot path on the fp64 matrix cores.
+//
+// One 256-thread workgroup (4 wave64) per QP, 79 KB of LDS (two workgroups per CU), no HBM traffic between the
+// input load and the output store.  All dense n x n work is 16x16 tiles on v_mfma_f64_16x16x4_f64:
+//
+//   H  : K = G'G (+ R s^2 + sigma + A' rho A on the diagonal), G = Q^1/2 s B_qp packed block-lower in LDS; the 36
+//        upper tiles (n = 120 -> 8x8 tiles) accumulate in registers, 9 tiles per wave.          [a7, MFMA contraction]
+//   F  : right-looking Cholesky K = U'U with the trailing tiles resident in registers; per block column one wave
+//        factors the 16x16 diagonal tile (LDL' elimination with the identity riding along in lanes 16..31, so it
+//        directly yields L_jj^-1), the panel is L_jj^-1 K_jb and the trailing update K_ab -= U_ja' U_jb.  [a9 factor]
+//   W  : W = L^-1 row by row, in place over U (W_ij = -W_ii sum_k L_ik W_kj).
+//   I  : K^-1 = W'W, tiles swizzled into LDS, then every thread pulls its row fragment of K^-1 into registers.
+//   ADMM: shared admm_loop() -- the two triangular solves of each iteration are applied as one mat-vec with the
+//        explicit inverse (depth-1 instead of depth-n substitution).                              [a9 iterations]
+//
+// Register tiles are in the MFMA C/D layout (lane l: column l&15, rows (l>>4)+4r, r = 0..3).  Register r of a
+// C-layout tile is exactly the B operand of K-step r of a product that contracts over the tile's ROW index, so
+// chains of tile products (panel, W rows) never leave the register file.  LDS tiles are row-major 16x16; tiles that
+// are read both along rows and along columns (the diagonal inverses, the final K^-1) are XOR-swizzled
+// (col ^ row), which makes both access directions bank-conflict free.
 #pragma once
 #include "srbdqp_common.hpp"
+
 namespace srbdqp {
-constexpr bool kMfmaReady = false;
-template <int N> struct MfmaTraits { static constexpr bool supported = false; static constexpr size_t lds_bytes = 0; static constexpr const char* name = "mfma_unavailable"; };
-template <int N> __global__ void srbdqp_mfma_kernel(KArgs a) {}
+
+constexpr bool kMfmaReady = true;
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int N>
+struct MfmaSmem {
+    static constexpr int n = Dims<N>::n, m = Dims<N>::m;
+    static constexpr int NT = (n + 15) / 16;              // tiles per side
+    static constexpr int NTT = NT * (NT + 1) / 2;         // upper tiles
+    static constexpr int TS = (NTT + 3) / 4;              // tile slots per wave
+    static constexpr int up2(int v) { return (v + 1) & ~1; }
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    // ---- persistent across all phases
+    static constexpr int o_x0 = 0;                        // 13 (+1)
+    static constexpr int o_tm = o_x0 + 14;                // N*9
+    static constexpr int o_J = o_tm + up2(N * 9);         // N*36
+    static constexpr int o_q = o_J + N * 36;              // n
+    static constexpr int o_px0 = o_q + n;                 // n   P x^0 (warm start)
+    static constexpr int o_red = o_px0 + n;               // 64
+    static constexpr int o_ct = o_red + 64;               // contact flags (bytes)
+    static constexpr int o_misc = o_ct + up2((N * 4 + 7) / 8);   // [0] = numerical-failure flag
+    static constexpr int o_R = o_misc + 8;                // ---- the big region, re-used phase by phase
+    // phase A (assembly): G + inputs
+    static constexpr int o_G = o_R;
+    static constexpr int o_xref = o_G + Dims<N>::gtot;
+    static constexpr int o_foot = o_xref + up2(N * 13);
+    static constexpr int o_pcom = o_foot + N * 12;
+    static constexpr int o_cp = o_pcom + up2(N * 3);
+    static constexpr int o_eh = o_cp + up2(N * 9);
+    static constexpr int o_gx = o_eh + n;                 // n   G x^0 (warm start)
+    static constexpr int endA = o_gx + n + 16;            // +16: masked operand reads may run past the last G row
+    // phase B (factor / inverse): tiles
+    static constexpr int o_T = o_R;
+    static constexpr int endB = o_T + NTT * 256;
+    // phase C (ADMM): vectors
+    static constexpr int o_rhs = o_R;
+    static constexpr int o_xt = o_rhs + n + 8;
+    static constexpr int o_w = o_xt + n;
+    static constexpr int o_nu = o_w + m;
+    static constexpr int o_xs = o_nu + m;
+    static constexpr int o_ys = o_xs + n;
+    static constexpr int endC = o_ys + m;
+    static constexpr int o_end = cmax(endA, cmax(endB, endC));
+    static constexpr size_t bytes = (size_t)o_end * sizeof(double);
+};
+
+template <int N>
+struct MfmaTraits {
+    static constexpr bool supported = (12 * N <= 128);
+    static constexpr size_t lds_bytes = MfmaSmem<N>::bytes;
+    static constexpr const char* name = (N == 10) ? "mfma_f64_n10" : (N == 8) ? "mfma_f64_n8" : (N == 4) ? "mfma_f64_n4" : "mfma_f64";
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// index of upper tile (a, b), a <= b
+__device__ __forceinline__ int tile_id(int a, int b) { return (b * (b + 1)) / 2 + a; }
+
+// C-layout register tile -> LDS tile (row-major; swizzled: col ^ row)
+template <bool SWZ>
+__device__ __forceinline__ void store_tile(double* tile, const v4d& v, int lane) {
+    const int col = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = g + 4 * r;
+        tile[row * 16 + (SWZ ? (col ^ row) : col)] = v[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 16x16 diagonal tile: T (SPD, row-major in LDS) -> L^-1 (lower triangular, XOR-swizzled, in place), T = L L'.
+// One wave.  Lanes 0..15 hold column c of T, lanes 16..31 column c of M (starts as I); the LDL' elimination
+// T <- E T applies the same row operations to M, so M ends as Ltilde^-1 (unit lower) for free; L^-1 = D^-1/2 M.
+// Returns false if a pivot is not positive.
+// ---------------------------------------------------------------------------------------------------------
+__device__ bool diag16_invert(double* tile, int lane) {
+    const int c = lane & 15;
+    const bool isT = lane < 16, isM = (lane >= 16) && (lane < 32);
+    double t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const double v = tile[r * 16 + c];            // lanes >= 16 read too (same addresses), then overwrite
+        t[r] = isT ? v : ((r == c) ? 1.0 : 0.0);
+    }
+    double dsave = 1.0;
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const double d = readlane_f64(t[p], p);       // pivot T[p][p] lives in lane p
+        ok = ok && (d > 0.0);
+        const double rd = 1.0 / d;
+        if (lane == p) dsave = d;
+        const double lvec = t[p] * rd;                // lane r (< 16): l_rp = T[p][r] / d
+#pragma unroll
+        for (int r = p + 1; r < 16; ++r) {
+            const double lr = readlane_f64(lvec, r);
+            t[r] = fma(-lr, t[p], t[r]);              // T rows in lanes 0..15, M rows in lanes 16..31
+        }
+    }
+    const double rsv = 1.0 / sqrt(dsave);             // lane p: d_p^-1/2
+    // everyone is done reading the tile (single wave, in order) -> overwrite with L^-1, swizzled
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const double rs = readlane_f64(rsv, r);
+        const double v = (r >= c) ? t[r] * rs : 0.0;
+        if (isM) tile[r * 16 + (c ^ r)] = v;
+    }
+    return ok;
+}
+
+template <int N>
+__global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    using S = MfmaSmem<N>;
+    constexpr int n = Dims<N>::n, m = Dims<N>::m, CH = n / 2;
+    constexpr int NT = S::NT, NTT = S::NTT, TS = S::TS;
+    static_assert(n <= 128, "mfma variant: two threads per row of K^-1, n <= 128");
+    static_assert(NT <= 8, "W phase assumes at most two tiles per wave per block row");
+    static_assert((S::o_rhs % 2) == 0 && (CH % 2) == 0 && (S::o_R % 2) == 0, "16-byte alignment");
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int mcol = lane & 15, kq = lane >> 4;       // MFMA operand coordinates of this lane
+    double* G = sm + S::o_G;
+    double* T = sm + S::o_T;
+
+    // ================= phase A: linearise, condense, gradient =================
+    load_and_linearise<N, S>(a, b, sm);
+    build_G<N, S>(a, sm, G);
+    if (t == 0) sm[S::o_misc] = 0.0;
+    __syncthreads();
+    build_gradient<N, S>(a, sm, G);
+    if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0 while G is still around
+        for (int k = t; k < n; k += kThreads) {
+            const int i = k / 12, kk = k - 12 * i, len = 12 * (i + 1);
+            const double* row = G + g_row_off(i, kk);
+            double acc = 0.0;
+            for (int c = 0; c < len; ++c) acc = fma(row[c], a.warm_u[(size_t)b * n + c] / a.s, acc);
+            sm[S::o_gx + k] = acc;
+        }
+        __syncthreads();
+        for (int c = t; c < n; c += kThreads) {
+            double acc = a.rs2 * (a.warm_u[(size_t)b * n + c] / a.s);
+            for (int k = 12 * (c / 12); k < n; ++k) {
+                const int i = k / 12, kk = k - 12 * i;
+                acc = fma(G[g_row_off(i, kk) + c], sm[S::o_gx + k], acc);
+            }
+            sm[S::o_px0 + c] = acc;
+        }
+    } else {
+        for (int c = t; c < n; c += kThreads) sm[S::o_px0 + c] = 0.0;
+    }
+
+    // tile slots of this wave: slot s <-> upper tile id 4 s + w
+    int ta[TS], tb[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int id = 4 * s + w;
+        int bb = 0;
+        while (((bb + 1) * (bb + 2)) / 2 <= id) ++bb;
+        tb[s] = (id < NTT) ? bb : -1;
+        ta[s] = (id < NTT) ? id - (bb * (bb + 1)) / 2 : -1;
+    }
+
+    // ================= phase H: K tiles = G'G on the fp64 matrix cores =================
+    v4d acc[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (ta[s] >= 0) {
+            const int ca = 16 * ta[s] + mcol, cb = 16 * tb[s] + mcol;
+            for (int i = (16 * tb[s]) / 12; i < N; ++i) {
+                const int len = 12 * (i + 1);
+                const double* base = G + 72 * i * (i + 1) + len * kq;
+#pragma unroll
+                for (int kk0 = 0; kk0 < 12; kk0 += 4) {
+                    const double* row = base + len * kk0;
+                    double av = row[ca], bv = row[cb];
+                    av = (ca < len) ? av : 0.0;
+                    bv = (cb < len) ? bv : 0.0;
+                    acc[s] = mfma_f64(av, bv, acc[s]);
+                }
+            }
+            if (ta[s] == tb[s]) {   // diagonal tile: + R s^2 + sigma + A' rho A; padding rows/cols -> identity
+                const int var = 16 * ta[s] + mcol;
+                const double dv = (var < n) ? a.rs2 + a.sigma + rho_diag<N, S>(a, sm, var < n ? var : 0) : 1.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (kq + 4 * r == mcol) acc[s][r] += dv;
+            }
+        }
+    }
+    __syncthreads();   // G is dead from here on; region R becomes the tile store
+
+    // ================= phase F: tiled right-looking Cholesky K = U'U, trailing tiles in registers =================
+    for (int j = 0; j < NT; ++j) {
+        double* Djj = T + tile_id(j, j) * 256;
+#pragma unroll
+        for (int s = 0; s < TS; ++s)
+            if (ta[s] == j && tb[s] == j) store_tile<false>(Djj, acc[s], lane);
+        __syncthreads();
+        if (w == (j & 3)) {
+            const bool ok = diag16_invert(Djj, lane);
+            if (!ok && lane == 0) sm[S::o_misc] = 1.0;
+        }
+        __syncthreads();
+        // panel: U_jb = L_jj^-1 K_jb
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            if (ta[s] == j && tb[s] > j) {
+                v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double av = Djj[mcol * 16 + (k ^ mcol)];      // L_jj^-1[m][k], k <= m
+                    av = (k <= mcol) ? av : 0.0;
+                    o = mfma_f64(av, acc[s][r], o);
+                }
+                acc[s] = o;
+                store_tile<false>(T + tile_id(j, tb[s]) * 256, o, lane);
+            }
+        }
+        __syncthreads();
+        // trailing update: K_ab -= U_ja' U_jb
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            if (ta[s] > j) {
+                const double* Ua = T + tile_id(j, ta[s]) * 256;
+                const double* Ub = T + tile_id(j, tb[s]) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    acc[s] = mfma_f64(-Ua[k * 16 + mcol], Ub[k * 16 + mcol], acc[s]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================= phase W: W = L^-1 (L = U'), block row by block row, in place over U =================
+    for (int i = 1; i < NT; ++i) {
+        v4d res[2];
+        const double* Dii = T + tile_id(i, i) * 256;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = w + 4 * q;
+            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (j < i) {
+                v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
+                {   // k = j:  L_ij W_jj
+                    const double* Uji = T + tile_id(j, i) * 256;
+                    const double* Djj = T + tile_id(j, j) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * r + kq;
+                        double bv = Djj[k * 16 + (mcol ^ k)];     // W_jj[k][n], n <= k
+                        bv = (mcol <= k) ? bv : 0.0;
+                        o = mfma_f64(Uji[k * 16 + mcol], bv, o);
+                    }
+                }
+                for (int k2 = j + 1; k2 < i; ++k2) {   // L_ik W_kj
+                    const double* Uki = T + tile_id(k2, i) * 256;
+                    const double* Wkj = T + tile_id(j, k2) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * r + kq;
+                        o = mfma_f64(Uki[k * 16 + mcol], Wkj[k * 16 + mcol], o);
+                    }
+                }
+                v4d o2 = (v4d){0.0, 0.0, 0.0, 0.0};     // W_ij = -W_ii * (sum)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double av = Dii[mcol * 16 + (k ^ mcol)];
+                    av = (k <= mcol) ? -av : 0.0;
+                    o2 = mfma_f64(av, o[r], o2);
+                }
+                res[q] = o2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = w + 4 * q;
+            if (j < i) store_tile<false>(T + tile_id(j, i) * 256, res[q], lane);
+        }
+        __syncthreads();
+    }
+
+    // ================= phase I: K^-1 = W'W =================
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (ta[s] >= 0) {
+            const int ia = ta[s], ib = tb[s];
+            const double* Dbb = T + tile_id(ib, ib) * 256;
+            {   // i = ib
+                const double* Wba = T + tile_id(ia, ib) * 256;     // only read when ia < ib
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double dv = Dbb[k * 16 + (mcol ^ k)];          // W_bb[k][.], lower
+                    dv = (mcol <= k) ? dv : 0.0;
+                    const double av = (ia < ib) ? Wba[k * 16 + mcol] : dv;
+                    acc[s] = mfma_f64(av, dv, acc[s]);
+                }
+            }
+            for (int i = ib + 1; i < NT; ++i) {
+                const double* Wia = T + tile_id(ia, i) * 256;
+                const double* Wib = T + tile_id(ib, i) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    acc[s] = mfma_f64(Wia[k * 16 + mcol], Wib[k * 16 + mcol], acc[s]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TS; ++s)
+        if (ta[s] >= 0) store_tile<true>(T + tile_id(ta[s], tb[s]) * 256, acc[s], lane);
+    __syncthreads();
+
+    // row fragment of K^-1 for the ADMM mat-vec: thread (r, h) owns K^-1[r][CH h .. CH h + CH - 1]
+    const int r = t >> 1, h = t & 1;
+    double kin[CH];
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        const int c = CH * h + cc;
+        const int rr = (r < n) ? r : n - 1;               // keep the address of idle threads inside the tile store
+        const int lo = (rr <= c) ? rr : c, hi = (rr <= c) ? c : rr;
+        const int row = lo & 15, col = hi & 15;
+        const double v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
+        kin[cc] = (r < n) ? v : 0.0;
+    }
+    const bool failed = sm[S::o_misc] != 0.0;
+    __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
+
+    for (int c = t; c < n; c += kThreads) {
+        sm[S::o_xs + c] = a.warm_u ? a.warm_u[(size_t)b * n + c] / a.s : 0.0;
+        sm[S::o_xt + c] = sm[S::o_px0 + c];
+    }
+    __syncthreads();
+
+    int status = -1, iters = 0;
+    if (!failed) iters = admm_loop<N, S, CH>(a, b, sm, kin, &status);
+    else {
+        for (int c = t; c < n; c += kThreads) sm[S::o_xs + c] = 0.0;
+        if (a.y_out) for (int i = t; i < m; i += kThreads) a.y_out[(size_t)b * m + i] = 0.0;
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (a.status) a.status[b] = status;
+        if (a.iters) a.iters[b] = iters;
+    }
+    rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+}
+
 }  // namespace srbdqp

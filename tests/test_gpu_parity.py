@@ -55,6 +55,7 @@ def test_solve_matches_oracle_and_exact_optimum(torch_first, built_lib, kernel, 
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=200 + N, schedule=schedule)
     with _engine(N, kernel=kid) as eng:
         out = eng.solve(x0, xr, ft, ct, want_y=True)
+        assert eng.kernel_name().startswith("gj_" if kernel == "gj" else "mfma_"), eng.kernel_name()
     p = orc.SrbdParams()
     for b in range(B):
         ref = orc.update(p, x0[b], xr[b], ft[b], ct[b])
