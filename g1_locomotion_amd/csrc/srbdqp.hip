@@ -25,6 +25,7 @@ struct srbdqp_handle {
     size_t ws_bytes = 0;
     std::string err;
     const char* kname = "none";
+    long long* stamps = nullptr;   // diagnostic stamp buffer (device), see srbdqp_set_stamp_buffer
 };
 
 namespace {
@@ -216,6 +217,12 @@ const char* srbdqp_last_error(const srbdqp_handle* h) { return h ? h->err.c_str(
 
 const char* srbdqp_kernel_name(const srbdqp_handle* h) { return h ? h->kname : "none"; }
 
+int srbdqp_set_stamp_buffer(srbdqp_handle* h, void* device_ptr) {
+    if (!h) return SRBDQP_E_INVALID;
+    h->stamps = reinterpret_cast<long long*>(device_ptr);
+    return SRBDQP_OK;
+}
+
 int srbdqp_synchronize(srbdqp_handle* h) {
     if (!h) return SRBDQP_E_INVALID;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -243,7 +250,7 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
     a.x0 = x0; a.xref = x_ref; a.foot = foot; a.contact = contact; a.pcom = pcom;
     a.warm_u = warm_u; a.warm_y = warm_y;
     a.u_out = u_out; a.x_out = x_out; a.y_out = y_out; a.status = status; a.iters = iters;
-    a.B = B; a.mode = 0;
+    a.B = B; a.mode = 0; a.stamps = h->stamps;
     return launch(h, a, stream ? reinterpret_cast<hipStream_t>(stream) : h->stream);
 }
 

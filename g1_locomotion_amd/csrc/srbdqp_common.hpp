@@ -34,6 +34,7 @@ struct KArgs {
     double* q_out;           // [B][n]
     double* l_out;           // [B][m]
     double* ub_out;          // [B][m]
+    long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null
     int32_t B;
     int32_t mode;            // 0 = solve, 1 = assemble only
     int32_t max_iter, check_every;
@@ -42,6 +43,9 @@ struct KArgs {
     double rs2;              // r_diag * s^2
     double rho, rho_eq, sigma, alpha, eps_abs, eps_rel;
 };
+
+// diagnostic phase stamp (thread 0 only; leaves the kernel through a buffer nothing else reads)
+#define SRBDQP_STAMP(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 template <int N>
 struct Dims {
@@ -78,7 +82,8 @@ struct Smem {
     static constexpr int o_red = o_ys + m;                  // 8*8   block reductions
     static constexpr int o_ct = o_red + 64;                 // N*4 bytes of contact flags (as doubles: N/2)
     static constexpr int o_misc = o_ct + up2((N * 4 + 7) / 8);
-    static constexpr int o_end = o_misc + 8;
+    static constexpr int o_sq = o_misc + 8;                 // 12    sqrt(q_diag) (lane-indexed reads must not hit the kernarg segment)
+    static constexpr int o_end = o_sq + 12;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -94,6 +99,7 @@ __device__ void load_and_linearise(const KArgs& a, int b, double* sm) {
     const uint8_t* gct = a.contact + (size_t)b * N * 4;
     uint8_t* sct = reinterpret_cast<uint8_t*>(sm + S::o_ct);
     if (t < 13) sm[S::o_x0 + t] = gx0[t];
+    if (t >= 32 && t < 44) sm[S::o_sq + t - 32] = a.sqrtq[t - 32];
     for (int i = t; i < N * 13; i += kThreads) sm[S::o_xref + i] = gxr[i];
     for (int i = t; i < N * 12; i += kThreads) sm[S::o_foot + i] = gft[i];
     if (t < N * 4) sct[t] = gct[t] ? 1 : 0;
@@ -158,19 +164,52 @@ __device__ __forceinline__ double bqp_entry(const KArgs& a, const double* sm, in
 
 // ---------------------------------------------------------------------------------------------------------
 // a6: condensation.  G = Q^1/2 * s * B_qp without the (all-zero) gravity rows, packed block-lower-triangular:
-// row k = 12 i + kk holds columns 0 .. 12 (i+1) - 1 at g_row_off(i, kk).
+// row k = 12 i + kk holds columns 0 .. 12 (i+1) - 1 at g_row_off(i, kk).  One entry per thread and step, block by
+// block (block = 12 x 12 entries of B_qp(i, j), j <= i); every LDS load is unconditional and the four row classes
+// (theta / p / omega / v) are selected arithmetically, so a wave never diverges.
 // ---------------------------------------------------------------------------------------------------------
 template <int N, class L>
-__device__ void build_G(const KArgs& a, const double* sm, double* G) {
+__device__ void build_G(const KArgs& a, double* sm, double* G) {
+    using S = L;
+    constexpr int NBLK = N * (N + 1) / 2;
     const int t = threadIdx.x;
-    for (int idx = t; idx < Dims<N>::gtot; idx += kThreads) {
+    // block table: blk -> (i, j), j <= i  (kept in the reduction scratch; done with it before anyone reduces)
+    int* tab = reinterpret_cast<int*>(sm + S::o_red);
+    if (t < NBLK) {
         int i = 0;
-        while (72 * (i + 1) * (i + 2) <= idx) ++i;
-        const int rem = idx - 72 * i * (i + 1);
-        const int len = 12 * (i + 1);
-        const int kk = rem / len, c = rem - kk * len;
-        const int j = c / 12, cc = c - 12 * j;
-        G[idx] = a.sqrtq[kk] * a.s * bqp_entry<N, L>(a, sm, i, kk, j, cc);
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        tab[t] = (i << 8) | (t - i * (i + 1) / 2);
+    }
+    __syncthreads();
+    // thread = (block group g of 3, row-pair type, rr, cc): type 0 writes the theta row rr and the omega row rr of
+    // a block, type 1 the p row rr and the v row rr; all index arithmetic is hoisted out of the block loop
+    const int g = t / 72, u = t - 72 * g;
+    const int type = u / 36, v = u - 36 * type;
+    const int rr = v / 12, cc = v - 12 * rr, ax = cc % 3;
+    const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = a.dt * a.dt * a.inv_mass;
+    const double wA = sm[S::o_sq + (type ? 3 : 0) + rr] * a.s;      // weight of the first row of the pair
+    const double wB = sm[S::o_sq + (type ? 9 : 6) + rr] * a.s;      // ... of the second
+    const int rowA = (type ? 3 : 0) + rr, rowB = (type ? 9 : 6) + rr;
+    if (g < 3) {
+        for (int blk = g; blk < NBLK; blk += 3) {
+            const int ij = tab[blk], i = ij >> 8, j = ij & 255;
+            const int len = 12 * (i + 1);
+            double* dst = G + 72 * i * (i + 1) + 12 * j + cc;
+            double vA, vB;
+            if (type == 0) {
+                const double* J = sm + S::o_J + j * 36 + cc;
+                const double* Ci = sm + S::o_cp + i * 9 + rr * 3;
+                const double* Cj = sm + S::o_cp + j * 9 + rr * 3;
+                const double j0 = J[0], j1 = J[12], j2 = J[24];
+                vA = dt2 * ((Ci[0] - Cj[0]) * j0 + (Ci[1] - Cj[1]) * j1 + (Ci[2] - Cj[2]) * j2);
+                vB = dt * ((rr == 0) ? j0 : (rr == 1) ? j1 : j2);
+            } else {
+                vA = (rr == ax) ? (double)(i - j) * dt2m : 0.0;
+                vB = (rr == ax) ? dtm : 0.0;
+            }
+            dst[len * rowA] = wA * vA;
+            dst[len * rowB] = wB * vB;
+        }
     }
 }
 
@@ -196,26 +235,40 @@ __device__ __forceinline__ double free_response(const KArgs& a, const double* sm
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// a7 (gradient half): q = G' * Q^1/2 (A_qp x0 - x_ref)
+// a7 (gradient half): q = G' * Q^1/2 (A_qp x0 - x_ref).  Two threads per column (even / odd rows of every block row).
 // ---------------------------------------------------------------------------------------------------------
 template <int N, class L>
 __device__ void build_gradient(const KArgs& a, double* sm, const double* G) {
     using S = L;
     constexpr int n = Dims<N>::n;
+    static_assert(2 * n <= kThreads, "two threads per column");
     const int t = threadIdx.x;
     for (int k = t; k < n; k += kThreads) {
         const int i = k / 12, kk = k - 12 * i;
-        sm[S::o_eh + k] = a.sqrtq[kk] * (free_response<N, L>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
+        sm[S::o_eh + k] = sm[S::o_sq + kk] * (free_response<N, L>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
     }
     __syncthreads();
-    for (int c = t; c < n; c += kThreads) {
-        double acc = 0.0;
-        for (int k = 12 * (c / 12); k < n; ++k) {
-            const int i = k / 12, kk = k - 12 * i;
-            acc += G[g_row_off(i, kk) + c] * sm[S::o_eh + k];
+    const int c = t >> 1, h = t & 1;
+    double acc = 0.0;
+    if (c < n) {
+        for (int i = c / 12; i < N; ++i) {
+            const int len = 12 * (i + 1);
+            const double* col = G + 72 * i * (i + 1) + len * h + c;
+            const double* e = sm + S::o_eh + 12 * i + h;
+            double p0 = col[0] * e[0], p1 = col[2 * len] * e[2], p2 = col[4 * len] * e[4];
+            p0 = fma(col[6 * len], e[6], p0);
+            p1 = fma(col[8 * len], e[8], p1);
+            p2 = fma(col[10 * len], e[10], p2);
+            acc += (p0 + p1) + p2;
         }
-        sm[S::o_q + c] = acc;
     }
+    {   // sum the two halves (lanes 2c, 2c+1)
+        int lo = __double2loint(acc), hi = __double2hiint(acc);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+        acc += __hiloint2double(hi, lo);
+    }
+    if (c < n && h == 0) sm[S::o_q + c] = acc;
     __syncthreads();
 }
 

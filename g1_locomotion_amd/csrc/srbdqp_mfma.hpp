@@ -20,10 +20,17 @@
 // (col ^ row), which makes both access directions bank-conflict free.
 #pragma once
 #include "srbdqp_common.hpp"
+#include "srbdqp_admm.hpp"
 
 namespace srbdqp {
 
 constexpr bool kMfmaReady = true;
+
+#ifdef SRBDQP_PROFILE_F
+#define F_T(var) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = (long long)t_; } while (0)
+#else
+#define F_T(var) do { } while (0)
+#endif
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -48,7 +55,8 @@ struct MfmaSmem {
     static constexpr int o_red = o_px0 + n;               // 64
     static constexpr int o_ct = o_red + 64;               // contact flags (bytes)
     static constexpr int o_misc = o_ct + up2((N * 4 + 7) / 8);   // [0] = numerical-failure flag
-    static constexpr int o_R = o_misc + 8;                // ---- the big region, re-used phase by phase
+    static constexpr int o_sq = o_misc + 8;               // 12  sqrt(q_diag)
+    static constexpr int o_R = o_sq + 12;                 // ---- the big region, re-used phase by phase
     // phase A (assembly): G + inputs
     static constexpr int o_G = o_R;
     static constexpr int o_xref = o_G + Dims<N>::gtot;
@@ -61,14 +69,10 @@ struct MfmaSmem {
     // phase B (factor / inverse): tiles
     static constexpr int o_T = o_R;
     static constexpr int endB = o_T + NTT * 256;
-    // phase C (ADMM): vectors
-    static constexpr int o_rhs = o_R;
-    static constexpr int o_xt = o_rhs + n + 8;
-    static constexpr int o_w = o_xt + n;
-    static constexpr int o_nu = o_w + m;
-    static constexpr int o_xs = o_nu + m;
-    static constexpr int o_ys = o_xs + n;
-    static constexpr int endC = o_ys + m;
+    // phase C (ADMM): double-buffered rhs + the solution vector
+    static constexpr int o_rhs = o_R;                     // 2 x (n + 8)
+    static constexpr int o_xs = o_rhs + 2 * (n + 8);      // n
+    static constexpr int endC = o_xs + n;
     static constexpr int o_end = cmax(endA, cmax(endB, endC));
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
 };
@@ -106,7 +110,51 @@ __device__ __forceinline__ void store_tile(double* tile, const v4d& v, int lane)
 // T <- E T applies the same row operations to M, so M ends as Ltilde^-1 (unit lower) for free; L^-1 = D^-1/2 M.
 // Returns false if a pivot is not positive.
 // ---------------------------------------------------------------------------------------------------------
-__device__ bool diag16_invert(double* tile, int lane) {
+// 1/d to full double precision without the IEEE division sequence (d is a positive, normal pivot):
+// v_rcp_f64 seed + two Newton steps.
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
+// One elimination step, P compile-time so that every t[] index is static.  The multipliers l_rP (one per lane)
+// reach the other lanes two ways: the one on the critical path (row P+1, which produces the next pivot) by
+// v_readlane, all the others by an LDS all-gather (one ds_write_b64 + broadcast ds_read_b128s) whose latency hides
+// behind the next pivot's reciprocal chain.  `scr` = 16 doubles of LDS scratch private to this wave.
+template <int P>
+__device__ __forceinline__ void diag16_step(double (&t)[16], double& dsave, bool& ok, double rd, int lane, double* scr) {
+    const double lvec = t[P] * rd;                    // lane r (< 16): l_rP = T[P][r] / d_P
+    if constexpr (P < 14) {
+        if (lane < 16) scr[lane] = lvec;
+        asm volatile("" ::: "memory");             // the double2 reads below must not be hoisted above this store
+    }
+    double rd_next = 0.0;
+    if constexpr (P < 15) {
+        const double l1 = readlane_f64(lvec, P + 1);
+        t[P + 1] = fma(-l1, t[P], t[P + 1]);
+        const double dn = readlane_f64(t[P + 1], P + 1);   // next pivot
+        ok = ok && (dn > 0.0);
+        dsave = (lane == P + 1) ? dn : dsave;
+        rd_next = fast_rcp(dn);
+    }
+    if constexpr (P < 14) {
+        constexpr int R0 = (P + 2) & ~1;              // first 16-byte aligned pair that holds a needed row
+        double2 lv[(16 - R0) / 2];
+#pragma unroll
+        for (int q = 0; q < (16 - R0) / 2; ++q) lv[q] = reinterpret_cast<const double2*>(scr + R0)[q];
+#pragma unroll
+        for (int r = P + 2; r < 16; ++r) {
+            const double lr = ((r - R0) & 1) ? lv[(r - R0) >> 1].y : lv[(r - R0) >> 1].x;
+            t[r] = fma(-lr, t[P], t[r]);              // T rows in lanes 0..15, M rows in lanes 16..31
+        }
+    }
+    if constexpr (P < 15) diag16_step<P + 1>(t, dsave, ok, rd_next, lane, scr);
+}
+
+__device__ __forceinline__ bool diag16_invert(double* tile, int lane) {
     const int c = lane & 15;
     const bool isT = lane < 16, isM = (lane >= 16) && (lane < 32);
     double t[16];
@@ -115,29 +163,28 @@ __device__ bool diag16_invert(double* tile, int lane) {
         const double v = tile[r * 16 + c];            // lanes >= 16 read too (same addresses), then overwrite
         t[r] = isT ? v : ((r == c) ? 1.0 : 0.0);
     }
-    double dsave = 1.0;
-    bool ok = true;
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const double d = readlane_f64(t[p], p);       // pivot T[p][p] lives in lane p
-        ok = ok && (d > 0.0);
-        const double rd = 1.0 / d;
-        if (lane == p) dsave = d;
-        const double lvec = t[p] * rd;                // lane r (< 16): l_rp = T[p][r] / d
-#pragma unroll
-        for (int r = p + 1; r < 16; ++r) {
-            const double lr = readlane_f64(lvec, r);
-            t[r] = fma(-lr, t[p], t[r]);              // T rows in lanes 0..15, M rows in lanes 16..31
-        }
-    }
+    asm volatile("" ::: "memory");
+    // the tile now lives in registers: its LDS words are free scratch until the final store
+    const double d0 = readlane_f64(t[0], 0);
+    double dsave = (lane == 0) ? d0 : 1.0;
+    bool ok = d0 > 0.0;
+    diag16_step<0>(t, dsave, ok, fast_rcp(d0), lane, tile);
     const double rsv = 1.0 / sqrt(dsave);             // lane p: d_p^-1/2
-    // everyone is done reading the tile (single wave, in order) -> overwrite with L^-1, swizzled
+    if (lane < 16) tile[lane] = rsv;
+    asm volatile("" ::: "memory");
+    double2 rs2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rs2[q] = reinterpret_cast<const double2*>(tile)[q];
+    double vout[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const double rs = readlane_f64(rsv, r);
-        const double v = (r >= c) ? t[r] * rs : 0.0;
-        if (isM) tile[r * 16 + (c ^ r)] = v;
+        const double rs = (r & 1) ? rs2[r >> 1].y : rs2[r >> 1].x;
+        vout[r] = (r >= c) ? t[r] * rs : 0.0;
     }
+    asm volatile("" ::: "memory");
+    // overwrite the tile with L^-1, swizzled (all reads of the scratch words are done: same wave, in order)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) if (isM) tile[r * 16 + (c ^ r)] = vout[r];
     return ok;
 }
 
@@ -159,11 +206,16 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
     double* T = sm + S::o_T;
 
     // ================= phase A: linearise, condense, gradient =================
+    SRBDQP_STAMP(a, b, 0);
+    if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime();
     load_and_linearise<N, S>(a, b, sm);
+    SRBDQP_STAMP(a, b, 1);
     build_G<N, S>(a, sm, G);
     if (t == 0) sm[S::o_misc] = 0.0;
     __syncthreads();
+    SRBDQP_STAMP(a, b, 2);
     build_gradient<N, S>(a, sm, G);
+    SRBDQP_STAMP(a, b, 3);
     if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0 while G is still around
         for (int k = t; k < n; k += kThreads) {
             const int i = k / 12, kk = k - 12 * i, len = 12 * (i + 1);
@@ -223,20 +275,27 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
             }
         }
     }
+    SRBDQP_STAMP(a, b, 4);
     __syncthreads();   // G is dead from here on; region R becomes the tile store
+    SRBDQP_STAMP(a, b, 5);
 
     // ================= phase F: tiled right-looking Cholesky K = U'U, trailing tiles in registers =================
+    long long fs0 = 0, fs1 = 0, fs2 = 0, fs3 = 0, ft0 = 0, ft1 = 0, ft2 = 0, ft3 = 0, ft4 = 0;
+    (void)fs0; (void)fs1; (void)fs2; (void)fs3; (void)ft0; (void)ft1; (void)ft2; (void)ft3; (void)ft4;
     for (int j = 0; j < NT; ++j) {
         double* Djj = T + tile_id(j, j) * 256;
+        F_T(ft0);
 #pragma unroll
         for (int s = 0; s < TS; ++s)
             if (ta[s] == j && tb[s] == j) store_tile<false>(Djj, acc[s], lane);
         __syncthreads();
+        F_T(ft1);
         if (w == (j & 3)) {
             const bool ok = diag16_invert(Djj, lane);
             if (!ok && lane == 0) sm[S::o_misc] = 1.0;
         }
         __syncthreads();
+        F_T(ft2);
         // panel: U_jb = L_jj^-1 K_jb
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
@@ -254,6 +313,7 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
             }
         }
         __syncthreads();
+        F_T(ft3);
         // trailing update: K_ab -= U_ja' U_jb
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
@@ -267,9 +327,15 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
                 }
             }
         }
+        F_T(ft4);
+        fs0 += ft1 - ft0; fs1 += ft2 - ft1; fs2 += ft3 - ft2; fs3 += ft4 - ft3;
     }
+#ifdef SRBDQP_PROFILE_F
+    if (a.stamps && t == 0) { a.stamps[(size_t)b * 16 + 12] = fs0; a.stamps[(size_t)b * 16 + 13] = fs1; a.stamps[(size_t)b * 16 + 14] = fs2; a.stamps[(size_t)b * 16 + 15] = fs3; }
+#endif
     __syncthreads();
 
+    SRBDQP_STAMP(a, b, 6);
     // ================= phase W: W = L^-1 (L = U'), block row by block row, in place over U =================
     for (int i = 1; i < NT; ++i) {
         v4d res[2];
@@ -320,6 +386,7 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
         __syncthreads();
     }
 
+    SRBDQP_STAMP(a, b, 7);
     // ================= phase I: K^-1 = W'W =================
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
@@ -355,29 +422,26 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
         if (ta[s] >= 0) store_tile<true>(T + tile_id(ta[s], tb[s]) * 256, acc[s], lane);
     __syncthreads();
 
-    // row fragment of K^-1 for the ADMM mat-vec: thread (r, h) owns K^-1[r][CH h .. CH h + CH - 1]
-    const int r = t >> 1, h = t & 1;
+    SRBDQP_STAMP(a, b, 8);
+    // row fragment of K^-1 for the ADMM mat-vec: thread (row rr, half h) owns K^-1[rr][CH h .. CH h + CH - 1];
+    // rows are dealt to lanes contact by contact (srbdqp_admm.hpp)
+    const int rown = admm_row_of_thread<N>(t), h = t & 1;
     double kin[CH];
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
         const int c = CH * h + cc;
-        const int rr = (r < n) ? r : n - 1;               // keep the address of idle threads inside the tile store
+        const int rr = (rown >= 0) ? rown : 0;            // keep the address of idle threads inside the tile store
         const int lo = (rr <= c) ? rr : c, hi = (rr <= c) ? c : rr;
         const int row = lo & 15, col = hi & 15;
         const double v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
-        kin[cc] = (r < n) ? v : 0.0;
+        kin[cc] = (rown >= 0) ? v : 0.0;
     }
     const bool failed = sm[S::o_misc] != 0.0;
     __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
 
-    for (int c = t; c < n; c += kThreads) {
-        sm[S::o_xs + c] = a.warm_u ? a.warm_u[(size_t)b * n + c] / a.s : 0.0;
-        sm[S::o_xt + c] = sm[S::o_px0 + c];
-    }
-    __syncthreads();
-
+    SRBDQP_STAMP(a, b, 9);
     int status = -1, iters = 0;
-    if (!failed) iters = admm_loop<N, S, CH>(a, b, sm, kin, &status);
+    if (!failed) iters = admm_loop_local<N, S, CH>(a, b, sm, sm + S::o_rhs, sm + S::o_xs, kin, &status);
     else {
         for (int c = t; c < n; c += kThreads) sm[S::o_xs + c] = 0.0;
         if (a.y_out) for (int i = t; i < m; i += kThreads) a.y_out[(size_t)b * m + i] = 0.0;
@@ -387,7 +451,12 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
         if (a.status) a.status[b] = status;
         if (a.iters) a.iters[b] = iters;
     }
+    SRBDQP_STAMP(a, b, 10);
     rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+    SRBDQP_STAMP(a, b, 11);
+#if !defined(SRBDQP_PROFILE_F) && !defined(SRBDQP_PROFILE_ADMM)
+    if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 }  // namespace srbdqp

@@ -126,6 +126,10 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B,
                         const uint8_t* contact, const double* pcom,
                         double* P_out, double* q_out, double* l_out, double* ub_out);
 
+/* Diagnostic: device buffer [B][16] of int64 that subsequent solves fill with per-QP s_memtime stamps of the kernel's
+ * phase boundaries (100 MHz constant clock); NULL switches stamping off.  Not part of the drop-in surface. */
+int srbdqp_set_stamp_buffer(srbdqp_handle* h, void* device_ptr);
+
 /* Block until everything enqueued on the handle's stream is done. */
 int srbdqp_synchronize(srbdqp_handle* h);
 
