@@ -16,9 +16,9 @@ ROWS_PER_STEP = 20
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
-SOLVED, MAX_ITER, NUMERICAL = 1, 2, -1
+SOLVED, MAX_ITER, NUMERICAL, CONTACT_BOUND = 1, 2, -1, -2
 FLAG_TIMING = 1
-KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA = 0, 1, 2
+KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT = 0, 1, 2, 3
 
 EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",
@@ -35,7 +35,7 @@ class Config(C.Structure):
     """struct srbdqp_config (include/srbdqp.h)."""
     _fields_ = [
         ("struct_size", C.c_int32), ("horizon", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
-        ("kernel", C.c_int32), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("reserved0", C.c_int32),
+        ("kernel", C.c_int32), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("max_contacts_per_step", C.c_int32),
         ("dt", C.c_double), ("mass", C.c_double), ("inertia", C.c_double * 3), ("mu", C.c_double),
         ("fz_min", C.c_double), ("fz_max", C.c_double), ("q_diag", C.c_double * NX), ("r_diag", C.c_double),
         ("force_scale", C.c_double), ("rho", C.c_double), ("rho_eq_scale", C.c_double), ("sigma", C.c_double),

@@ -12,11 +12,13 @@
 #include "srbdqp_common.hpp"
 #include "srbdqp_gj.hpp"
 #include "srbdqp_mfma.hpp"
+#include "srbdqp_compact.hpp"
 
 using srbdqp::KArgs;
 
 struct srbdqp_handle {
     srbdqp_config cfg;
+    int maxs_override = 0;         // set by the host-buffer API after scanning the contact flags
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -46,7 +48,7 @@ bool horizon_supported(int N) { return N == 8 || N == 10 || N == 12 || N == 4; }
 int resolve_kernel(const srbdqp_config& c) {
     if (c.kernel == SRBDQP_KERNEL_GJ) return SRBDQP_KERNEL_GJ;
     if (c.kernel == SRBDQP_KERNEL_MFMA) return SRBDQP_KERNEL_MFMA;
-    return srbdqp::kMfmaReady ? SRBDQP_KERNEL_MFMA : SRBDQP_KERNEL_GJ;
+    return SRBDQP_KERNEL_COMPACT;
 }
 
 void fill_args(const srbdqp_config& c, KArgs& a) {
@@ -69,27 +71,46 @@ void fill_args(const srbdqp_config& c, KArgs& a) {
     a.eps_rel = c.eps_rel;
 }
 
+template <typename K>
+int set_lds_once(srbdqp_handle* h, K kernel, size_t lds, bool& done) {
+    if (!done) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+    return SRBDQP_OK;
+}
+
+template <int N, int MAXS>
+int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
+    constexpr size_t lds = srbdqp::CompactTraits<N, MAXS>::lds_bytes;
+    static bool attr_set = false;
+    int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS>, lds, attr_set);
+    if (rc != SRBDQP_OK) return rc;
+    static const std::string nm = "compact_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
+    h->kname = nm.c_str();
+    hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), lds, st, a);
+    return SRBDQP_OK;
+}
+
 template <int N>
-int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int variant) {
+int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int variant, int maxs) {
     const dim3 grid((unsigned)a.B), block(srbdqp::kThreads);
-    if (variant == SRBDQP_KERNEL_MFMA && srbdqp::MfmaTraits<N>::supported) {
+    int rc = SRBDQP_OK;
+    if (variant == SRBDQP_KERNEL_COMPACT) {
+        rc = (maxs <= 2) ? launch_compact<N, 2>(h, a, st) : launch_compact<N, 4>(h, a, st);
+        if (rc != SRBDQP_OK) return rc;
+    } else if (variant == SRBDQP_KERNEL_MFMA && srbdqp::MfmaTraits<N>::supported) {
         constexpr size_t lds = srbdqp::MfmaTraits<N>::lds_bytes;
         static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&srbdqp::srbdqp_mfma_kernel<N>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        rc = set_lds_once(h, &srbdqp::srbdqp_mfma_kernel<N>, lds, attr_set);
+        if (rc != SRBDQP_OK) return rc;
         h->kname = srbdqp::MfmaTraits<N>::name;
         hipLaunchKernelGGL(srbdqp::srbdqp_mfma_kernel<N>, grid, block, lds, st, a);
     } else {
         constexpr size_t lds = srbdqp::GjSmem<N>::bytes;
         static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&srbdqp::srbdqp_gj_kernel<N>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        rc = set_lds_once(h, &srbdqp::srbdqp_gj_kernel<N>, lds, attr_set);
+        if (rc != SRBDQP_OK) return rc;
         static const std::string nm = "gj_f64_n" + std::to_string(N);
         h->kname = nm.c_str();
         hipLaunchKernelGGL(srbdqp::srbdqp_gj_kernel<N>, grid, block, lds, st, a);
@@ -98,16 +119,16 @@ int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int variant) {
     return SRBDQP_OK;
 }
 
-int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
+int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4) {
     if (a.B <= 0) return SRBDQP_OK;
     const int variant = (a.mode == 1) ? SRBDQP_KERNEL_GJ : resolve_kernel(h->cfg);
     const bool timing = (h->cfg.flags & SRBDQP_FLAG_TIMING) != 0;
     if (timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
     int rc;
     switch (h->cfg.horizon) {
-        case 4: rc = launch_n<4>(h, a, st, variant); break;
-        case 8: rc = launch_n<8>(h, a, st, variant); break;
-        case 10: rc = launch_n<10>(h, a, st, variant); break;
+        case 4: rc = launch_n<4>(h, a, st, variant, maxs); break;
+        case 8: rc = launch_n<8>(h, a, st, variant, maxs); break;
+        case 10: rc = launch_n<10>(h, a, st, variant, maxs); break;
         default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
     }
     if (rc != SRBDQP_OK) return rc;
@@ -174,7 +195,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if (cfg->struct_size != (int32_t)sizeof(srbdqp_config)) { g_create_err = "srbdqp_config.struct_size mismatch"; return SRBDQP_E_INVALID; }
     if (!horizon_supported(cfg->horizon) || cfg->horizon > 10) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10})"; return SRBDQP_E_INVALID; }
     if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) ||
-        cfg->max_iter < 1 || cfg->check_every < 1 || !(cfg->mu >= 0)) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
+        cfg->max_iter < 1 || cfg->check_every < 1 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -251,7 +272,8 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
     a.warm_u = warm_u; a.warm_y = warm_y;
     a.u_out = u_out; a.x_out = x_out; a.y_out = y_out; a.status = status; a.iters = iters;
     a.B = B; a.mode = 0; a.stamps = h->stamps;
-    return launch(h, a, stream ? reinterpret_cast<hipStream_t>(stream) : h->stream);
+    int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
+    return launch(h, a, stream ? reinterpret_cast<hipStream_t>(stream) : h->stream, maxs);
 }
 
 int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,
@@ -289,7 +311,17 @@ int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B, const double* x0, const 
     if (pcom) HIP_TRY(h, hipMemcpyAsync(dpc, pcom, b * N * 3 * 8, hipMemcpyHostToDevice, st));
     if (warm_u) HIP_TRY(h, hipMemcpyAsync(dwu, warm_u, b * n * 8, hipMemcpyHostToDevice, st));
     if (warm_y) HIP_TRY(h, hipMemcpyAsync(dwy, warm_y, b * m * 8, hipMemcpyHostToDevice, st));
+    if (h->cfg.max_contacts_per_step <= 0) {   // pick the kernel instantiation from the batch's own contact flags
+        int worst = 0;
+        for (size_t q = 0; q < b * N && worst <= 2; ++q) {
+            const uint8_t* c = contact + 4 * q;
+            const int cnt = (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
+            if (cnt > worst) worst = cnt;
+        }
+        h->maxs_override = (worst <= 2) ? 2 : 4;
+    }
     rc = srbdqp_solve_batch_device_f64(h, B, dx0, dxr, dft, dct, dpc, dwu, dwy, du, dx, dy, dst, dit, st);
+    h->maxs_override = 0;
     if (rc != SRBDQP_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(u_out, du, b * n * 8, hipMemcpyDeviceToHost, st));
     if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, dx, b * (N + 1) * 13 * 8, hipMemcpyDeviceToHost, st));

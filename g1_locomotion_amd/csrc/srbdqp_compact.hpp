@@ -1,0 +1,567 @@
+// srbdqp_compact.hpp -- kernel variant v2 ("compact"): v1's fp64-MFMA pipeline on the PRESOLVED QP.
+//
+// Presolve = fixed-variable elimination: a swing contact's force is clamped to zero by its constraint rows, so its
+// 3 variables and 5 rows are dropped before anything dense is built.  With na stance contact points over the
+// horizon the QP has n_eff = 3 na variables and 5 na rows (2-contact single support: n_eff = 6 N instead of 12 N):
+// 4x less Hessian / factor work, a 4x smaller ADMM mat-vec, and (measured on the oracle) a much shorter tail of
+// slow-converging QPs, because the rho_eq-weighted clamp rows no longer ill-condition K.
+//
+// Template parameter MAXS = bound on stance contact points per horizon step (2 = single support classes,
+// 4 = anything): it sizes LDS (G has at most 3 MAXS (i+1) columns in block row i) and the register tile slots.
+// A QP that violates the bound is reported with status SRBDQP_CONTACT_BOUND, never silently mis-solved.
+//
+// Compact ordering: stance contacts sorted by (step, contact index) -> e = 0..na-1; variable 3e+ax, row 5e+j.
+// Because the order is by step, G restricted to the compact columns is still block lower triangular and all of
+// v1's machinery (packed G rows, masked MFMA operand reads, register-resident tiled Cholesky, in-place W, K^-1)
+// carries over with run-time tile counts.
+#pragma once
+#include "srbdqp_common.hpp"
+#include "srbdqp_admm.hpp"
+#include "srbdqp_mfma.hpp"
+
+namespace srbdqp {
+
+constexpr int kStatusContactBound = -2;
+
+template <int N, int MAXS>
+struct CompactSmem {
+    static constexpr int n = Dims<N>::n, m = Dims<N>::m;
+    static constexpr int NCMAX = MAXS * N;                // stance contacts over the horizon
+    static constexpr int nmax = 3 * NCMAX;                // compact variables
+    static constexpr int NT = (nmax + 15) / 16;
+    static constexpr int NTT = NT * (NT + 1) / 2;
+    static constexpr int TS = (NTT + 3) / 4;
+    static constexpr int CHMAX = 2 * ((nmax + 3) / 4);    // columns per mat-vec half (even)
+    static constexpr int gmax = 36 * MAXS * (N * (N + 1) / 2);
+    static constexpr int up2(int v) { return (v + 1) & ~1; }
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    // ---- persistent
+    static constexpr int o_x0 = 0;
+    static constexpr int o_tm = o_x0 + 14;
+    static constexpr int o_J = o_tm + up2(N * 9);
+    static constexpr int o_q = o_J + N * 36;              // nmax (compact gradient)
+    static constexpr int o_px0 = o_q + up2(nmax);         // nmax
+    static constexpr int o_red = o_px0 + up2(nmax);       // 64
+    static constexpr int o_ct = o_red + 64;
+    static constexpr int o_misc = o_ct + up2((N * 4 + 7) / 8);
+    static constexpr int o_sq = o_misc + 8;
+    static constexpr int o_int = o_sq + 12;               // ints: cnt[N], rowbase[N], na, flags; bytes: act[4N]
+    static constexpr int o_R = o_int + up2((2 * N + 8) / 2 + (4 * N + 7) / 8 + 1);
+    // phase A
+    static constexpr int o_G = o_R;
+    static constexpr int o_xref = o_G + gmax;
+    static constexpr int o_foot = o_xref + up2(N * 13);
+    static constexpr int o_pcom = o_foot + N * 12;
+    static constexpr int o_cp = o_pcom + up2(N * 3);
+    static constexpr int o_eh = o_cp + up2(N * 9);
+    static constexpr int o_gx = o_eh + n;                 // n (row space): G x^0
+    static constexpr int o_x0c = o_gx + n;                // nmax: compact warm start
+    static constexpr int endA = o_x0c + up2(nmax) + 16;
+    // phase B
+    static constexpr int o_T = o_R;
+    static constexpr int endB = o_T + NTT * 256;
+    // phase C
+    static constexpr int o_rhs = o_R;                     // 2 x (2 CHMAX + 8)
+    static constexpr int o_xs = o_rhs + 2 * (2 * CHMAX + 8);   // n (full variable vector, for the roll-out)
+    static constexpr int endC = o_xs + n;
+    static constexpr int o_end = cmax(endA, cmax(endB, endC));
+    static constexpr size_t bytes = (size_t)o_end * sizeof(double);
+};
+
+// The presolved ADMM: same iteration as admm_loop_local(), on the compact contacts.  Wave w owns compact contacts
+// [w CPW, (w+1) CPW), CPW = ceil(na / 4) <= 10.
+template <int N, class L, int CHMAX>
+__device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsbuf, double* xs_full,
+                                 const double (&kin)[CHMAX], int na, int CH, const uint8_t* act, int* status_out) {
+    using S = L;
+    constexpr int n = Dims<N>::n, m = Dims<N>::m;
+    constexpr int RB = 2 * CHMAX + 8;                  // one rhs buffer
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int lr = lane >> 1, h = lane & 1;
+    const int CPW = (na + 3) >> 2;
+    const int cg = lr / 3, ax = lr - 3 * cg;
+    const int e = w * CPW + cg;
+    const bool active = (cg < CPW) && (e < na);
+    const int base = 6 * cg;
+    const int gc = active ? act[e] : 0;                // original contact index 4 k + ci
+    const int r = active ? 3 * e + ax : 0;             // compact variable
+    const bool has_row = active && (ax < 2 || h == 0);
+    const int j = (ax < 2) ? 2 * ax + h : 4;
+    const int irow = 5 * gc + j;                       // original row index (for warm_y / y_out)
+    const double sigma = a.sigma, alpha = a.alpha, mu = a.mu;
+    double* red = sm + S::o_red;
+    const double lo = (j < 4) ? -kInf : a.fzmin_s, hi = (j < 4) ? 0.0 : a.fzmax_s;
+    const double rho = a.rho, irho = 1.0 / rho;
+    const double sgn = (j < 4 && h == 1) ? -1.0 : 1.0;
+    const double muc = (j < 4) ? mu : 0.0;
+    const double rowm = has_row ? 1.0 : 0.0;
+
+    auto At = [&](double v) -> double {
+        const double other = dpp_swap1(v);
+        const double s = v + other;
+        const double s01 = bperm_f64(s, base + 0), s23 = bperm_f64(s, base + 2);
+        const double d = (h == 0) ? v - other : other - v;
+        return (ax < 2) ? d : fma(-mu, s01 + s23, s);
+    };
+    auto Arow = [&](double v) -> double {
+        const double vf = bperm_f64(v, base + 4);
+        return fma(-muc, vf, sgn * v);
+    };
+
+    for (int i = t; i < 2 * RB; i += kThreads) rhsbuf[i] = 0.0;     // padding columns must read as 0
+    for (int i = t; i < n; i += kThreads) xs_full[i] = 0.0;
+    const double qv = active ? sm[S::o_q + r] : 0.0;
+    double x = (active && a.warm_u) ? a.warm_u[(size_t)b * n + 3 * gc + ax] / a.s : 0.0;
+    double px = active ? sm[S::o_px0 + r] : 0.0;
+    double y = (has_row && a.warm_y) ? a.warm_y[(size_t)b * m + irow] : 0.0;
+    double z = rowm * fmin(fmax(Arow(x), lo), hi);
+    double axr = rowm * Arow(x);                        // (A x)_row, carried by recursion
+    double qn[1] = {fabs(qv)};
+    block_max<1>(qn, red);                              // its barriers also order the zero fill above
+    {
+        const double rhs0 = sigma * x - qv + At(rowm * (rho * z - y));
+        if (active && h == 0) rhsbuf[r] = rhs0;
+    }
+    __syncthreads();
+
+    int status = 2, iters = a.max_iter, nchk = 0;
+    for (int k = 1; k <= a.max_iter; ++k) {
+        const bool check = (k % a.check_every == 0) || (k == a.max_iter);
+        const double* rb = rhsbuf + ((k - 1) & 1) * RB;
+        double* wb = rhsbuf + (k & 1) * RB;
+        double xt;
+        {
+            constexpr int BL = 8, NBMAX = (CHMAX / 2 + BL - 1) / BL;      // blocks of BL double2 = 16 columns
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            const double2* rv = reinterpret_cast<const double2*>(rb + CH * h);
+#pragma unroll
+            for (int blk = 0; blk < NBMAX; ++blk) {
+                if (blk * 2 * BL < CH) {                                   // wave-uniform
+                    double2 v[BL];
+#pragma unroll
+                    for (int i = 0; i < BL; ++i) v[i] = rv[blk * BL + i];
+#pragma unroll
+                    for (int i = 0; i < BL; i += 2) {
+                        const int c0 = 2 * (blk * BL + i);
+                        if (c0 + 1 < CHMAX) { acc0 = fma(kin[c0], v[i].x, acc0); acc1 = fma(kin[c0 + 1], v[i].y, acc1); }
+                        if (c0 + 3 < CHMAX) { acc2 = fma(kin[c0 + 2], v[i + 1].x, acc2); acc3 = fma(kin[c0 + 3], v[i + 1].y, acc3); }
+                    }
+                }
+            }
+            const double acc = (acc0 + acc1) + (acc2 + acc3);
+            xt = acc + dpp_swap1(acc);
+        }
+        const double zt = Arow(xt);
+        const double nu = rowm * (rho * (zt - z) + y);
+        const double zh = alpha * zt + (1.0 - alpha) * z;
+        const double zn = fmin(fmax(zh + y * irho, lo), hi);
+        y = rowm * (y + rho * (zh - zn));
+        z = rowm * zn;
+        axr = rowm * (alpha * zt + (1.0 - alpha) * axr);     // A x^{k+1} = alpha A x~ + (1 - alpha) A x^k
+        const double wv = rho * z - y;
+        const double atnu = At(nu), atw = At(wv);
+        const double pxt = sigma * (x - xt) - qv - atnu;
+        x = alpha * xt + (1.0 - alpha) * x;
+        px = alpha * pxt + (1.0 - alpha) * px;
+        if (active && h == 0) wb[r] = sigma * x - qv + atw;
+        if (check) {
+            const double aty = At(y);
+            double rd = fabs(px + qv + aty), rp = fabs(axr - z);
+            rd = (rd == rd) ? rd : kInf * 10.0;
+            rp = (rp == rp) ? rp : kInf * 10.0;
+            double v[4];
+            v[0] = rowm * rp;
+            v[1] = rowm * fmax(fabs(axr), fabs(z));
+            v[2] = active ? rd : 0.0;
+            v[3] = active ? fmax(fabs(px), fabs(aty)) : 0.0;
+            block_max_nonneg<4>(v, red, nchk & 1);
+            ++nchk;
+            const double e_prim = a.eps_abs + a.eps_rel * v[1];
+            const double e_dual = a.eps_abs + a.eps_rel * fmax(v[3], qn[0]);
+            const bool bad = !(v[0] <= kInf) || !(v[2] <= kInf);
+            if (bad) { status = -1; iters = k; break; }
+            if (v[0] <= e_prim && v[2] <= e_dual) { status = 1; iters = k; break; }
+        } else {
+            __syncthreads();
+        }
+    }
+    if (active && h == 0) xs_full[3 * gc + ax] = x;
+    if (a.y_out && has_row) a.y_out[(size_t)b * m + irow] = y;
+    __syncthreads();
+    *status_out = status;
+    return iters;
+}
+
+template <int N, int MAXS>
+__global__ __launch_bounds__(kThreads, (MAXS <= 2 ? 3 : 2)) void srbdqp_compact_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    using S = CompactSmem<N, MAXS>;
+    constexpr int n = Dims<N>::n, m = Dims<N>::m;
+    constexpr int TS = S::TS, CHMAX = S::CHMAX;
+    static_assert(S::NT <= 8, "W phase assumes at most two tiles per wave per block row");
+    static_assert(2 * S::nmax <= kThreads, "two threads per compact column / row");
+    static_assert((S::o_R % 2) == 0 && (S::o_rhs % 2) == 0, "16-byte alignment");
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int mcol = lane & 15, kq = lane >> 4;
+    double* G = sm + S::o_G;
+    double* T = sm + S::o_T;
+    int* icnt = reinterpret_cast<int*>(sm + S::o_int);          // cnt[i] = stance contacts in steps 0..i
+    int* irb = icnt + N;                                        // rowbase[i] = offset of block row i in G
+    int* imisc = irb + N;                                       // [0] na, [1] bound violated
+    uint8_t* act = reinterpret_cast<uint8_t*>(imisc + 8);       // compact contact -> original contact
+
+    // ================= phase A =================
+    SRBDQP_STAMP(a, b, 0);
+    if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime();
+    load_and_linearise<N, S>(a, b, sm);
+    if (t < 64) {   // presolve: compact the stance contacts (wave 0)
+        const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
+        const bool flag = (t < 4 * N) && sct[t < 4 * N ? t : 0] != 0;
+        const unsigned long long bal = __ballot(flag);
+        if (flag) act[__popcll(bal & ((1ull << t) - 1ull))] = (uint8_t)t;
+        if (t < N) icnt[t] = __popcll(bal & ((1ull << (4 * (t + 1))) - 1ull));
+        if (t == 0) {
+            imisc[0] = __popcll(bal);
+            sm[S::o_misc] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {   // offsets of the block rows of G, and the per-step bound check
+        int viol = 0, rb = 0;
+        for (int i = 0; i < N; ++i) {
+            const int ci = icnt[i] - (i ? icnt[i - 1] : 0);
+            viol |= (ci > MAXS);
+            irb[i] = rb;
+            rb += 36 * icnt[i];
+        }
+        imisc[1] = viol;
+    }
+    __syncthreads();
+    const int na = imisc[0];
+    const int n_eff = 3 * na;
+    if (imisc[1] != 0 || na == 0) {   // bound violated (status -2) or nothing to solve (all forces 0)
+        for (int c = t; c < n; c += kThreads) sm[S::o_xs + c] = 0.0;
+        if (a.y_out) for (int i = t; i < m; i += kThreads) a.y_out[(size_t)b * m + i] = 0.0;
+        if (t == 0) {
+            if (a.status) a.status[b] = (imisc[1] != 0) ? kStatusContactBound : 1;
+            if (a.iters) a.iters[b] = 0;
+        }
+        __syncthreads();
+        rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+        return;
+    }
+    SRBDQP_STAMP(a, b, 1);
+    // ---- a6: compact G.  thread = (contact slot g of 14, row-pair type, rr, ax)
+    if (t < 252) {
+        const int g = t / 18, u = t - 18 * g;
+        const int type = u / 9, v = u - 9 * type;
+        const int rr = v / 3, ax = v - 3 * rr;
+        const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = a.dt * a.dt * a.inv_mass;
+        const double wA = sm[S::o_sq + (type ? 3 : 0) + rr] * a.s, wB = sm[S::o_sq + (type ? 9 : 6) + rr] * a.s;
+        const int rowA = (type ? 3 : 0) + rr, rowB = (type ? 9 : 6) + rr;
+        for (int e = g; e < na; e += 14) {
+            const int gc = act[e], j = gc >> 2, cc = 3 * (gc & 3) + ax;
+            const double* J = sm + S::o_J + j * 36 + cc;
+            const double j0 = J[0], j1 = J[12], j2 = J[24];
+            const double* Cj = sm + S::o_cp + j * 9 + rr * 3;
+            const double c0 = Cj[0], c1 = Cj[1], c2 = Cj[2];
+            const double jr = (rr == 0) ? j0 : (rr == 1) ? j1 : j2;
+            for (int i = j; i < N; ++i) {
+                const int len = 3 * icnt[i];
+                double* dst = G + irb[i] + 3 * e + ax;
+                double vA, vB;
+                if (type == 0) {
+                    const double* Ci = sm + S::o_cp + i * 9 + rr * 3;
+                    vA = dt2 * ((Ci[0] - c0) * j0 + (Ci[1] - c1) * j1 + (Ci[2] - c2) * j2);
+                    vB = dt * jr;
+                } else {
+                    vA = (rr == ax) ? (double)(i - j) * dt2m : 0.0;
+                    vB = (rr == ax) ? dtm : 0.0;
+                }
+                dst[len * rowA] = wA * vA;
+                dst[len * rowB] = wB * vB;
+            }
+        }
+    }
+    for (int k = t; k < n; k += kThreads) {   // Q^1/2 (A_qp x0 - x_ref), all 12 N rows
+        const int i = k / 12, kk = k - 12 * i;
+        sm[S::o_eh + k] = sm[S::o_sq + kk] * (free_response<N, S>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
+    }
+    __syncthreads();
+    SRBDQP_STAMP(a, b, 2);
+    {   // ---- a7 gradient (compact columns), two threads per column
+        const int c = t >> 1, h = t & 1;
+        double acc = 0.0;
+        if (c < n_eff) {
+            for (int i = act[c / 3] >> 2; i < N; ++i) {
+                const int len = 3 * icnt[i];
+                const double* col = G + irb[i] + len * h + c;
+                const double* e = sm + S::o_eh + 12 * i + h;
+                double p0 = col[0] * e[0], p1 = col[2 * len] * e[2], p2 = col[4 * len] * e[4];
+                p0 = fma(col[6 * len], e[6], p0);
+                p1 = fma(col[8 * len], e[8], p1);
+                p2 = fma(col[10 * len], e[10], p2);
+                acc += (p0 + p1) + p2;
+            }
+        }
+        acc += dpp_swap1(acc);
+        if (c < n_eff && h == 0) sm[S::o_q + c] = acc;
+    }
+    if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0 on the compact columns
+        for (int c = t; c < n_eff; c += kThreads)
+            sm[S::o_x0c + c] = a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)] / a.s;
+        __syncthreads();
+        for (int k = t; k < n; k += kThreads) {
+            const int i = k / 12, kk = k - 12 * i, len = 3 * icnt[i];
+            const double* row = G + irb[i] + len * kk;
+            double acc = 0.0;
+            for (int c = 0; c < len; ++c) acc = fma(row[c], sm[S::o_x0c + c], acc);
+            sm[S::o_gx + k] = acc;
+        }
+        __syncthreads();
+        for (int c = t; c < n_eff; c += kThreads) {
+            double acc = a.rs2 * sm[S::o_x0c + c];
+            for (int i = act[c / 3] >> 2; i < N; ++i) {
+                const int len = 3 * icnt[i];
+                const double* col = G + irb[i] + c;
+                for (int kk = 0; kk < 12; ++kk) acc = fma(col[len * kk], sm[S::o_gx + 12 * i + kk], acc);
+            }
+            sm[S::o_px0 + c] = acc;
+        }
+    } else {
+        for (int c = t; c < n_eff; c += kThreads) sm[S::o_px0 + c] = 0.0;
+    }
+    SRBDQP_STAMP(a, b, 3);
+
+    // run-time tile geometry
+    const int NT = (n_eff + 15) >> 4;
+    const int NTT = (NT * (NT + 1)) >> 1;
+    int ta[TS], tb[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int id = 4 * s + w;
+        int bb = 0;
+        while (((bb + 1) * (bb + 2)) / 2 <= id) ++bb;
+        tb[s] = (id < NTT) ? bb : -1;
+        ta[s] = (id < NTT) ? id - (bb * (bb + 1)) / 2 : -1;
+    }
+
+    // ================= phase H =================
+    v4d acc[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (ta[s] >= 0) {
+            const int ca = 16 * ta[s] + mcol, cb = 16 * tb[s] + mcol;
+            int i0 = 0;
+            while (i0 < N && 3 * icnt[i0] <= 16 * tb[s]) ++i0;      // first block row that reaches column block b
+            for (int i = i0; i < N; ++i) {
+                const int len = 3 * icnt[i];
+                const double* base = G + irb[i] + len * kq;
+#pragma unroll
+                for (int kk0 = 0; kk0 < 12; kk0 += 4) {
+                    const double* row = base + len * kk0;
+                    double av = row[ca], bv = row[cb];
+                    av = (ca < len) ? av : 0.0;
+                    bv = (cb < len) ? bv : 0.0;
+                    acc[s] = mfma_f64(av, bv, acc[s]);
+                }
+            }
+            if (ta[s] == tb[s]) {   // + R s^2 + sigma + A' rho A (stance contacts only: uniform rho); padding -> identity
+                const int var = 16 * ta[s] + mcol;
+                const double dv = (var < n_eff) ? a.rs2 + a.sigma + (((var % 3) < 2) ? 2.0 * a.rho : (4.0 * a.mu * a.mu + 1.0) * a.rho) : 1.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (kq + 4 * r == mcol) acc[s][r] += dv;
+            }
+        }
+    }
+    SRBDQP_STAMP(a, b, 4);
+    __syncthreads();
+    SRBDQP_STAMP(a, b, 5);
+
+    // ================= phase F =================
+    for (int j = 0; j < NT; ++j) {
+        double* Djj = T + tile_id(j, j) * 256;
+#pragma unroll
+        for (int s = 0; s < TS; ++s)
+            if (ta[s] == j && tb[s] == j) store_tile<false>(Djj, acc[s], lane);
+        __syncthreads();
+        if (w == (j & 3)) {
+            const bool ok = diag16_invert(Djj, lane);
+            if (!ok && lane == 0) sm[S::o_misc] = 1.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            if (ta[s] == j && tb[s] > j) {
+                v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double av = Djj[mcol * 16 + (k ^ mcol)];
+                    av = (k <= mcol) ? av : 0.0;
+                    o = mfma_f64(av, acc[s][r], o);
+                }
+                acc[s] = o;
+                store_tile<false>(T + tile_id(j, tb[s]) * 256, o, lane);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            if (ta[s] > j) {
+                const double* Ua = T + tile_id(j, ta[s]) * 256;
+                const double* Ub = T + tile_id(j, tb[s]) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    acc[s] = mfma_f64(-Ua[k * 16 + mcol], Ub[k * 16 + mcol], acc[s]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    SRBDQP_STAMP(a, b, 6);
+
+    // ================= phase W =================
+    for (int i = 1; i < NT; ++i) {
+        v4d res[2];
+        const double* Dii = T + tile_id(i, i) * 256;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = w + 4 * q;
+            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (j < i) {
+                v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
+                {
+                    const double* Uji = T + tile_id(j, i) * 256;
+                    const double* Djj = T + tile_id(j, j) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * r + kq;
+                        double bv = Djj[k * 16 + (mcol ^ k)];
+                        bv = (mcol <= k) ? bv : 0.0;
+                        o = mfma_f64(Uji[k * 16 + mcol], bv, o);
+                    }
+                }
+                for (int k2 = j + 1; k2 < i; ++k2) {
+                    const double* Uki = T + tile_id(k2, i) * 256;
+                    const double* Wkj = T + tile_id(j, k2) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * r + kq;
+                        o = mfma_f64(Uki[k * 16 + mcol], Wkj[k * 16 + mcol], o);
+                    }
+                }
+                v4d o2 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double av = Dii[mcol * 16 + (k ^ mcol)];
+                    av = (k <= mcol) ? -av : 0.0;
+                    o2 = mfma_f64(av, o[r], o2);
+                }
+                res[q] = o2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = w + 4 * q;
+            if (j < i) store_tile<false>(T + tile_id(j, i) * 256, res[q], lane);
+        }
+        __syncthreads();
+    }
+    SRBDQP_STAMP(a, b, 7);
+
+    // ================= phase I =================
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (ta[s] >= 0) {
+            const int ia = ta[s], ib = tb[s];
+            const double* Dbb = T + tile_id(ib, ib) * 256;
+            {
+                const double* Wba = T + tile_id(ia, ib) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double dv = Dbb[k * 16 + (mcol ^ k)];
+                    dv = (mcol <= k) ? dv : 0.0;
+                    const double av = (ia < ib) ? Wba[k * 16 + mcol] : dv;
+                    acc[s] = mfma_f64(av, dv, acc[s]);
+                }
+            }
+            for (int i = ib + 1; i < NT; ++i) {
+                const double* Wia = T + tile_id(ia, i) * 256;
+                const double* Wib = T + tile_id(ib, i) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    acc[s] = mfma_f64(Wia[k * 16 + mcol], Wib[k * 16 + mcol], acc[s]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TS; ++s)
+        if (ta[s] >= 0) store_tile<true>(T + tile_id(ta[s], tb[s]) * 256, acc[s], lane);
+    __syncthreads();
+    SRBDQP_STAMP(a, b, 8);
+
+    // K^-1 row fragments in the compact contact-local mapping
+    const int CH = 2 * ((n_eff + 3) >> 2);
+    double kin[CHMAX];
+    {
+        const int lr = lane >> 1, h = lane & 1;
+        const int CPW = (na + 3) >> 2;
+        const int cg = lr / 3, e = w * CPW + cg;
+        const bool rowok = (cg < CPW) && (e < na);
+        const int rr = rowok ? 3 * e + (lr - 3 * cg) : 0;
+#pragma unroll
+        for (int cc = 0; cc < CHMAX; ++cc) {
+            const int c = CH * h + cc;
+            const bool ok = rowok && (cc < CH) && (c < n_eff);
+            const int cs = ok ? c : 0;
+            const int lo = (rr <= cs) ? rr : cs, hi = (rr <= cs) ? cs : rr;
+            const int row = lo & 15, col = hi & 15;
+            const double v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
+            kin[cc] = ok ? v : 0.0;
+        }
+    }
+    const bool failed = sm[S::o_misc] != 0.0;
+    __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
+
+    SRBDQP_STAMP(a, b, 9);
+    int status = -1, iters = 0;
+    if (!failed) iters = admm_loop_compact<N, S, CHMAX>(a, b, sm, sm + S::o_rhs, sm + S::o_xs, kin, na, CH, act, &status);
+    else {
+        for (int c = t; c < n; c += kThreads) sm[S::o_xs + c] = 0.0;
+        __syncthreads();
+    }
+    if (a.y_out) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
+        const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
+        for (int i = t; i < m; i += kThreads)
+            if (failed || sct[i / 5] == 0) a.y_out[(size_t)b * m + i] = 0.0;
+    }
+    if (t == 0) {
+        if (a.status) a.status[b] = status;
+        if (a.iters) a.iters[b] = iters;
+    }
+    SRBDQP_STAMP(a, b, 10);
+    rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+    SRBDQP_STAMP(a, b, 11);
+    if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();
+}
+
+template <int N, int MAXS>
+struct CompactTraits {
+    static constexpr bool supported = (3 * MAXS * N <= 128);
+    static constexpr size_t lds_bytes = CompactSmem<N, MAXS>::bytes;
+};
+
+}  // namespace srbdqp

@@ -158,10 +158,11 @@ __device__ __forceinline__ bool diag16_invert(double* tile, int lane) {
     const int c = lane & 15;
     const bool isT = lane < 16, isM = (lane >= 16) && (lane < 32);
     double t[16];
+    const double tmask = isT ? 1.0 : 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const double v = tile[r * 16 + c];            // lanes >= 16 read too (same addresses), then overwrite
-        t[r] = isT ? v : ((r == c) ? 1.0 : 0.0);
+        const double v = tile[r * 16 + c];            // every lane reads (same addresses); arithmetic select, no branch
+        t[r] = fma(v, tmask, (!isT && r == c) ? 1.0 : 0.0);
     }
     asm volatile("" ::: "memory");
     // the tile now lives in registers: its LDS words are free scratch until the final store
@@ -175,16 +176,13 @@ __device__ __forceinline__ bool diag16_invert(double* tile, int lane) {
     double2 rs2[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) rs2[q] = reinterpret_cast<const double2*>(tile)[q];
-    double vout[16];
+    asm volatile("" ::: "memory");
+    // overwrite the tile with L^-1, swizzled (the scratch words were read into registers above: same wave, in order)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const double rs = (r & 1) ? rs2[r >> 1].y : rs2[r >> 1].x;
-        vout[r] = (r >= c) ? t[r] * rs : 0.0;
+        if (isM) tile[r * 16 + (c ^ r)] = (r >= c) ? t[r] * rs : 0.0;
     }
-    asm volatile("" ::: "memory");
-    // overwrite the tile with L^-1, swizzled (all reads of the scratch words are done: same wave, in order)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) if (isM) tile[r * 16 + (c ^ r)] = vout[r];
     return ok;
 }
 

@@ -43,7 +43,8 @@ extern "C" {
 /* per-QP status[] values */
 #define SRBDQP_SOLVED    1        /* primal and dual residual below tolerance */
 #define SRBDQP_MAX_ITER  2        /* iteration cap reached; best iterate returned */
-#define SRBDQP_NUMERICAL (-1)     /* non-finite residual */
+#define SRBDQP_NUMERICAL (-1)     /* non-finite residual / non-positive pivot */
+#define SRBDQP_CONTACT_BOUND (-2) /* more stance contacts in a step than srbdqp_config.max_contacts_per_step allows */
 
 /* srbdqp_config.flags */
 #define SRBDQP_FLAG_TIMING 1      /* bracket every kernel launch with HIP events (srbdqp_last_kernel_ms) */
@@ -51,7 +52,8 @@ extern "C" {
 /* srbdqp_config.kernel: which implementation of the hot path runs */
 #define SRBDQP_KERNEL_AUTO  0     /* the fastest parity-green kernel */
 #define SRBDQP_KERNEL_GJ    1     /* v0: VALU assembly + in-LDS Gauss-Jordan inverse */
-#define SRBDQP_KERNEL_MFMA  2     /* v1: fp64-MFMA contraction + tiled Cholesky inverse */
+#define SRBDQP_KERNEL_MFMA  2     /* v1: fp64-MFMA contraction + tiled Cholesky inverse, all 12N variables */
+#define SRBDQP_KERNEL_COMPACT 3   /* v2: v1's pipeline on the presolved QP (swing-contact variables eliminated) */
 
 /* Everything `MPC.__init__(dt)` / `MPC.init_matrices()` hold (run_simulation.py:169-170).  Values the
  * reference keeps inside the absent module are this build's documented choices. */
@@ -63,7 +65,9 @@ typedef struct srbdqp_config {
     int32_t kernel;               /* SRBDQP_KERNEL_* */
     int32_t max_iter;
     int32_t check_every;
-    int32_t reserved0;
+    int32_t max_contacts_per_step; /* bound on stance contact points per horizon step: 1..4; 0 = decide per call
+                                    * (host-buffer API scans the contact flags, device API assumes 4).  A bound of
+                                    * <= 2 selects the smaller, higher-occupancy kernel instantiation. */
     double dt;                    /* run_simulation.py:169 */
     double mass;                  /* wbid.py:291 model.getMass() */
     double inertia[3];            /* wbid.py:261-266 torso inertia diagonal */

@@ -30,6 +30,7 @@ typedef struct {
     double q_diag[NX], r_diag, force_scale;
     double rho, rho_eq_scale, sigma, alpha, eps_abs, eps_rel;
     int max_iter, check_every;
+    int eliminate_swing;   /* presolve: drop the variables/rows of swing contacts (kernel v2); 0 = clamp via bounds */
 } srbd_oracle_params;
 
 static void matmul(const double* A, const double* B, double* C, int m, int k, int n) {
@@ -69,7 +70,7 @@ static void linearise(const srbd_oracle_params* p, double yaw, const double* r /
 /* workspace size in doubles for horizon N */
 size_t srbd_oracle_work_doubles(int N) {
     const size_t n = 12 * (size_t)N, s = 13 * (size_t)N, m = 20 * (size_t)N;
-    return (size_t)N * (NX * NX + NX * NU) + s * NX + s * n + 3 * n * n + 8 * n + 8 * m + 4 * s + 1024;
+    return (size_t)N * (NX * NX + NX * NU) + s * NX + s * n + 3 * n * n + 8 * n + 8 * m + 4 * s + 4 * N + 1024;
 }
 
 int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, const double* xref, const double* foot,
@@ -159,96 +160,106 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
     }
     if (P_out) memcpy(P_out, P, sizeof(double) * (size_t)n * n);
     if (q_out) memcpy(q_out, q, sizeof(double) * n);
-    /* a8 bounds */
-    for (int k = 0; k < N; ++k) for (int ci = 0; ci < NC; ++ci) {
-        const int r0 = 20 * k + 5 * ci;
-        const int on = contact[k * NC + ci] != 0;
+    /* presolve: the contacts that take part in the solve */
+    int nc = 0;
+    int* cmap = (int*)w; w += 4 * N;                 /* compact contact -> original contact (4k+ci) */
+    for (int gc = 0; gc < 4 * N; ++gc) if (!p->eliminate_swing || contact[gc]) cmap[nc++] = gc;
+    const int nr = 3 * nc, mr = 5 * nc;
+    /* a8 bounds (compact rows) */
+    for (int e = 0; e < nc; ++e) {
+        const int r0 = 5 * e;
+        const int on = contact[cmap[e]] != 0;
         for (int j = 0; j < 4; ++j) { lo[r0 + j] = -INF; hi[r0 + j] = 0.0; rho[r0 + j] = p->rho; }
         lo[r0 + 4] = on ? p->fz_min / sc : 0.0;
         hi[r0 + 4] = on ? p->fz_max / sc : 0.0;
         rho[r0 + 4] = on ? p->rho : p->rho * p->rho_eq_scale;
     }
-    /* a9: K, Cholesky, inverse */
-    memcpy(K, P, sizeof(double) * (size_t)n * n);
-    for (int k = 0; k < N; ++k) for (int ci = 0; ci < NC; ++ci) {
-        const int r0 = 20 * k + 5 * ci, c0 = NU * k + 3 * ci;
-        K[(size_t)(c0) * n + c0] += p->sigma + rho[r0] + rho[r0 + 1];
-        K[(size_t)(c0 + 1) * n + c0 + 1] += p->sigma + rho[r0 + 2] + rho[r0 + 3];
-        K[(size_t)(c0 + 2) * n + c0 + 2] += p->sigma + mu * mu * (rho[r0] + rho[r0 + 1] + rho[r0 + 2] + rho[r0 + 3]) + rho[r0 + 4];
-        const double d02 = -mu * (rho[r0] - rho[r0 + 1]), d12 = -mu * (rho[r0 + 2] - rho[r0 + 3]);
-        K[(size_t)(c0) * n + c0 + 2] += d02; K[(size_t)(c0 + 2) * n + c0] += d02;
-        K[(size_t)(c0 + 1) * n + c0 + 2] += d12; K[(size_t)(c0 + 2) * n + c0 + 1] += d12;
+    /* a9: K (compact), Cholesky, inverse */
+#define VIDX(v) (3 * cmap[(v) / 3] + (v) % 3)       /* compact variable -> original variable */
+    for (int i = 0; i < nr; ++i) for (int j = 0; j < nr; ++j) K[(size_t)i * nr + j] = P[(size_t)VIDX(i) * n + VIDX(j)];
+    for (int i = 0; i < nr; ++i) tmpn[i] = q[VIDX(i)];   /* compact gradient */
+    double* qc = tmpn; double* tmp2 = Atw;               /* note: Atw is reused below only after qc is copied */
+    (void)tmp2;
+    double* qcv = e;                                     /* e[] (length s >= nr) is free now: keep the compact q there */
+    for (int i = 0; i < nr; ++i) qcv[i] = qc[i];
+    for (int e_ = 0; e_ < nc; ++e_) {
+        const int r0 = 5 * e_, c0 = 3 * e_;
+        K[(size_t)(c0) * nr + c0] += p->sigma + rho[r0] + rho[r0 + 1];
+        K[(size_t)(c0 + 1) * nr + c0 + 1] += p->sigma + rho[r0 + 2] + rho[r0 + 3];
+        K[(size_t)(c0 + 2) * nr + c0 + 2] += p->sigma + mu * mu * (rho[r0] + rho[r0 + 1] + rho[r0 + 2] + rho[r0 + 3]) + rho[r0 + 4];
     }
-    for (int j = 0; j < n; ++j) {            /* lower Cholesky in place */
-        double d = K[(size_t)j * n + j];
-        for (int k = 0; k < j; ++k) d -= K[(size_t)j * n + k] * K[(size_t)j * n + k];
+    if (nr > 0) {
+    for (int j = 0; j < nr; ++j) {            /* lower Cholesky in place */
+        double d = K[(size_t)j * nr + j];
+        for (int k = 0; k < j; ++k) d -= K[(size_t)j * nr + k] * K[(size_t)j * nr + k];
         if (!(d > 0.0)) { *status_out = -1; *iters_out = 0; return -1; }
         d = sqrt(d);
-        K[(size_t)j * n + j] = d;
-        for (int i = j + 1; i < n; ++i) {
-            double v = K[(size_t)i * n + j];
-            for (int k = 0; k < j; ++k) v -= K[(size_t)i * n + k] * K[(size_t)j * n + k];
-            K[(size_t)i * n + j] = v / d;
+        K[(size_t)j * nr + j] = d;
+        for (int i = j + 1; i < nr; ++i) {
+            double v = K[(size_t)i * nr + j];
+            for (int k = 0; k < j; ++k) v -= K[(size_t)i * nr + k] * K[(size_t)j * nr + k];
+            K[(size_t)i * nr + j] = v / d;
         }
+    }
     }
     /* W = L^-1 (lower) into Kinv's lower part, then Kinv = W' W */
     double* W = Kinv;
-    memset(W, 0, sizeof(double) * (size_t)n * n);
-    for (int j = 0; j < n; ++j) {
-        W[(size_t)j * n + j] = 1.0 / K[(size_t)j * n + j];
-        for (int i = j + 1; i < n; ++i) {
+    memset(W, 0, sizeof(double) * (size_t)nr * nr);
+    for (int j = 0; j < nr; ++j) {
+        W[(size_t)j * nr + j] = 1.0 / K[(size_t)j * nr + j];
+        for (int i = j + 1; i < nr; ++i) {
             double v = 0.0;
-            for (int k = j; k < i; ++k) v += K[(size_t)i * n + k] * W[(size_t)k * n + j];
-            W[(size_t)i * n + j] = -v / K[(size_t)i * n + i];
+            for (int k = j; k < i; ++k) v += K[(size_t)i * nr + k] * W[(size_t)k * nr + j];
+            W[(size_t)i * nr + j] = -v / K[(size_t)i * nr + i];
         }
     }
-    memcpy(K, W, sizeof(double) * (size_t)n * n);   /* K now holds W */
-    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) {
+    memcpy(K, W, sizeof(double) * (size_t)nr * nr);   /* K now holds W */
+    for (int i = 0; i < nr; ++i) for (int j = 0; j <= i; ++j) {
         double v = 0.0;
-        for (int k = i; k < n; ++k) v += K[(size_t)k * n + i] * K[(size_t)k * n + j];
-        Kinv[(size_t)i * n + j] = v;
+        for (int k = i; k < nr; ++k) v += K[(size_t)k * nr + i] * K[(size_t)k * nr + j];
+        Kinv[(size_t)i * nr + j] = v;
     }
-    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) Kinv[(size_t)i * n + j] = Kinv[(size_t)j * n + i];
+    for (int i = 0; i < nr; ++i) for (int j = i + 1; j < nr; ++j) Kinv[(size_t)i * nr + j] = Kinv[(size_t)j * nr + i];
 
-    /* ADMM */
-#define A_ROW(vec, r0, j) ((j) == 0 ? (vec)[0] - mu * (vec)[2] : (j) == 1 ? -(vec)[0] - mu * (vec)[2] : \
-                           (j) == 2 ? (vec)[1] - mu * (vec)[2] : (j) == 3 ? -(vec)[1] - mu * (vec)[2] : (vec)[2])
+    /* ADMM on the compact problem */
+#define A_ROW(vec, j) ((j) == 0 ? (vec)[0] - mu * (vec)[2] : (j) == 1 ? -(vec)[0] - mu * (vec)[2] : \
+                       (j) == 2 ? (vec)[1] - mu * (vec)[2] : (j) == 3 ? -(vec)[1] - mu * (vec)[2] : (vec)[2])
 #define AT_APPLY(out, wv_)                                                                         \
-    for (int k_ = 0; k_ < N; ++k_) for (int ci_ = 0; ci_ < NC; ++ci_) {                            \
-        const double* pw = (wv_) + 20 * k_ + 5 * ci_; double* po = (out) + NU * k_ + 3 * ci_;     \
+    for (int e_ = 0; e_ < nc; ++e_) {                                                              \
+        const double* pw = (wv_) + 5 * e_; double* po = (out) + 3 * e_;                            \
         po[0] = pw[0] - pw[1]; po[1] = pw[2] - pw[3];                                              \
         po[2] = -mu * (pw[0] + pw[1] + pw[2] + pw[3]) + pw[4];                                     \
     }
     memset(x, 0, sizeof(double) * n);
     memset(y, 0, sizeof(double) * m);
     memset(Px, 0, sizeof(double) * n);
-    for (int i = 0; i < m; ++i) { z[i] = fmin(fmax(0.0, lo[i]), hi[i]); }
+    for (int i = 0; i < mr; ++i) { z[i] = fmin(fmax(0.0, lo[i]), hi[i]); }
     double qn = 0.0;
-    for (int i = 0; i < n; ++i) qn = fmax(qn, fabs(q[i]));
+    for (int i = 0; i < nr; ++i) qn = fmax(qn, fabs(qcv[i]));
     int status = 2, iters = p->max_iter;
-    for (int k = 1; k <= p->max_iter; ++k) {
-        for (int i = 0; i < m; ++i) wv[i] = rho[i] * z[i] - y[i];
+    if (nr == 0) { status = 1; iters = 0; }
+    for (int k = 1; k <= p->max_iter && nr > 0; ++k) {
+        for (int i = 0; i < mr; ++i) wv[i] = rho[i] * z[i] - y[i];
         AT_APPLY(Atw, wv);
-        for (int i = 0; i < n; ++i) rhs[i] = p->sigma * x[i] - q[i] + Atw[i];
-        for (int i = 0; i < n; ++i) {
-            const double* Ki = Kinv + (size_t)i * n;
+        for (int i = 0; i < nr; ++i) rhs[i] = p->sigma * x[i] - qcv[i] + Atw[i];
+        for (int i = 0; i < nr; ++i) {
+            const double* Ki = Kinv + (size_t)i * nr;
             double v = 0.0;
-            for (int j = 0; j < n; ++j) v += Ki[j] * rhs[j];
+            for (int j = 0; j < nr; ++j) v += Ki[j] * rhs[j];
             xt[i] = v;
         }
-        for (int i = 0; i < m; ++i) {
-            const int kk = i / 20, rr = i % 20, ci = rr / 5, j = rr % 5;
-            const double* v = xt + NU * kk + 3 * ci;
-            zt[i] = A_ROW(v, 0, j);
+        for (int i = 0; i < mr; ++i) {
+            const double* v = xt + 3 * (i / 5);
+            zt[i] = A_ROW(v, i % 5);
             wv[i] = rho[i] * (zt[i] - z[i]) + y[i];       /* nu */
         }
         AT_APPLY(tmpn, wv);
-        for (int i = 0; i < n; ++i) {
-            const double pxt = p->sigma * (x[i] - xt[i]) - q[i] - tmpn[i];
+        for (int i = 0; i < nr; ++i) {
+            const double pxt = p->sigma * (x[i] - xt[i]) - qcv[i] - tmpn[i];
             x[i] = p->alpha * xt[i] + (1.0 - p->alpha) * x[i];
             Px[i] = p->alpha * pxt + (1.0 - p->alpha) * Px[i];
         }
-        for (int i = 0; i < m; ++i) {
+        for (int i = 0; i < mr; ++i) {
             const double zh = p->alpha * zt[i] + (1.0 - p->alpha) * z[i];
             const double zn = fmin(fmax(zh + y[i] / rho[i], lo[i]), hi[i]);
             y[i] = y[i] + rho[i] * (zh - zn);
@@ -256,15 +267,14 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
         }
         if (k % p->check_every == 0 || k == p->max_iter) {
             double rp = 0, rd = 0, nax = 0, nz = 0, npx = 0, naty = 0;
-            for (int i = 0; i < m; ++i) {
-                const int kk = i / 20, rr = i % 20, ci = rr / 5, j = rr % 5;
-                const double* v = x + NU * kk + 3 * ci;
-                const double ax = A_ROW(v, 0, j);
+            for (int i = 0; i < mr; ++i) {
+                const double* v = x + 3 * (i / 5);
+                const double ax = A_ROW(v, i % 5);
                 rp = fmax(rp, fabs(ax - z[i])); nax = fmax(nax, fabs(ax)); nz = fmax(nz, fabs(z[i]));
             }
             AT_APPLY(Atw, y);
-            for (int i = 0; i < n; ++i) {
-                const double r_ = fabs(Px[i] + q[i] + Atw[i]);
+            for (int i = 0; i < nr; ++i) {
+                const double r_ = fabs(Px[i] + qcv[i] + Atw[i]);
                 if (r_ != r_) rd = r_; else if (rd == rd) rd = fmax(rd, r_);
                 npx = fmax(npx, fabs(Px[i])); naty = fmax(naty, fabs(Atw[i]));
             }
@@ -274,6 +284,10 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
             if (rp <= ep && rd <= ed) { status = 1; iters = k; break; }
         }
     }
+    /* expand the compact solution (x is compact here) into the full variable vector */
+    for (int i = 0; i < n; ++i) rhs[i] = 0.0;
+    for (int i = 0; i < nr; ++i) rhs[VIDX(i)] = x[i];
+    memcpy(x, rhs, sizeof(double) * n);
     for (int i = 0; i < n; ++i) u_out[i] = sc * x[i];
     if (x_out) {
         for (int c = 0; c < NX; ++c) x_out[c] = x0[c];

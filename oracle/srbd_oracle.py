@@ -75,6 +75,9 @@ class SrbdParams:
     eps_rel: float = 1.0e-6
     max_iter: int = 500
     check_every: int = 5
+    # presolve: variables of swing contacts (force clamped to 0) are eliminated before the ADMM (kernel v2);
+    # False = keep all 12N variables and clamp through the bounds (kernel v0/v1)
+    eliminate_swing: bool = True
 
     def as_dict(self):
         return asdict(self)
@@ -275,15 +278,38 @@ def rollout(qp, x0, u_hat, force_scale):
     return np.vstack([x0[None, :], X.reshape(-1, NX)])
 
 
+def presolve(qp, contact_hor):
+    """Fixed-variable elimination: drop the 3 variables and 5 rows of every swing contact (their force is 0).
+    Returns (reduced qp dict, var_index, row_index).  The reduced problem has the same optimum on the kept variables."""
+    on = np.asarray(contact_hor).reshape(-1).astype(bool)
+    vi = np.where(np.repeat(on, 3))[0]
+    ri = np.where(np.repeat(on, ROWS_PER_CONTACT))[0]
+    red = dict(P=qp["P"][np.ix_(vi, vi)], q=qp["q"][vi], A=qp["A"][np.ix_(ri, vi)], l=qp["l"][ri], u=qp["u"][ri])
+    return red, vi, ri
+
+
 def update(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None, warm=None, dtype=np.float64):
     """Oracle twin of MPC.update: returns dict(u (N,12) in newtons, x (N+1,13), iters, status, ...)."""
     qp = build_qp(p, x0, x_ref, foot_hor, contact_hor, pcom_hor)
+    n, m = qp["P"].shape[0], qp["A"].shape[0]
     xi, yi = (None, None) if warm is None else warm
-    uh, z, y, iters, status = admm_solve(p, qp["P"], qp["q"], qp["A"], qp["l"], qp["u"], xi, yi, dtype=dtype)
+    if p.eliminate_swing:
+        red, vi, ri = presolve(qp, contact_hor)
+        uh = np.zeros(n); y = np.zeros(m)
+        if len(vi) == 0:
+            iters, status = 0, STATUS_SOLVED
+        else:
+            xr_, _, yr_, iters, status = admm_solve(p, red["P"], red["q"], red["A"], red["l"], red["u"],
+                                                    None if xi is None else np.asarray(xi)[vi],
+                                                    None if yi is None else np.asarray(yi)[ri], dtype=dtype)
+            uh[vi] = xr_
+            y[ri] = yr_
+    else:
+        uh, _, y, iters, status = admm_solve(p, qp["P"], qp["q"], qp["A"], qp["l"], qp["u"], xi, yi, dtype=dtype)
     N = np.asarray(x_ref).shape[0]
-    uh64 = uh.astype(np.float64)
+    uh64 = np.asarray(uh, dtype=np.float64)
     return dict(u=(uh64 * p.force_scale).reshape(N, NU), x=rollout(qp, x0, uh64, p.force_scale),
-                iters=iters, status=status, u_hat=uh64, y=y.astype(np.float64), qp=qp)
+                iters=iters, status=status, u_hat=uh64, y=np.asarray(y, dtype=np.float64), qp=qp)
 
 
 # --------------------------------------------------------------------------------------
