@@ -42,7 +42,7 @@ def algorithmic_flops(N: int, K: float) -> float:
 
 def algorithmic_bytes(N: int) -> int:
     """HBM bytes per QP, fp64 (inputs + outputs)."""
-    return (13 + 13 * N + 12 * N) * 8 + 4 * N + (12 * N + 13 * (N + 1)) * 8 + 8
+    return (13 + 13 * N + 12 * N + 4 * N) * 8 + (12 * N + 13 * (N + 1)) * 8 + 8
 
 
 def main():
@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="QPs per GPU per step (default: configs[1])")
-    ap.add_argument("--kernel", choices=["auto", "gj", "mfma"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "gj", "mfma", "compact"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -88,8 +88,9 @@ def main():
     d_it = torch.empty(B, dtype=torch.int32, device=dev)
     d_u0_all = torch.empty((world, B, 12), dtype=torch.float64, device=dev) if world > 1 else None
 
-    kid = {"auto": _lib.KERNEL_AUTO, "gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA}[args.kernel]
-    eng = BatchMPC(horizon=N, device=local_rank, kernel=kid)
+    kid = {"auto": _lib.KERNEL_AUTO, "gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "compact": _lib.KERNEL_COMPACT}[args.kernel]
+    # configs[1] is the 2-contact (single support) workload: at most 2 stance contact points per horizon step
+    eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=2)
     # a non-default stream: the C-ABI treats a NULL stream as "the handle's own", and the HIP events that time the
     # kernel must sit on the stream the kernel is launched on
     stream = torch.cuda.Stream(device=dev)

@@ -151,6 +151,11 @@ __device__ __forceinline__ void diag16_step(double (&t)[16], double& dsave, bool
             t[r] = fma(-lr, t[P], t[r]);              // T rows in lanes 0..15, M rows in lanes 16..31
         }
     }
+    // keep this step's row updates HERE: left alone, the compiler sinks each row's FMA chain to the step where the row
+    // becomes the pivot (left-looking order), which keeps every step's multipliers live at once and spills.  An empty
+    // asm with a read-write operand pins the value without emitting an instruction.
+#pragma unroll
+    for (int r = P + 2; r < 16; ++r) asm volatile("" : "+v"(t[r]));
     if constexpr (P < 15) diag16_step<P + 1>(t, dsave, ok, rd_next, lane, scr);
 }
 

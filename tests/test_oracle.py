@@ -1,0 +1,175 @@
+"""CPU tests of the oracle itself: it must be right before it may judge the HIP path.
+
+The reference holds no fixtures for this path (parity unpinned, see oracle/srbd_oracle.py), so the oracle is pinned
+by (a) first-principles checks of every stage against an independent computation, (b) the committed golden vectors
+(which freeze the specification), (c) the plain-C restatement agreeing with the NumPy one.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import srbd_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "srbd_qp_golden.npz")
+CASES = [("n10_single_a", 10), ("n10_single_b", 10), ("n10_double", 10), ("n10_mixed", 10), ("n8_mixed", 8), ("n4_single", 4)]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _case(gold, name):
+    return gold[f"{name}/x0"], gold[f"{name}/x_ref"], gold[f"{name}/foot"], gold[f"{name}/contact"]
+
+
+def test_linearisation_matches_finite_differences_of_the_nonlinear_srbd():
+    """A_c, B_c of the single rigid body (yaw-only Euler-rate approximation) vs numeric differentiation."""
+    p = orc.SrbdParams()
+    rng = np.random.default_rng(0)
+    yaw = 0.7
+    r = rng.uniform(-0.2, 0.2, (4, 3))
+    Iinv = orc.rot_z(yaw) @ np.diag(1.0 / np.array(p.inertia)) @ orc.rot_z(yaw).T
+
+    def f(x, u):   # continuous dynamics in the model's own approximation
+        dx = np.zeros(13)
+        dx[0:3] = orc.rot_z(yaw).T @ x[6:9]
+        dx[3:6] = x[9:12]
+        F = u.reshape(4, 3)
+        dx[6:9] = Iinv @ sum(np.cross(r[i], F[i]) for i in range(4))
+        dx[9:12] = F.sum(0) / p.mass + np.array([0, 0, x[12]])
+        return dx
+
+    A, B = orc.linearise(p, yaw, r)
+    x, u = rng.normal(size=13), rng.normal(size=12) * 50
+    for j in range(13):
+        e = np.zeros(13); e[j] = 1e-6
+        col = (f(x + e, u) - f(x - e, u)) / 2e-6
+        assert np.allclose((A[:, j] - np.eye(13)[:, j]) / p.dt, col, atol=1e-8)
+    for j in range(12):
+        e = np.zeros(12); e[j] = 1e-3
+        col = (f(x, u + e) - f(x, u - e)) / 2e-3
+        assert np.allclose(B[:, j] / p.dt, col, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,N", CASES)
+def test_condensation_equals_step_by_step_simulation(gold, name, N):
+    p = orc.SrbdParams()
+    x0, xr, ft, ct = _case(gold, name)
+    A_qp, B_qp = orc.condense(p, xr[:, 2], ft, xr[:, 3:6])
+    rng = np.random.default_rng(1)
+    U = rng.normal(size=(N, 12)) * 30
+    x = x0.copy()
+    for k in range(N):
+        A, B = orc.linearise(p, xr[k, 2], ft[k].reshape(4, 3) - xr[k, 3:6])
+        x = A @ x + B @ U[k]
+        assert np.allclose((A_qp @ x0 + B_qp @ U.reshape(-1))[13 * k:13 * (k + 1)], x, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,N", CASES)
+def test_golden_vectors_are_reproduced(gold, name, N):
+    """Freezes the specification: QP data, exact optimum and the ADMM twin's iterate."""
+    p = orc.SrbdParams()
+    x0, xr, ft, ct = _case(gold, name)
+    qp = orc.build_qp(p, x0, xr, ft, ct)
+    assert np.allclose(qp["q"], gold[f"{name}/q"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_array_equal(qp["l"], gold[f"{name}/l"])
+    np.testing.assert_array_equal(qp["u"], gold[f"{name}/u"])
+    if f"{name}/P" in gold:
+        assert np.allclose(qp["P"], gold[f"{name}/P"], rtol=1e-12, atol=1e-9)
+    else:
+        assert np.allclose(np.diag(qp["P"]), gold[f"{name}/P_diag"], rtol=1e-12)
+        assert np.allclose(qp["P"].sum(1), gold[f"{name}/P_rowsum"], rtol=1e-11, atol=1e-6)
+    xs, ys = orc.solve_reference(p, qp)
+    assert np.abs(xs * p.force_scale - gold[f"{name}/u_exact"].reshape(-1)).max() < 1e-6
+    tw = orc.update(p, x0, xr, ft, ct)
+    assert tw["iters"] == int(gold[f"{name}/iters_admm"])
+    assert np.abs(tw["u"] - gold[f"{name}/u_admm"]).max() < 1e-7
+    assert np.abs(tw["u"] - gold[f"{name}/u_exact"]).max() < 5e-2      # ADMM at eps 1e-6 vs exact optimum [N]
+
+
+@pytest.mark.parametrize("name,N", CASES)
+def test_exact_optimum_satisfies_kkt_and_physics(gold, name, N):
+    p = orc.SrbdParams()
+    x0, xr, ft, ct = _case(gold, name)
+    qp = orc.build_qp(p, x0, xr, ft, ct)
+    u = gold[f"{name}/u_exact"]
+    kr = orc.kkt_residuals(qp["P"], qp["q"], qp["A"], qp["l"], qp["u"], u.reshape(-1) / p.force_scale, gold[f"{name}/y_exact"])
+    assert max(kr.values()) < 1e-8, kr
+    f = u.reshape(N, 4, 3)
+    on = ct.astype(bool)
+    assert np.all(f[~on] == 0.0)                                         # swing contacts carry no force
+    assert np.all(f[on][:, 2] >= p.fz_min - 1e-7) and np.all(f[on][:, 2] <= p.fz_max + 1e-7)
+    assert np.all(np.abs(f[on][:, 0]) <= p.mu * f[on][:, 2] + 1e-7) and np.all(np.abs(f[on][:, 1]) <= p.mu * f[on][:, 2] + 1e-7)
+    # first-step net vertical force is of the order of the weight (a standing/walking robot)
+    assert 0.3 * p.mass * 9.81 < f[0, :, 2].sum() < 3.0 * p.mass * 9.81
+
+
+@pytest.mark.parametrize("name,N", CASES[:3])
+def test_presolve_does_not_change_the_optimum(gold, name, N):
+    p = orc.SrbdParams(eps_abs=1e-8, eps_rel=1e-8, max_iter=5000)
+    x0, xr, ft, ct = _case(gold, name)
+    a = orc.update(p, x0, xr, ft, ct)["u"]
+    b = orc.update(orc.SrbdParams(**{**p.as_dict(), "eliminate_swing": False}), x0, xr, ft, ct)["u"]
+    assert np.abs(a - b).max() < 2e-3
+
+
+def test_force_scaling_is_only_a_change_of_variables(gold):
+    x0, xr, ft, ct = _case(gold, "n4_single")
+    u1 = orc.solve_reference(orc.SrbdParams(force_scale=100.0), orc.build_qp(orc.SrbdParams(force_scale=100.0), x0, xr, ft, ct))[0] * 100.0
+    u2 = orc.solve_reference(orc.SrbdParams(force_scale=10.0), orc.build_qp(orc.SrbdParams(force_scale=10.0), x0, xr, ft, ct))[0] * 10.0
+    assert np.abs(u1 - u2).max() < 1e-6
+
+
+def test_left_right_mirror_symmetry():
+    """Mirroring the scene in the x-z plane (y -> -y, left <-> right foot) mirrors the optimal forces."""
+    p = orc.SrbdParams()
+    N = 6
+    x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, 91, "double"))
+    x0[2] = 0.0; xr[:, 2] = 0.0     # yaw 0 so that the mirror plane is world x-z
+    ft = ft.copy()
+    # re-place the feet symmetric about the CoM target for yaw = 0
+    for k in range(N):
+        ft[k] = [0.0, 0.07, 0, 0.17, 0.07, 0, 0.0, -0.06, 0, 0.17, -0.06, 0]
+    S13 = np.array([-1, 1, -1, 1, -1, 1, -1, 1, -1, 1, -1, 1, 1.0])       # roll, yaw, y, wx, wz, vy flip
+    S3 = np.array([1, -1, 1.0])
+    x0m, xrm = x0 * S13, xr * S13
+    ftm = ft.reshape(N, 4, 3)[:, [2, 3, 0, 1], :] * S3
+    u = orc.solve_reference(p, orc.build_qp(p, x0, xr, ft, ct))[0].reshape(N, 4, 3)
+    um = orc.solve_reference(p, orc.build_qp(p, x0m, xrm, ftm.reshape(N, 12), ct))[0].reshape(N, 4, 3)
+    assert np.abs(um - u[:, [2, 3, 0, 1], :] * S3).max() < 1e-7
+
+
+def test_c_restatement_agrees_with_numpy_oracle(gold):
+    import c_oracle
+    for elim in (True, False):
+        p = orc.SrbdParams(eliminate_swing=elim)
+        for name, N in CASES:
+            x0, xr, ft, ct = _case(gold, name)
+            out = c_oracle.solve_batch(p, x0[None], xr[None], ft[None], ct[None])
+            key = "admm" if elim else "admm_full"
+            assert int(out["iters"][0]) == int(gold[f"{name}/iters_{key}"])
+            assert np.abs(out["u"][0] - gold[f"{name}/u_{key}"]).max() < 1e-6
+            a = c_oracle.assemble(p, x0, xr, ft, ct)
+            assert np.allclose(a["q"], gold[f"{name}/q"], rtol=1e-11, atol=1e-8)
+
+
+def test_c_restatement_is_thread_safe_and_batch_consistent():
+    import c_oracle
+    p = orc.SrbdParams()
+    x0, xr, ft, ct = orc.synthetic_batch(24, 10, 5, "mixed")
+    a = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=1)
+    b = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=4)
+    np.testing.assert_array_equal(a["u"], b["u"])
+    np.testing.assert_array_equal(a["iters"], b["iters"])
+
+
+def test_flight_phase_and_status_codes():
+    p = orc.SrbdParams()
+    x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, 10, 3, "double"))
+    r = orc.update(p, x0, xr, ft, np.zeros_like(ct))
+    assert r["status"] == orc.STATUS_SOLVED and r["iters"] == 0 and np.all(r["u"] == 0)
+    assert abs(r["x"][10, 11] - (x0[11] + 10 * p.dt * x0[12])) < 1e-12          # free fall: v_z += N dt g
+    r = orc.update(orc.SrbdParams(max_iter=5), x0, xr, ft, ct)
+    assert r["status"] == orc.STATUS_MAX_ITER and r["iters"] == 5
