@@ -141,6 +141,16 @@ def main():
         flops_launch = algorithmic_flops(N, mean_iters) * B
         achieved_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
         hbm_gbs = algorithmic_bytes(N) * B / (kernel_ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same kernel + workload
+        try:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+                d = json.load(open(f))
+                if eng.kernel_name().replace("_f64", "").replace("_n", "_kernel<").split("<")[0].split("_")[0] in d.get("kernel", "") \
+                        and f"<{N}," in d.get("kernel", "") and B == BATCH_PER_GPU:
+                    traffic = d["hbm"]["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "QP solves/sec, SRBD N=10 12-state/12-input",
             "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +162,9 @@ def main():
                        "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
                        "eps_abs": eng.cfg.eps_abs, "eps_rel": eng.cfg.eps_rel},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": None,
+                         "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*_pmc_summary.json)",
+                         "algorithmic_bytes_per_launch": algorithmic_bytes(N) * B,
                          "kernel": eng.kernel_name(), "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_qp": algorithmic_flops(N, mean_iters),
                          "hbm_algorithmic_GBps": hbm_gbs, "hbm_frac_of_8TBps": hbm_gbs / 8000.0},
