@@ -146,8 +146,7 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
                 d = json.load(open(f))
-                if eng.kernel_name().replace("_f64", "").replace("_n", "_kernel<").split("<")[0].split("_")[0] in d.get("kernel", "") \
-                        and f"<{N}," in d.get("kernel", "") and B == BATCH_PER_GPU:
+                if d.get("bench_kernel_name") == eng.kernel_name() and d.get("batch_per_launch") == B:
                     traffic = d["hbm"]["traffic_bytes_per_launch"]
         except Exception:
             traffic = None

@@ -49,6 +49,23 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
     return v;                          // lane 63 holds the wave maximum
 }
 
+// fp32 variant: one v_max_f32 with a DPP source per step (no 64-bit lane moves).  Monotone rounding commutes with max,
+// so max over float(v_i) == float(max v_i): the oracle reproduces the decision by rounding its maxima to float32.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_maxf_step(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return fmaxf(v, __int_as_float(o));
+}
+__device__ __forceinline__ float wave_maxf_nonneg(float v) {
+    v = dpp_maxf_step<0x111, 0xF>(v);
+    v = dpp_maxf_step<0x112, 0xF>(v);
+    v = dpp_maxf_step<0x114, 0xF>(v);
+    v = dpp_maxf_step<0x118, 0xF>(v);
+    v = dpp_maxf_step<0x142, 0xA>(v);
+    v = dpp_maxf_step<0x143, 0xC>(v);
+    return v;                          // lane 63 holds the wave maximum
+}
+
 // block-wide max of NV non-negative values; `slot` alternates 0/1 between consecutive calls so that one barrier
 // per call is enough (the second buffer is only rewritten after every wave has passed the next call's barrier).
 template <int NV>

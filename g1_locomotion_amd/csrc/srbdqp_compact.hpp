@@ -68,8 +68,20 @@ struct CompactSmem {
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
 };
 
-// The presolved ADMM: same iteration as admm_loop_local(), on the compact contacts.  Wave w owns compact contacts
-// [w CPW, (w+1) CPW), CPW = ceil(na / 4) <= 10.
+// Lane mapping of the presolved ADMM: the na stance contacts are packed into as FEW waves as possible (10 contacts =
+// 60 lanes per wave): the mat-vec is bound by the LDS broadcast of rhs, which every participating wave reads in
+// full, so 20 contacts on 2 waves cost half the LDS time of 20 contacts on 4 waves.  Idle waves only join barriers.
+__device__ __forceinline__ int admm_waves_used(int na) { return (na + 9) / 10; }
+__device__ __forceinline__ int admm_contacts_per_wave(int na) { const int wu = (na + 9) / 10; return (na + wu - 1) / wu; }
+
+// The presolved ADMM (OSQP Algorithm 1 on the compact contacts), arithmetic as oracle admm_solve().  Per iteration:
+//   x~ = K^-1 rhs      row fragment x rhs broadcast from LDS (all loads in flight, then the FMAs), halves summed by DPP
+//   rows               the lane carrying row j gets fz~ by one ds_bpermute pair; z~, nu, relaxation, projection, dual
+//   A'(rho z - y)      one DPP swap + two ds_bpermute pairs; new rhs to the OTHER LDS buffer; ONE barrier
+// P x is NOT updated every iteration: with c_{k+1} = (1-a) c_k + a (sigma (x_k - x~) - q) per variable and
+// s_{k+1} = (1-a) s_k + a nu_k per row, P x_k = c_k - A' s_k, so A' nu is only applied at check iterations.
+// Check iterations reduce 4 maxima in fp32 with DPP and publish them on the iteration's own barrier; the decision
+// is read at the top of the next iteration (no extra barrier, no extra iteration).
 template <int N, class L, int CHMAX>
 __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsbuf, double* xs_full,
                                  const double (&kin)[CHMAX], int na, int CH, const uint8_t* act, int* status_out) {
@@ -78,7 +90,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     constexpr int RB = 2 * CHMAX + 8;                  // one rhs buffer
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int lr = lane >> 1, h = lane & 1;
-    const int CPW = (na + 3) >> 2;
+    const int CPW = admm_contacts_per_wave(na);
     const int cg = lr / 3, ax = lr - 3 * cg;
     const int e = w * CPW + cg;
     const bool active = (cg < CPW) && (e < na);
@@ -88,13 +100,14 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     const bool has_row = active && (ax < 2 || h == 0);
     const int j = (ax < 2) ? 2 * ax + h : 4;
     const int irow = 5 * gc + j;                       // original row index (for warm_y / y_out)
-    const double sigma = a.sigma, alpha = a.alpha, mu = a.mu;
-    double* red = sm + S::o_red;
+    const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu;
+    float* redf = reinterpret_cast<float*>(sm + S::o_red);
     const double lo = (j < 4) ? -kInf : a.fzmin_s, hi = (j < 4) ? 0.0 : a.fzmax_s;
     const double rho = a.rho, irho = 1.0 / rho;
     const double sgn = (j < 4 && h == 1) ? -1.0 : 1.0;
     const double muc = (j < 4) ? mu : 0.0;
     const double rowm = has_row ? 1.0 : 0.0;
+    const bool wave_on = w < admm_waves_used(na);
 
     auto At = [&](double v) -> double {
         const double other = dpp_swap1(v);
@@ -112,12 +125,13 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     for (int i = t; i < n; i += kThreads) xs_full[i] = 0.0;
     const double qv = active ? sm[S::o_q + r] : 0.0;
     double x = (active && a.warm_u) ? a.warm_u[(size_t)b * n + 3 * gc + ax] / a.s : 0.0;
-    double px = active ? sm[S::o_px0 + r] : 0.0;
+    double cpx = active ? sm[S::o_px0 + r] : 0.0;       // P x = cpx - A' spx
+    double spx = 0.0;
     double y = (has_row && a.warm_y) ? a.warm_y[(size_t)b * m + irow] : 0.0;
-    double z = rowm * fmin(fmax(Arow(x), lo), hi);
     double axr = rowm * Arow(x);                        // (A x)_row, carried by recursion
+    double z = rowm * fmin(fmax(axr, lo), hi);
     double qn[1] = {fabs(qv)};
-    block_max<1>(qn, red);                              // its barriers also order the zero fill above
+    block_max<1>(qn, sm + S::o_red);                    // its barriers also order the zero fill above
     {
         const double rhs0 = sigma * x - qv + At(rowm * (rho * z - y));
         if (active && h == 0) rhsbuf[r] = rhs0;
@@ -125,65 +139,81 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     __syncthreads();
 
     int status = 2, iters = a.max_iter, nchk = 0;
-    for (int k = 1; k <= a.max_iter; ++k) {
+    bool pending = false;                               // a check's maxima are waiting in redf[(nchk - 1) & 1]
+    for (int k = 1; k <= a.max_iter + 1; ++k) {
+        if (pending) {   // decision of the check made at iteration k - 1 (its maxima rode on that iteration's barrier)
+            const float* buf = redf + ((nchk - 1) & 1) * 16;
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (double)fmaxf(fmaxf(buf[q], buf[4 + q]), fmaxf(buf[8 + q], buf[12 + q]));
+            const double e_prim = a.eps_abs + a.eps_rel * v[1];
+            const double e_dual = a.eps_abs + a.eps_rel * fmax(v[3], (double)(float)qn[0]);
+            if (!(v[0] <= kInf) || !(v[2] <= kInf)) { status = -1; iters = k - 1; break; }
+            if (v[0] <= e_prim && v[2] <= e_dual) { status = 1; iters = k - 1; break; }
+            pending = false;
+        }
+        if (k > a.max_iter) break;
         const bool check = (k % a.check_every == 0) || (k == a.max_iter);
         const double* rb = rhsbuf + ((k - 1) & 1) * RB;
         double* wb = rhsbuf + (k & 1) * RB;
-        double xt;
-        {
-            constexpr int BL = 8, NBMAX = (CHMAX / 2 + BL - 1) / BL;      // blocks of BL double2 = 16 columns
-            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-            const double2* rv = reinterpret_cast<const double2*>(rb + CH * h);
+        if (wave_on) {
+            double xt;
+            {
+                // all of this half's rhs in flight at once (<= 16 ds_read_b128 per block), THEN the FMAs.  Columns past
+                // CH read the zero padding and meet kin = 0.
+                constexpr int NV = CHMAX / 2, BL = (NV <= 16) ? NV : (NV + 1) / 2, NBMAX = (NV + BL - 1) / BL;
+                double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+                const double2* rv = reinterpret_cast<const double2*>(rb + CH * h);
 #pragma unroll
-            for (int blk = 0; blk < NBMAX; ++blk) {
-                if (blk * 2 * BL < CH) {                                   // wave-uniform
-                    double2 v[BL];
+                for (int blk = 0; blk < NBMAX; ++blk) {
+                    if (blk == 0 || blk * 2 * BL < CH) {                       // wave-uniform
+                        double2 v[BL];
 #pragma unroll
-                    for (int i = 0; i < BL; ++i) v[i] = rv[blk * BL + i];
+                        for (int i = 0; i < BL; ++i) v[i] = (blk * BL + i < NV) ? rv[blk * BL + i] : make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int i = 0; i < BL; i += 2) {
-                        const int c0 = 2 * (blk * BL + i);
-                        if (c0 + 1 < CHMAX) { acc0 = fma(kin[c0], v[i].x, acc0); acc1 = fma(kin[c0 + 1], v[i].y, acc1); }
-                        if (c0 + 3 < CHMAX) { acc2 = fma(kin[c0 + 2], v[i + 1].x, acc2); acc3 = fma(kin[c0 + 3], v[i + 1].y, acc3); }
+                        for (int i = 0; i < BL; ++i) {
+                            const int c0 = 2 * (blk * BL + i);
+                            if (c0 + 1 < CHMAX) {
+                                if (i & 1) { acc2 = fma(kin[c0], v[i].x, acc2); acc3 = fma(kin[c0 + 1], v[i].y, acc3); }
+                                else { acc0 = fma(kin[c0], v[i].x, acc0); acc1 = fma(kin[c0 + 1], v[i].y, acc1); }
+                            }
+                        }
                     }
                 }
+                const double acc = (acc0 + acc1) + (acc2 + acc3);
+                xt = acc + dpp_swap1(acc);
             }
-            const double acc = (acc0 + acc1) + (acc2 + acc3);
-            xt = acc + dpp_swap1(acc);
+            const double zt = Arow(xt);
+            const double nu = rowm * (rho * (zt - z) + y);
+            const double zh = alpha * zt + oma * z;
+            const double zn = fmin(fmax(zh + y * irho, lo), hi);
+            y = rowm * (y + rho * (zh - zn));
+            z = rowm * zn;
+            axr = rowm * (alpha * zt + oma * axr);          // A x^{k+1} = alpha A x~ + (1 - alpha) A x^k
+            spx = alpha * nu + oma * spx;
+            const double atw = At(rho * z - y);
+            cpx = alpha * (sigma * (x - xt) - qv) + oma * cpx;
+            x = alpha * xt + oma * x;
+            if (active && h == 0) wb[r] = sigma * x - qv + atw;
+            if (check) {
+                const double aty = At(y), px = cpx - At(spx);
+                double rd = fabs(px + qv + aty), rp = fabs(axr - z);
+                rd = (rd == rd) ? rd : kInf * 10.0;              // a NaN residual must survive the max
+                rp = (rp == rp) ? rp : kInf * 10.0;
+                const float v0 = (float)(rowm * rp), v1 = (float)(rowm * fmax(fabs(axr), fabs(z)));
+                const float v2 = active ? (float)rd : 0.0f, v3 = active ? (float)fmax(fabs(px), fabs(aty)) : 0.0f;
+                const float m0 = wave_maxf_nonneg(v0), m1 = wave_maxf_nonneg(v1), m2 = wave_maxf_nonneg(v2), m3 = wave_maxf_nonneg(v3);
+                if (lane == 63) {
+                    float* buf = redf + (nchk & 1) * 16 + 4 * w;
+                    buf[0] = m0; buf[1] = m1; buf[2] = m2; buf[3] = m3;
+                }
+            }
+        } else if (check && lane == 63) {                     // idle waves contribute zeros
+            float* buf = redf + (nchk & 1) * 16 + 4 * w;
+            buf[0] = 0.0f; buf[1] = 0.0f; buf[2] = 0.0f; buf[3] = 0.0f;
         }
-        const double zt = Arow(xt);
-        const double nu = rowm * (rho * (zt - z) + y);
-        const double zh = alpha * zt + (1.0 - alpha) * z;
-        const double zn = fmin(fmax(zh + y * irho, lo), hi);
-        y = rowm * (y + rho * (zh - zn));
-        z = rowm * zn;
-        axr = rowm * (alpha * zt + (1.0 - alpha) * axr);     // A x^{k+1} = alpha A x~ + (1 - alpha) A x^k
-        const double wv = rho * z - y;
-        const double atnu = At(nu), atw = At(wv);
-        const double pxt = sigma * (x - xt) - qv - atnu;
-        x = alpha * xt + (1.0 - alpha) * x;
-        px = alpha * pxt + (1.0 - alpha) * px;
-        if (active && h == 0) wb[r] = sigma * x - qv + atw;
-        if (check) {
-            const double aty = At(y);
-            double rd = fabs(px + qv + aty), rp = fabs(axr - z);
-            rd = (rd == rd) ? rd : kInf * 10.0;
-            rp = (rp == rp) ? rp : kInf * 10.0;
-            double v[4];
-            v[0] = rowm * rp;
-            v[1] = rowm * fmax(fabs(axr), fabs(z));
-            v[2] = active ? rd : 0.0;
-            v[3] = active ? fmax(fabs(px), fabs(aty)) : 0.0;
-            block_max_nonneg<4>(v, red, nchk & 1);
-            ++nchk;
-            const double e_prim = a.eps_abs + a.eps_rel * v[1];
-            const double e_dual = a.eps_abs + a.eps_rel * fmax(v[3], qn[0]);
-            const bool bad = !(v[0] <= kInf) || !(v[2] <= kInf);
-            if (bad) { status = -1; iters = k; break; }
-            if (v[0] <= e_prim && v[2] <= e_dual) { status = 1; iters = k; break; }
-        } else {
-            __syncthreads();
-        }
+        if (check) { ++nchk; pending = true; }
+        __syncthreads();
     }
     if (active && h == 0) xs_full[3 * gc + ax] = x;
     if (a.y_out && has_row) a.y_out[(size_t)b * m + irow] = y;
@@ -215,7 +245,9 @@ __global__ __launch_bounds__(kThreads, (MAXS <= 2 ? 3 : 2)) void srbdqp_compact_
 
     // ================= phase A =================
     SRBDQP_STAMP(a, b, 0);
+#ifndef SRBDQP_PROFILE_ADMM
     if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     load_and_linearise<N, S>(a, b, sm);
     if (t < 64) {   // presolve: compact the stance contacts (wave 0)
         const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
@@ -518,7 +550,7 @@ __global__ __launch_bounds__(kThreads, (MAXS <= 2 ? 3 : 2)) void srbdqp_compact_
     double kin[CHMAX];
     {
         const int lr = lane >> 1, h = lane & 1;
-        const int CPW = (na + 3) >> 2;
+        const int CPW = admm_contacts_per_wave(na);
         const int cg = lr / 3, e = w * CPW + cg;
         const bool rowok = (cg < CPW) && (e < na);
         const int rr = rowok ? 3 * e + (lr - 3 * cg) : 0;
@@ -555,7 +587,9 @@ __global__ __launch_bounds__(kThreads, (MAXS <= 2 ? 3 : 2)) void srbdqp_compact_
     SRBDQP_STAMP(a, b, 10);
     rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
     SRBDQP_STAMP(a, b, 11);
+#ifndef SRBDQP_PROFILE_ADMM
     if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int N, int MAXS>

@@ -278,9 +278,11 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
                 if (r_ != r_) rd = r_; else if (rd == rd) rd = fmax(rd, r_);
                 npx = fmax(npx, fabs(Px[i])); naty = fmax(naty, fabs(Atw[i]));
             }
+            /* the maxima are compared after rounding to float (the kernels reduce them in fp32; see srbd_oracle.py) */
+            rp = (double)(float)rp; rd = (double)(float)rd;
             if (!(rp <= INF) || !(rd <= INF)) { status = -1; iters = k; break; }
-            const double ep = p->eps_abs + p->eps_rel * fmax(nax, nz);
-            const double ed = p->eps_abs + p->eps_rel * fmax(fmax(npx, naty), qn);
+            const double ep = p->eps_abs + p->eps_rel * (double)(float)fmax(nax, nz);
+            const double ed = p->eps_abs + p->eps_rel * fmax((double)(float)fmax(npx, naty), (double)(float)qn);
             if (rp <= ep && rd <= ed) { status = 1; iters = k; break; }
         }
     }

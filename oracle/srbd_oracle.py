@@ -233,10 +233,13 @@ def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.
         if k % p.check_every == 0 or k == p.max_iter:
             Ax = A @ x
             Aty = A.T @ y
-            r_prim = np.max(np.abs(Ax - z))
-            r_dual = np.max(np.abs(Px + q + Aty))
-            e_prim = p.eps_abs + p.eps_rel * max(np.max(np.abs(Ax)), np.max(np.abs(z)))
-            e_dual = p.eps_abs + p.eps_rel * max(np.max(np.abs(Px)), np.max(np.abs(Aty)), qn)
+            # the four maxima (and |q|) are rounded to float32 before the comparison: the kernels reduce them across
+            # the workgroup in fp32 (one DPP v_max_f32 per step); rounding is monotone, so it commutes with max
+            f32 = lambda v: float(np.float32(v))
+            r_prim = f32(np.max(np.abs(Ax - z)))
+            r_dual = f32(np.max(np.abs(Px + q + Aty)))
+            e_prim = p.eps_abs + p.eps_rel * f32(max(np.max(np.abs(Ax)), np.max(np.abs(z))))
+            e_dual = p.eps_abs + p.eps_rel * max(f32(max(np.max(np.abs(Px)), np.max(np.abs(Aty)))), f32(qn))
             if trace is not None:
                 trace.append((k, float(r_prim), float(r_dual)))
             if not np.isfinite(r_prim + r_dual):

@@ -29,6 +29,8 @@ for B in (1, 4096):
         print(f"  {nm:10s} mean {dlt[:, i].mean() / 100:9.0f} cyc   median {np.median(dlt[:, i]) / 100:9.0f} cyc")
     tot = (s[:, 11] - s[:, 0]) * 100.0
     print(f"  total      mean {tot.mean() / 100:9.0f} cyc   per ADMM iteration {np.mean(dlt[:, 9] / np.maximum(its, 1)) / 100:.0f} cyc")
+    if os.environ.get("PROFILE") == "ADMM":
+        print("  ADMM segments (cycles/iter): matvec %.0f  rows %.0f  At x2 + update %.0f  check %.0f  barrier %.0f" % tuple((s[:, c] / np.maximum(its, 1)).mean() for c in (12, 13, 14, 15, 1)))
     if not os.environ.get("PROFILE") and s[:, 13].any():
         rt = (s[:, 13] - s[:, 12]) * 10.0   # ns, 100 MHz constant clock
         clk = (s[:, 11] - s[:, 0]) / np.maximum(rt, 1.0)
@@ -37,7 +39,7 @@ for B in (1, 4096):
         print(f"  kernel span {ends.max():.1f} us; last start {starts.max():.1f} us; 50%/90%/99% of QPs finished by {np.percentile(ends,50):.0f}/{np.percentile(ends,90):.0f}/{np.percentile(ends,99):.0f} us; sum(wall)/512 = {rt.sum()/512e3:.1f} us")
     if os.environ.get("PROFILE") == "F" and s[:, 12:16].any():
         print("  F segments (cycles total over 8 steps): store+barrier %.0f  diag16 %.0f  panel %.0f  trailing %.0f" % tuple(s[:, 12 + i].mean() for i in range(4)))
-    elif s[:, 12:16].any():
+    elif False:
         print("  ADMM segments (cycles/iter): matvec %.0f  rows+At %.0f  write+barrier %.0f  | check iterations: %.0f cycles per check" % (
             (s[:, 12] / its).mean(), (s[:, 13] / its).mean(), (s[:, 14] / np.maximum(its - its // 5, 1)).mean(), (s[:, 15] / np.maximum(its // 5, 1)).mean()))
     eng.close()
