@@ -173,7 +173,7 @@ int srbdqp_default_config(srbdqp_config* c) {
     c->device = 0;
     c->flags = 0;
     c->kernel = SRBDQP_KERNEL_AUTO;
-    c->max_iter = 500;
+    c->max_iter = 250;
     c->check_every = 5;
     c->dt = 0.04;
     c->mass = 34.13385728;

@@ -136,10 +136,16 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
         const double rhs0 = sigma * x - qv + At(rowm * (rho * z - y));
         if (active && h == 0) rhsbuf[r] = rhs0;
     }
+    if (t < 4) reinterpret_cast<int*>(redf + 32)[t] = 0;
     __syncthreads();
 
     int status = 2, iters = a.max_iter, nchk = 0;
+    long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0, tp5 = 0, seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0, seg4 = 0;
+    (void)tp0; (void)tp1; (void)tp2; (void)tp3; (void)tp4; (void)tp5; (void)seg0; (void)seg1; (void)seg2; (void)seg3; (void)seg4;
     bool pending = false;                               // a check's maxima are waiting in redf[(nchk - 1) & 1]
+    double e_prim_last = kInf * 1.0e10;                 // e_prim of the last full check (pre-test threshold)
+    int* vflag = reinterpret_cast<int*>(redf + 32);     // [4] per-wave 'some row fails the pre-test' flags
+    bool vote_ok = true;
     for (int k = 1; k <= a.max_iter + 1; ++k) {
         if (pending) {   // decision of the check made at iteration k - 1 (its maxima rode on that iteration's barrier)
             const float* buf = redf + ((nchk - 1) & 1) * 16;
@@ -148,20 +154,26 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
             for (int q = 0; q < 4; ++q) v[q] = (double)fmaxf(fmaxf(buf[q], buf[4 + q]), fmaxf(buf[8 + q], buf[12 + q]));
             const double e_prim = a.eps_abs + a.eps_rel * v[1];
             const double e_dual = a.eps_abs + a.eps_rel * fmax(v[3], (double)(float)qn[0]);
+            e_prim_last = e_prim;
             if (!(v[0] <= kInf) || !(v[2] <= kInf)) { status = -1; iters = k - 1; break; }
             if (v[0] <= e_prim && v[2] <= e_dual) { status = 1; iters = k - 1; break; }
             pending = false;
         }
         if (k > a.max_iter) break;
-        const bool check = (k % a.check_every == 0) || (k == a.max_iter);
+        const bool at_mark = (k % a.check_every == 0);
+        if (at_mark) vote_ok = (vflag[0] | vflag[1] | vflag[2] | vflag[3]) == 0;   // pre-test made at iteration k - 1
+        const bool check = (at_mark && vote_ok) || (k == a.max_iter);
+        const bool pretest = ((k + 1) % a.check_every == 0);
         const double* rb = rhsbuf + ((k - 1) & 1) * RB;
         double* wb = rhsbuf + (k & 1) * RB;
+        ADMM_T(tp0);
         if (wave_on) {
             double xt;
             {
-                // all of this half's rhs in flight at once (<= 16 ds_read_b128 per block), THEN the FMAs.  Columns past
-                // CH read the zero padding and meet kin = 0.
-                constexpr int NV = CHMAX / 2, BL = (NV <= 16) ? NV : (NV + 1) / 2, NBMAX = (NV + BL - 1) / BL;
+                // rhs in blocks of 8 ds_read_b128, all in flight before the FMAs that consume them (a bigger block spills:
+                // kin + 16 double2 exceed the 168-VGPR budget of 3 workgroups/CU, and a spilled kin value costs a scratch
+                // round trip EVERY iteration).  Columns past CH read the zero padding and meet kin = 0.
+                constexpr int NV = CHMAX / 2, BL = (NV <= 8) ? NV : 8, NBMAX = (NV + BL - 1) / BL;   // 8 ds_read_b128 in flight
                 double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
                 const double2* rv = reinterpret_cast<const double2*>(rb + CH * h);
 #pragma unroll
@@ -183,7 +195,15 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                 const double acc = (acc0 + acc1) + (acc2 + acc3);
                 xt = acc + dpp_swap1(acc);
             }
+#if defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 1 || SRBDQP_ABLATE == 5 || SRBDQP_ABLATE == 6)
+            xt = kin[0] * rb[r];   // ablation: no mat-vec
+#endif
+            ADMM_T(tp1);
+#if defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 2 || SRBDQP_ABLATE == 5 || SRBDQP_ABLATE == 6)
+            const double zt = sgn * xt;   // ablation: no fz gather
+#else
             const double zt = Arow(xt);
+#endif
             const double nu = rowm * (rho * (zt - z) + y);
             const double zh = alpha * zt + oma * z;
             const double zn = fmin(fmax(zh + y * irho, lo), hi);
@@ -191,10 +211,20 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
             z = rowm * zn;
             axr = rowm * (alpha * zt + oma * axr);          // A x^{k+1} = alpha A x~ + (1 - alpha) A x^k
             spx = alpha * nu + oma * spx;
+            ADMM_T(tp2);
+#if defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 3 || SRBDQP_ABLATE == 5 || SRBDQP_ABLATE == 6)
+            const double atw = rho * z - y;   // ablation: no A' gather
+#else
             const double atw = At(rho * z - y);
+#endif
             cpx = alpha * (sigma * (x - xt) - qv) + oma * cpx;
             x = alpha * xt + oma * x;
             if (active && h == 0) wb[r] = sigma * x - qv + atw;
+            ADMM_T(tp3);
+            if (pretest) {   // one ballot instead of a reduction: does any row still violate the last e_prim?
+                const unsigned long long bad = __ballot(has_row && !(fabs(axr - z) <= e_prim_last));
+                if (lane == 0) vflag[w] = (bad != 0ull) ? 1 : 0;
+            }
             if (check) {
                 const double aty = At(y), px = cpx - At(spx);
                 double rd = fabs(px + qv + aty), rp = fabs(axr - z);
@@ -208,13 +238,24 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                     buf[0] = m0; buf[1] = m1; buf[2] = m2; buf[3] = m3;
                 }
             }
-        } else if (check && lane == 63) {                     // idle waves contribute zeros
-            float* buf = redf + (nchk & 1) * 16 + 4 * w;
-            buf[0] = 0.0f; buf[1] = 0.0f; buf[2] = 0.0f; buf[3] = 0.0f;
+        } else {                                              // idle waves contribute zeros / 'no objection'
+            if (check && lane == 63) {
+                float* buf = redf + (nchk & 1) * 16 + 4 * w;
+                buf[0] = 0.0f; buf[1] = 0.0f; buf[2] = 0.0f; buf[3] = 0.0f;
+            }
+            if (pretest && lane == 0) vflag[w] = 0;
         }
         if (check) { ++nchk; pending = true; }
+        ADMM_T(tp4);
+#if !(defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 4 || SRBDQP_ABLATE == 6))
         __syncthreads();
+#endif
+        ADMM_T(tp5);
+        seg0 += tp1 - tp0; seg1 += tp2 - tp1; seg2 += tp3 - tp2; seg3 += tp4 - tp3; seg4 += tp5 - tp4;
     }
+#ifdef SRBDQP_PROFILE_ADMM
+    if (a.stamps && t == 0) { long long* st = a.stamps + (size_t)b * 16; st[12] = seg0; st[13] = seg1; st[14] = seg2; st[15] = seg3; st[1] = seg4; }
+#endif
     if (active && h == 0) xs_full[3 * gc + ax] = x;
     if (a.y_out && has_row) a.y_out[(size_t)b * m + irow] = y;
     __syncthreads();

@@ -236,7 +236,8 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
     for (int i = 0; i < mr; ++i) { z[i] = fmin(fmax(0.0, lo[i]), hi[i]); }
     double qn = 0.0;
     for (int i = 0; i < nr; ++i) qn = fmax(qn, fabs(qcv[i]));
-    int status = 2, iters = p->max_iter;
+    int status = 2, iters = p->max_iter, vote_ok = 1;
+    double e_prim_last = INFINITY;
     if (nr == 0) { status = 1; iters = 0; }
     for (int k = 1; k <= p->max_iter && nr > 0; ++k) {
         for (int i = 0; i < mr; ++i) wv[i] = rho[i] * z[i] - y[i];
@@ -265,7 +266,16 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
             y[i] = y[i] + rho[i] * (zh - zn);
             z[i] = zn;
         }
-        if (k % p->check_every == 0 || k == p->max_iter) {
+        /* residual pre-test (see srbd_oracle.py): full check at k only if |Ax - z| <= e_prim_last held at k-1 */
+        if ((k + 1) % p->check_every == 0) {
+            double rpm = 0;
+            for (int i = 0; i < mr; ++i) {
+                const double* v = x + 3 * (i / 5);
+                rpm = fmax(rpm, fabs(A_ROW(v, i % 5) - z[i]));
+            }
+            vote_ok = (rpm <= e_prim_last);
+        }
+        if ((k % p->check_every == 0 && vote_ok) || k == p->max_iter) {
             double rp = 0, rd = 0, nax = 0, nz = 0, npx = 0, naty = 0;
             for (int i = 0; i < mr; ++i) {
                 const double* v = x + 3 * (i / 5);
@@ -282,6 +292,7 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
             rp = (double)(float)rp; rd = (double)(float)rd;
             if (!(rp <= INF) || !(rd <= INF)) { status = -1; iters = k; break; }
             const double ep = p->eps_abs + p->eps_rel * (double)(float)fmax(nax, nz);
+            e_prim_last = ep;
             const double ed = p->eps_abs + p->eps_rel * fmax((double)(float)fmax(npx, naty), (double)(float)qn);
             if (rp <= ep && rd <= ed) { status = 1; iters = k; break; }
         }

@@ -73,7 +73,7 @@ class SrbdParams:
     alpha: float = 1.6
     eps_abs: float = 1.0e-6
     eps_rel: float = 1.0e-6
-    max_iter: int = 500
+    max_iter: int = 250
     check_every: int = 5
     # presolve: variables of swing contacts (force clamped to 0) are eliminated before the ADMM (kernel v2);
     # False = keep all 12N variables and clamp through the bounds (kernel v0/v1)
@@ -218,6 +218,7 @@ def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.
     Px = P @ x
     qn = np.max(np.abs(q))
     status, iters = STATUS_MAX_ITER, p.max_iter
+    e_prim_last, vote_ok = np.inf, True
     for k in range(1, p.max_iter + 1):
         rhs = sigma * x - q + A.T @ (rho * z - y)
         xt = Kinv @ rhs
@@ -230,7 +231,13 @@ def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.
         zn = np.clip(zh + y / rho, l, u)
         y = y + rho * (zh - zn)
         z = zn
+        # Residual pre-test (kernels: one ballot, no reduction): a full convergence check at iteration k is only made
+        # if at iteration k-1 every row satisfied |Ax - z| <= e_prim of the LAST full check (inf before the first one).
+        if (k + 1) % p.check_every == 0:
+            vote_ok = bool(np.max(np.abs(A @ x - z)) <= e_prim_last)
         if k % p.check_every == 0 or k == p.max_iter:
+            if not (vote_ok or k == p.max_iter):
+                continue
             Ax = A @ x
             Aty = A.T @ y
             # the four maxima (and |q|) are rounded to float32 before the comparison: the kernels reduce them across
@@ -240,6 +247,7 @@ def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.
             r_dual = f32(np.max(np.abs(Px + q + Aty)))
             e_prim = p.eps_abs + p.eps_rel * f32(max(np.max(np.abs(Ax)), np.max(np.abs(z))))
             e_dual = p.eps_abs + p.eps_rel * max(f32(max(np.max(np.abs(Px)), np.max(np.abs(Aty)))), f32(qn))
+            e_prim_last = e_prim
             if trace is not None:
                 trace.append((k, float(r_prim), float(r_dual)))
             if not np.isfinite(r_prim + r_dual):

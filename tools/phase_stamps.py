@@ -16,7 +16,7 @@ for B in (1, 4096):
     u = torch.empty((B, 10, 12), dtype=torch.float64, device=dev)
     it = torch.empty(B, dtype=torch.int32, device=dev)
     st = torch.zeros((B, 16), dtype=torch.int64, device=dev)
-    eng = BatchMPC(horizon=10, max_contacts_per_step=int(os.environ.get("MAXS", "2")), kernel=int(os.environ.get("KERNEL", "0")))
+    eng = BatchMPC(horizon=10, max_contacts_per_step=int(os.environ.get("MAXS", "2")), kernel=int(os.environ.get("KERNEL", "0")), **({"max_iter": 35, "eps_abs": 0.0, "eps_rel": 0.0} if os.environ.get("FIXED_ITERS") else {}))
     eng._lib.srbdqp_set_stamp_buffer(eng._h, C.c_void_p(st.data_ptr()))
     for _ in range(3):
         eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(), iters=it.data_ptr())
@@ -30,7 +30,7 @@ for B in (1, 4096):
     tot = (s[:, 11] - s[:, 0]) * 100.0
     print(f"  total      mean {tot.mean() / 100:9.0f} cyc   per ADMM iteration {np.mean(dlt[:, 9] / np.maximum(its, 1)) / 100:.0f} cyc")
     if os.environ.get("PROFILE") == "ADMM":
-        print("  ADMM segments (cycles/iter): matvec %.0f  rows %.0f  At x2 + update %.0f  check %.0f  barrier %.0f" % tuple((s[:, c] / np.maximum(its, 1)).mean() for c in (12, 13, 14, 15, 1)))
+        print("  ADMM segments (cycles/iter): matvec %.0f  Arow+rows %.0f  At(w)+update+write %.0f  check(amortised) %.0f  barrier %.0f" % tuple((s[:, c] / np.maximum(its, 1)).mean() for c in (12, 13, 14, 15, 1)))
     if not os.environ.get("PROFILE") and s[:, 13].any():
         rt = (s[:, 13] - s[:, 12]) * 10.0   # ns, 100 MHz constant clock
         clk = (s[:, 11] - s[:, 0]) / np.maximum(rt, 1.0)
