@@ -23,7 +23,7 @@ KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT = 0, 1, 2, 3
 EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",
     "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_assemble_f64",
-    "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_kernel_name", "srbdqp_version",
+    "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_kernel_name", "srbdqp_version",
 )
 
 
@@ -41,6 +41,12 @@ class Config(C.Structure):
         ("force_scale", C.c_double), ("rho", C.c_double), ("rho_eq_scale", C.c_double), ("sigma", C.c_double),
         ("alpha", C.c_double), ("eps_abs", C.c_double), ("eps_rel", C.c_double),
     ]
+
+
+class Stage(C.Structure):
+    """struct srbdqp_stage (include/srbdqp.h): host addresses of the pinned, GPU-mapped staging arrays."""
+    _fields_ = [("capacity", C.c_int32), ("reserved", C.c_int32)] + [(k, C.c_void_p) for k in (
+        "x0", "x_ref", "foot", "contact", "pcom", "warm_u", "warm_y", "u", "x", "y", "status", "iters")]
 
 
 _lib = None
@@ -99,6 +105,10 @@ def load():
     lib.srbdqp_solve_batch_device_f64.restype = C.c_int
     lib.srbdqp_assemble_f64.argtypes = [H, C.c_int32, dp, dp, dp, u8p, dp, dp, dp, dp, dp]
     lib.srbdqp_assemble_f64.restype = C.c_int
+    lib.srbdqp_stage_ptrs.argtypes = [H, C.POINTER(Stage)]
+    lib.srbdqp_stage_ptrs.restype = C.c_int
+    lib.srbdqp_solve_staged_f64.argtypes = [H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.srbdqp_solve_staged_f64.restype = C.c_int
     lib.srbdqp_set_stamp_buffer.argtypes = [H, C.c_void_p]
     lib.srbdqp_set_stamp_buffer.restype = C.c_int
     lib.srbdqp_synchronize.argtypes = [H]

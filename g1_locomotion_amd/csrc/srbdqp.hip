@@ -28,6 +28,11 @@ struct srbdqp_handle {
     std::string err;
     const char* kname = "none";
     long long* stamps = nullptr;   // diagnostic stamp buffer (device), see srbdqp_set_stamp_buffer
+    // low-latency staging: one pinned, GPU-mapped slab carved into the arrays of srbdqp_stage
+    char* stage_host = nullptr;
+    char* stage_dev = nullptr;
+    srbdqp_stage stage_h{};        // host addresses
+    srbdqp_stage stage_d{};        // device addresses of the same memory
 };
 
 namespace {
@@ -211,6 +216,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->stage_host) (void)hipHostFree(h->stage_host);
         delete h;
         return SRBDQP_E_HIP;
     };
@@ -218,6 +224,26 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+    {   // staging slab for the low-latency path
+        const size_t N = (size_t)cfg->horizon, n = 12 * N, m = 20 * N, cap = 16;
+        auto carve = [&](char* base, srbdqp_stage& st) {
+            Carver c(base);
+            st.capacity = (int32_t)cap;
+            st.x0 = c.take<double>(cap * 13); st.x_ref = c.take<double>(cap * N * 13); st.foot = c.take<double>(cap * N * 12);
+            st.contact = c.take<uint8_t>(cap * N * 4); st.pcom = c.take<double>(cap * N * 3);
+            st.warm_u = c.take<double>(cap * n); st.warm_y = c.take<double>(cap * m);
+            st.u = c.take<double>(cap * n); st.x = c.take<double>(cap * (N + 1) * 13); st.y = c.take<double>(cap * m);
+            st.status = c.take<int32_t>(cap); st.iters = c.take<int32_t>(cap);
+            return c.off;
+        };
+        srbdqp_stage tmp{};
+        const size_t bytes = carve(reinterpret_cast<char*>(4096), tmp);   // dry run for the size (non-null base)
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->stage_host), bytes, hipHostMallocMapped)) != hipSuccess) return fail("hipHostMalloc(staging)", e);
+        if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->stage_dev), h->stage_host, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
+        std::memset(h->stage_host, 0, bytes);
+        carve(h->stage_host, h->stage_h);
+        carve(h->stage_dev, h->stage_d);
+    }
     *out = h;
     return SRBDQP_OK;
 }
@@ -227,6 +253,7 @@ int srbdqp_destroy(srbdqp_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -237,6 +264,35 @@ int srbdqp_destroy(srbdqp_handle* h) {
 const char* srbdqp_last_error(const srbdqp_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 const char* srbdqp_kernel_name(const srbdqp_handle* h) { return h ? h->kname : "none"; }
+
+int srbdqp_stage_ptrs(srbdqp_handle* h, srbdqp_stage* out) {
+    if (!h || !out) return SRBDQP_E_INVALID;
+    *out = h->stage_h;
+    return SRBDQP_OK;
+}
+
+int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32_t use_warm, int32_t want_x, int32_t want_y) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || B > h->stage_h.capacity) { h->err = "staged batch exceeds the staging capacity"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    const srbdqp_stage& d = h->stage_d;
+    if (h->cfg.max_contacts_per_step <= 0) {   // same per-batch kernel choice as the host-buffer API
+        int worst = 0;
+        const uint8_t* c = h->stage_h.contact;
+        for (size_t q = 0; q < (size_t)B * h->cfg.horizon; ++q) {
+            const int cnt = (c[4 * q] != 0) + (c[4 * q + 1] != 0) + (c[4 * q + 2] != 0) + (c[4 * q + 3] != 0);
+            if (cnt > worst) worst = cnt;
+        }
+        h->maxs_override = (worst <= 2) ? 2 : 4;
+    }
+    int rc = srbdqp_solve_batch_device_f64(h, B, d.x0, d.x_ref, d.foot, d.contact, use_pcom ? d.pcom : nullptr,
+                                           use_warm ? d.warm_u : nullptr, use_warm ? d.warm_y : nullptr, d.u,
+                                           want_x ? d.x : nullptr, want_y ? d.y : nullptr, d.status, d.iters, h->stream);
+    h->maxs_override = 0;
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SRBDQP_OK;
+}
 
 int srbdqp_set_stamp_buffer(srbdqp_handle* h, void* device_ptr) {
     if (!h) return SRBDQP_E_INVALID;

@@ -74,6 +74,7 @@ class BatchMPC:
     # -- lifetime ------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            self._stage = None                      # the views point into memory the library is about to free
             self._lib.srbdqp_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -141,6 +142,30 @@ class BatchMPC:
                                                      v(iters), v(stream))
         _lib.check(rc, self._h)
 
+    # -- low-latency staged API (small batches; the single-robot control loop) --------------------------
+    def stage(self):
+        """NumPy views of the library's pinned, GPU-mapped staging arrays (dict; first axis = capacity)."""
+        if getattr(self, "_stage", None) is None:
+            st = _lib.Stage()
+            _lib.check(self._lib.srbdqp_stage_ptrs(self._h, C.byref(st)), self._h)
+            cap, N, n, m = st.capacity, self.N, self.n, self.m
+
+            def view(addr, ctype, shape):
+                cnt = int(np.prod(shape))
+                return np.ctypeslib.as_array((ctype * cnt).from_address(addr)).reshape(shape)
+            d, u8, i32 = C.c_double, C.c_uint8, C.c_int32
+            self._stage = dict(
+                capacity=cap, x0=view(st.x0, d, (cap, NX)), x_ref=view(st.x_ref, d, (cap, N, NX)),
+                foot=view(st.foot, d, (cap, N, NU)), contact=view(st.contact, u8, (cap, N, NC)),
+                pcom=view(st.pcom, d, (cap, N, 3)), warm_u=view(st.warm_u, d, (cap, n)), warm_y=view(st.warm_y, d, (cap, m)),
+                u=view(st.u, d, (cap, N, NU)), x=view(st.x, d, (cap, N + 1, NX)), y=view(st.y, d, (cap, m)),
+                status=view(st.status, i32, (cap,)), iters=view(st.iters, i32, (cap,)))
+        return self._stage
+
+    def solve_staged(self, B=1, use_pcom=False, use_warm=False, want_x=True, want_y=False):
+        """One kernel launch over the first B staged QPs; inputs are read and outputs written in the staging arrays."""
+        _lib.check(self._lib.srbdqp_solve_staged_f64(self._h, int(B), int(use_pcom), int(use_warm), int(want_x), int(want_y)), self._h)
+
     def synchronize(self):
         _lib.check(self._lib.srbdqp_synchronize(self._h), self._h)
 
@@ -166,7 +191,7 @@ class MPC:
         self._device = device
         self._overrides = overrides
         self._engine: Optional[BatchMPC] = None
-        self._warm = None
+        self._warm = False
         self.u_opt = None                       # (N, 12) last optimal forces [N]
         self.x_opt = None                       # (N+1, 13) last roll-out
         self.status = 0
@@ -179,31 +204,35 @@ class MPC:
         return self
 
     def solve(self, x_current, x_ref_hor, c_horizon, contact_horizon, p_com_horizon=None):
-        """Assemble + solve one QP on the GPU; returns (u (N,12) newtons, x (N+1,13))."""
+        """Assemble + solve one QP on the GPU; returns (u (N,12) newtons, x (N+1,13)).
+        Inputs are written straight into the library's pinned staging arrays (no hipMemcpy on this path)."""
         if self._engine is None:
             self.init_matrices()
-        N = self.HORIZON_LENGTH
-        x0 = np.asarray(x_current, dtype=np.float64).reshape(1, NX)
-        xr = np.asarray(x_ref_hor, dtype=np.float64).reshape(1, N, NX)
-        ft = np.asarray(c_horizon, dtype=np.float64).reshape(1, N, NU)
-        ct = np.asarray(contact_horizon).reshape(1, N, NC)
-        pc = None if p_com_horizon is None else np.asarray(p_com_horizon, dtype=np.float64).reshape(1, N, 3)
-        wu, wy = (None, None)
-        if self.warm_start and self._warm is not None:
-            wu, wy = self._warm
-        out = self._engine.solve(x0, xr, ft, ct, pcom=pc, warm_u=wu, warm_y=wy, want_x=True, want_y=self.warm_start)
-        self.status = int(out["status"][0])
-        self.iters = int(out["iters"][0])
-        self.u_opt = out["u"][0]
-        self.x_opt = out["x"][0]
+        eng, N = self._engine, self.HORIZON_LENGTH
+        st = eng.stage()
+        st["x0"][0] = np.asarray(x_current, dtype=np.float64).reshape(NX)
+        st["x_ref"][0] = np.asarray(x_ref_hor, dtype=np.float64).reshape(N, NX)
+        st["foot"][0] = np.asarray(c_horizon, dtype=np.float64).reshape(N, NU)
+        st["contact"][0] = np.asarray(contact_horizon).reshape(N, NC) != 0
+        use_pcom = p_com_horizon is not None
+        if use_pcom:
+            st["pcom"][0] = np.asarray(p_com_horizon, dtype=np.float64).reshape(N, 3)
+        use_warm = self.warm_start and self._warm
+        eng.solve_staged(1, use_pcom=use_pcom, use_warm=use_warm, want_x=True, want_y=self.warm_start)
+        self.status = int(st["status"][0])
+        self.iters = int(st["iters"][0])
+        self.u_opt = st["u"][0].copy()
+        self.x_opt = st["x"][0].copy()
         if self.warm_start and self.status in (_lib.SOLVED, _lib.MAX_ITER):
-            # shift the plan one step: next call's u_k starts from this call's u_{k+1}
-            u_shift = np.vstack([self.u_opt[1:], self.u_opt[-1:]]).reshape(1, -1)
-            y = out["y"].reshape(N, _lib.ROWS_PER_STEP)
-            y_shift = np.vstack([y[1:], y[-1:]]).reshape(1, -1)
-            self._warm = (u_shift, y_shift)
+            # shift the plan one step: next call's u_k starts from this call's u_{k+1}; written in place for the next call
+            wu = st["warm_u"][0].reshape(N, NU)
+            wu[:-1] = self.u_opt[1:]; wu[-1] = self.u_opt[-1]
+            y = st["y"][0].reshape(N, _lib.ROWS_PER_STEP)
+            wy = st["warm_y"][0].reshape(N, _lib.ROWS_PER_STEP)
+            wy[:-1] = y[1:]; wy[-1] = y[-1]
+            self._warm = True
         else:
-            self._warm = None
+            self._warm = False
         return self.u_opt, self.x_opt
 
     def update(self, contact_horizon: Sequence, c_horizon: Sequence, p_com_horizon, x_current=None,
@@ -217,7 +246,7 @@ class MPC:
         return u_opt0, x_opt1
 
     def reset_warm_start(self):
-        self._warm = None
+        self._warm = False
 
     def close(self):
         if self._engine is not None:

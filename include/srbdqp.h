@@ -130,6 +130,19 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B,
                         const uint8_t* contact, const double* pcom,
                         double* P_out, double* q_out, double* l_out, double* ub_out);
 
+/* Low-latency path for small batches (the single-robot control loop, B = 1): the library owns pinned, GPU-mapped host
+ * staging arrays; the caller fills the inputs in place, calls srbdqp_solve_staged_f64 (one kernel launch that reads and
+ * writes the staging memory directly over PCIe -- no hipMemcpy calls), and reads the outputs in place.  Shapes as in
+ * srbdqp_solve_batch_f64 with B <= capacity.  ~ MPC.update() for one robot (run_simulation.py:106). */
+typedef struct srbdqp_stage {
+    int32_t capacity;             /* max B */
+    int32_t reserved;
+    double* x0; double* x_ref; double* foot; uint8_t* contact; double* pcom; double* warm_u; double* warm_y;
+    double* u; double* x; double* y; int32_t* status; int32_t* iters;
+} srbdqp_stage;
+int srbdqp_stage_ptrs(srbdqp_handle* h, srbdqp_stage* out);
+int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32_t use_warm, int32_t want_x, int32_t want_y);
+
 /* Diagnostic: device buffer [B][16] of int64 that subsequent solves fill with per-QP s_memtime stamps of the kernel's
  * phase boundaries (100 MHz constant clock); NULL switches stamping off.  Not part of the drop-in surface. */
 int srbdqp_set_stamp_buffer(srbdqp_handle* h, void* device_ptr);

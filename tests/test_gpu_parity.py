@@ -111,3 +111,31 @@ def test_contact_bound_and_empty_contact_set(torch_first, built_lib):
         out = eng.solve(x0, xr, ft, ct)
     assert (out["status"][[0, 2, 3]] == _lib.CONTACT_BOUND).all() and out["status"][1] == orc.STATUS_SOLVED
     assert np.all(out["u"][[0, 2, 3]] == 0.0)
+
+
+def test_mpc_update_drop_in_path(torch_first, built_lib):
+    """The reference caller's sequence (g1_mujoco_sim/src/run_simulation.py:73-111) through MPC.update(): shapes of
+    what comes back, parity with the oracle, and warm starting across consecutive control steps."""
+    from g1_locomotion_amd import mpc
+    N = 10
+    x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=55, schedule="double"))
+    MPC = mpc.MPC(dt=0.04)
+    MPC.init_matrices()
+    MPC.x0[:] = x0.reshape(13, 1)
+    MPC.x_ref_hor[:] = xr
+    c_horizon = [ft[k].copy() for k in range(MPC.HORIZON_LENGTH)]
+    contact_horizon = [np.array([1, 1, 1, 1]) for _ in range(MPC.HORIZON_LENGTH)]
+    p_com_horizon = MPC.x_ref_hor[:, 3:6].copy()
+    u_opt0, x_opt1 = MPC.update(contact_horizon, c_horizon, p_com_horizon, x_current=MPC.x0, one_rollout=True)
+    assert u_opt0.flatten().shape == (12,) and x_opt1.shape == (N + 1, 13) and x_opt1[1, 3:6].flatten().shape == (3,)
+    ref = orc.update(orc.SrbdParams(), x0, xr, ft, ct, pcom_hor=p_com_horizon)
+    assert MPC.status == ref["status"] == orc.STATUS_SOLVED
+    assert np.abs(u_opt0.flatten() - ref["u"][0]).max() <= TOL_TWIN_N
+    assert np.abs(x_opt1 - ref["x"]).max() <= 1e-5
+    # next control step: same scene, state moved to the predicted one, plan and duals shifted by one step (warm start)
+    MPC.x0[:] = x_opt1[1].reshape(13, 1)
+    u2, _ = MPC.update(contact_horizon, c_horizon, p_com_horizon, x_current=MPC.x0, one_rollout=False)
+    assert MPC.status == orc.STATUS_SOLVED
+    ref2 = orc.update(orc.SrbdParams(eps_abs=1e-8, eps_rel=1e-8, max_iter=3000), x_opt1[1], xr, ft, ct, pcom_hor=p_com_horizon)
+    assert np.abs(u2.flatten() - ref2["u"][0]).max() <= TOL_EXACT_N
+    MPC.close()
