@@ -6,7 +6,7 @@
 """
 from . import _lib  # noqa: F401
 from . import mpc  # noqa: F401
-from .mpc import MPC, BatchMPC  # noqa: F401
+from .mpc import MPC, BatchMPC, RaggedMPC  # noqa: F401
 from ._lib import SrbdqpError  # noqa: F401
 
-__all__ = ["mpc", "MPC", "BatchMPC", "SrbdqpError"]
+__all__ = ["mpc", "MPC", "BatchMPC", "RaggedMPC", "SrbdqpError"]

@@ -48,7 +48,9 @@ std::string g_create_err;
         }                                                                                        \
     } while (0)
 
-bool horizon_supported(int N) { return N == 8 || N == 10 || N == 12 || N == 4; }
+// fp64 instantiations: N in {4, 8, 10} with up to 4 stance contacts per step; N in {12, 16} with at most 2 (the dense
+// 12N x 12N inverse of the larger cases does not fit on chip)
+bool horizon_supported(int N) { return N == 4 || N == 8 || N == 10 || N == 12 || N == 16; }
 
 int resolve_kernel(const srbdqp_config& c) {
     if (c.kernel == SRBDQP_KERNEL_GJ) return SRBDQP_KERNEL_GJ;
@@ -124,6 +126,18 @@ int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int variant, int 
     return SRBDQP_OK;
 }
 
+template <int N>
+int launch_long(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
+    if (a.mode == 1) { h->err = "srbdqp_assemble_f64 is limited to horizons <= 10"; return SRBDQP_E_INVALID; }
+    // only the <= 2-contacts-per-step instantiation exists: a QP with more stance contacts in a step comes back with
+    // status SRBDQP_CONTACT_BOUND
+    (void)maxs;
+    int rc = launch_compact<N, 2>(h, a, st);
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipGetLastError());
+    return SRBDQP_OK;
+}
+
 int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4) {
     if (a.B <= 0) return SRBDQP_OK;
     const int variant = (a.mode == 1) ? SRBDQP_KERNEL_GJ : resolve_kernel(h->cfg);
@@ -134,6 +148,8 @@ int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4) {
         case 4: rc = launch_n<4>(h, a, st, variant, maxs); break;
         case 8: rc = launch_n<8>(h, a, st, variant, maxs); break;
         case 10: rc = launch_n<10>(h, a, st, variant, maxs); break;
+        case 12: rc = launch_long<12>(h, a, st, maxs); break;
+        case 16: rc = launch_long<16>(h, a, st, maxs); break;
         default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
     }
     if (rc != SRBDQP_OK) return rc;
@@ -198,7 +214,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if (!cfg || !out) { g_create_err = "null argument"; return SRBDQP_E_INVALID; }
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(srbdqp_config)) { g_create_err = "srbdqp_config.struct_size mismatch"; return SRBDQP_E_INVALID; }
-    if (!horizon_supported(cfg->horizon) || cfg->horizon > 10) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10})"; return SRBDQP_E_INVALID; }
+    if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10}; {12, 16} with max_contacts_per_step <= 2)"; return SRBDQP_E_INVALID; }
+    if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons 12 and 16 exist only for the compact kernel"; return SRBDQP_E_INVALID; }
     if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) ||
         cfg->max_iter < 1 || cfg->check_every < 1 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }

@@ -66,6 +66,10 @@ struct CompactSmem {
     static constexpr int endC = o_xs + n;
     static constexpr int o_end = cmax(endA, cmax(endB, endC));
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
+    // workgroups per CU that LDS admits (160 KiB per CU), capped at 3: the register budget the kernel is compiled for
+    // (3 only for the small problems: a 168-register budget cannot hold a K^-1 row fragment of more than 30 doubles)
+    static constexpr int lds_wgs = 163840 / (int)bytes;
+    static constexpr int waves_per_simd = (lds_wgs >= 3 && nmax <= 60) ? 3 : (lds_wgs >= 2 ? 2 : 1);
 };
 
 // Lane mapping of the presolved ADMM: the na stance contacts are packed into as FEW waves as possible (10 contacts =
@@ -264,13 +268,14 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
 }
 
 template <int N, int MAXS>
-__global__ __launch_bounds__(kThreads, (MAXS <= 2 ? 3 : 2)) void srbdqp_compact_kernel(KArgs a) {
+__global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) void srbdqp_compact_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     using S = CompactSmem<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m;
     constexpr int TS = S::TS, CHMAX = S::CHMAX;
     static_assert(S::NT <= 8, "W phase assumes at most two tiles per wave per block row");
     static_assert(2 * S::nmax <= kThreads, "two threads per compact column / row");
+    static_assert(4 * N <= 64, "the presolve compacts the 4N contact flags with one wave-wide ballot");
     static_assert((S::o_R % 2) == 0 && (S::o_rhs % 2) == 0, "16-byte alignment");
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(kThreads, (MAXS <= 2 ? 3 : 2)) void srbdqp_compact_
         const bool flag = (t < 4 * N) && sct[t < 4 * N ? t : 0] != 0;
         const unsigned long long bal = __ballot(flag);
         if (flag) act[__popcll(bal & ((1ull << t) - 1ull))] = (uint8_t)t;
-        if (t < N) icnt[t] = __popcll(bal & ((1ull << (4 * (t + 1))) - 1ull));
+        if (t < N) icnt[t] = __popcll(bal & ((4 * (t + 1) >= 64) ? ~0ull : ((1ull << (4 * (t + 1))) - 1ull)));
         if (t == 0) {
             imisc[0] = __popcll(bal);
             sm[S::o_misc] = 0.0;

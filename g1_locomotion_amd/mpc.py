@@ -176,6 +176,37 @@ class BatchMPC:
         return self._lib.srbdqp_kernel_name(self._h).decode()
 
 
+class RaggedMPC:
+    """Mixed-horizon batches (BASELINE.json configs[4]): QPs are bucketed by horizon and every bucket is one kernel
+    launch on its own engine / HIP stream, so the buckets run concurrently.  Per-QP contact schedules are free."""
+
+    def __init__(self, horizons=(8, 12, 16), dt: float = 0.04, device: int = 0, **overrides):
+        self.engines = {int(N): BatchMPC(horizon=int(N), dt=dt, device=device, **overrides) for N in horizons}
+
+    def solve(self, problems):
+        """problems: sequence of dicts(x0 (13,), x_ref (N,13), foot (N,12), contact (N,4)[, pcom (N,3)]) with per-QP N.
+        Returns a list of dicts(u (N,12), x (N+1,13), status, iters) in the input order."""
+        buckets = {}
+        for i, pr in enumerate(problems):
+            N = int(np.asarray(pr["x_ref"]).shape[0])
+            if N not in self.engines:
+                raise ValueError(f"no engine for horizon {N} (have {sorted(self.engines)})")
+            buckets.setdefault(N, []).append(i)
+        out = [None] * len(problems)
+        for N, idx in buckets.items():
+            has_pcom = all("pcom" in problems[i] for i in idx)
+            res = self.engines[N].solve(np.stack([problems[i]["x0"] for i in idx]), np.stack([problems[i]["x_ref"] for i in idx]),
+                                        np.stack([problems[i]["foot"] for i in idx]), np.stack([problems[i]["contact"] for i in idx]),
+                                        pcom=np.stack([problems[i]["pcom"] for i in idx]) if has_pcom else None)
+            for j, i in enumerate(idx):
+                out[i] = dict(u=res["u"][j], x=res["x"][j], status=int(res["status"][j]), iters=int(res["iters"][j]))
+        return out
+
+    def close(self):
+        for e in self.engines.values():
+            e.close()
+
+
 class MPC:
     """Drop-in for ``srbd_mpc.mpc.MPC`` on the hot path (run_simulation.py:169-170,73-82,96,103,106)."""
 

@@ -139,3 +139,27 @@ def test_mpc_update_drop_in_path(torch_first, built_lib):
     ref2 = orc.update(orc.SrbdParams(eps_abs=1e-8, eps_rel=1e-8, max_iter=3000), x_opt1[1], xr, ft, ct, pcom_hor=p_com_horizon)
     assert np.abs(u2.flatten() - ref2["u"][0]).max() <= TOL_EXACT_N
     MPC.close()
+
+
+def test_ragged_horizons_bucketed_launch(torch_first, built_lib):
+    """BASELINE.json configs[4] (fp64 subset): mixed horizons N in {8, 12, 16}, per-QP random-phase single-support
+    schedule, one launch per horizon bucket; every QP against the oracle twin and the exact optimum."""
+    from g1_locomotion_amd import RaggedMPC
+    rng = np.random.default_rng(5)
+    problems = []
+    for i in range(18):
+        N = int(rng.choice([8, 12, 16]))
+        x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=900 + i, schedule="single"))
+        problems.append(dict(x0=x0, x_ref=xr, foot=ft, contact=ct))
+    eng = RaggedMPC(horizons=(8, 12, 16))
+    res = eng.solve(problems)
+    eng.close()
+    p = orc.SrbdParams()
+    for pr, r in zip(problems, res):
+        ref = orc.update(p, pr["x0"], pr["x_ref"], pr["foot"], pr["contact"])
+        assert r["status"] == ref["status"] and abs(r["iters"] - ref["iters"]) <= p.check_every
+        assert r["u"].shape == pr["foot"].shape and np.abs(r["u"] - ref["u"]).max() <= TOL_TWIN_N
+        assert np.abs(r["x"] - ref["x"]).max() <= 1e-5
+        if ref["status"] == orc.STATUS_SOLVED:
+            xs, _ = orc.solve_reference(p, ref["qp"])
+            assert np.abs(r["u"].reshape(-1) - xs * p.force_scale).max() <= TOL_EXACT_N
