@@ -23,7 +23,7 @@ KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT = 0, 1, 2, 3
 EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",
     "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_assemble_f64",
-    "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_kernel_name", "srbdqp_version",
+    "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_kernel_name", "srbdqp_version",
 )
 
 
@@ -105,6 +105,8 @@ def load():
     lib.srbdqp_solve_batch_device_f64.restype = C.c_int
     lib.srbdqp_assemble_f64.argtypes = [H, C.c_int32, dp, dp, dp, u8p, dp, dp, dp, dp, dp]
     lib.srbdqp_assemble_f64.restype = C.c_int
+    lib.srbdqp_set_schedule_hint.argtypes = [H, C.c_void_p]
+    lib.srbdqp_set_schedule_hint.restype = C.c_int
     lib.srbdqp_stage_ptrs.argtypes = [H, C.POINTER(Stage)]
     lib.srbdqp_stage_ptrs.restype = C.c_int
     lib.srbdqp_solve_staged_f64.argtypes = [H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]

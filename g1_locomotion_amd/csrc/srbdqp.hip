@@ -28,6 +28,9 @@ struct srbdqp_handle {
     std::string err;
     const char* kname = "none";
     long long* stamps = nullptr;   // diagnostic stamp buffer (device), see srbdqp_set_stamp_buffer
+    const int32_t* sched_hint = nullptr;   // device: previous step's iters[] (srbdqp_set_schedule_hint)
+    int32_t* perm = nullptr;       // device: dispatch order built from the hint
+    size_t perm_cap = 0;
     // low-latency staging: one pinned, GPU-mapped slab carved into the arrays of srbdqp_stage
     char* stage_host = nullptr;
     char* stage_dev = nullptr;
@@ -36,6 +39,30 @@ struct srbdqp_handle {
 };
 
 namespace {
+
+// Longest-first dispatch order from the previous step's iteration counts (one workgroup; counting sort by iters/4,
+// descending).  QPs that needed many ADMM iterations last time are started first, so the straggler tail of a launch
+// overlaps the bulk instead of trailing it.  The hint only orders work; every QP is solved in full either way.
+__global__ __launch_bounds__(1024) void srbdqp_schedule_kernel(const int32_t* iters_prev, int32_t* perm, int B) {
+    __shared__ int cnt[128];
+    __shared__ int base[128];
+    const int t = threadIdx.x;
+    if (t < 128) cnt[t] = 0;
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) {
+        int k = iters_prev[i] >> 2;
+        k = k < 0 ? 0 : (k > 127 ? 127 : k);
+        atomicAdd(&cnt[127 - k], 1);
+    }
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int k = 0; k < 128; ++k) { base[k] = acc; acc += cnt[k]; } }
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) {
+        int k = iters_prev[i] >> 2;
+        k = k < 0 ? 0 : (k > 127 ? 127 : k);
+        perm[atomicAdd(&base[127 - k], 1)] = i;
+    }
+}
 
 std::string g_create_err;
 
@@ -270,6 +297,7 @@ int srbdqp_destroy(srbdqp_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->perm) (void)hipFree(h->perm);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -311,6 +339,12 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     return SRBDQP_OK;
 }
 
+int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev) {
+    if (!h) return SRBDQP_E_INVALID;
+    h->sched_hint = device_iters_prev;
+    return SRBDQP_OK;
+}
+
 int srbdqp_set_stamp_buffer(srbdqp_handle* h, void* device_ptr) {
     if (!h) return SRBDQP_E_INVALID;
     h->stamps = reinterpret_cast<long long*>(device_ptr);
@@ -345,8 +379,19 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
     a.warm_u = warm_u; a.warm_y = warm_y;
     a.u_out = u_out; a.x_out = x_out; a.y_out = y_out; a.status = status; a.iters = iters;
     a.B = B; a.mode = 0; a.stamps = h->stamps;
+    hipStream_t lst = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+    if (h->sched_hint && B > 1) {
+        if ((size_t)B > h->perm_cap) {
+            if (h->perm) HIP_TRY(h, hipFree(h->perm));
+            h->perm = nullptr; h->perm_cap = 0;
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->perm), sizeof(int32_t) * (size_t)B));
+            h->perm_cap = (size_t)B;
+        }
+        hipLaunchKernelGGL(srbdqp_schedule_kernel, dim3(1), dim3(1024), 0, lst, h->sched_hint, h->perm, (int)B);
+        a.perm = h->perm;
+    }
     int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
-    return launch(h, a, stream ? reinterpret_cast<hipStream_t>(stream) : h->stream, maxs);
+    return launch(h, a, lst, maxs);
 }
 
 int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,

@@ -34,6 +34,7 @@ struct KArgs {
     double* q_out;           // [B][n]
     double* l_out;           // [B][m]
     double* ub_out;          // [B][m]
+    const int32_t* perm;     // optional dispatch order: workgroup i solves QP perm[i] (longest-first scheduling), or null
     long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null
     int32_t B;
     int32_t mode;            // 0 = solve, 1 = assemble only
@@ -43,6 +44,9 @@ struct KArgs {
     double rs2;              // r_diag * s^2
     double rho, rho_eq, sigma, alpha, eps_abs, eps_rel;
 };
+
+// QP index of this workgroup
+#define SRBDQP_QP_INDEX(a) ((a).perm ? (a).perm[blockIdx.x] : (int)blockIdx.x)
 
 // diagnostic phase stamp (thread 0 only; leaves the kernel through a buffer nothing else reads)
 #define SRBDQP_STAMP(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)

@@ -277,8 +277,8 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     static_assert(2 * S::nmax <= kThreads, "two threads per compact column / row");
     static_assert(4 * N <= 64, "the presolve compacts the 4N contact flags with one wave-wide ballot");
     static_assert((S::o_R % 2) == 0 && (S::o_rhs % 2) == 0, "16-byte alignment");
-    const int b = blockIdx.x;
-    if (b >= a.B) return;
+    if ((int)blockIdx.x >= a.B) return;
+    const int b = SRBDQP_QP_INDEX(a);
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int mcol = lane & 15, kq = lane >> 4;

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(kThreads) void srbdqp_gj_kernel(KArgs a) {
     constexpr int n = Dims<N>::n, m = Dims<N>::m, CH = n / 2;
     static_assert(n <= 128, "gj variant: two threads per row of K, n <= 128");
     static_assert((S::o_rhs % 2) == 0 && (CH % 2) == 0, "16-byte alignment of the rhs halves");
-    const int b = blockIdx.x;
-    if (b >= a.B) return;
+    if ((int)blockIdx.x >= a.B) return;
+    const int b = SRBDQP_QP_INDEX(a);
     const int t = threadIdx.x, r = t >> 1, h = t & 1;
     double* G = sm + GS::o_G;
     double* rowbuf = sm + GS::o_row;

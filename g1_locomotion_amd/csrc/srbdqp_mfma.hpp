@@ -200,8 +200,8 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
     static_assert(n <= 128, "mfma variant: two threads per row of K^-1, n <= 128");
     static_assert(NT <= 8, "W phase assumes at most two tiles per wave per block row");
     static_assert((S::o_rhs % 2) == 0 && (CH % 2) == 0 && (S::o_R % 2) == 0, "16-byte alignment");
-    const int b = blockIdx.x;
-    if (b >= a.B) return;
+    if ((int)blockIdx.x >= a.B) return;
+    const int b = SRBDQP_QP_INDEX(a);
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int mcol = lane & 15, kq = lane >> 4;       // MFMA operand coordinates of this lane

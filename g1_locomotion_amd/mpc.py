@@ -142,6 +142,10 @@ class BatchMPC:
                                                      v(iters), v(stream))
         _lib.check(rc, self._h)
 
+    def set_schedule_hint(self, iters_prev_ptr=0):
+        """Device address of the previous step's iters[] (or 0): longest-first dispatch for the next device solves."""
+        _lib.check(self._lib.srbdqp_set_schedule_hint(self._h, C.c_void_p(int(iters_prev_ptr)) if iters_prev_ptr else None), self._h)
+
     # -- low-latency staged API (small batches; the single-robot control loop) --------------------------
     def stage(self):
         """NumPy views of the library's pinned, GPU-mapped staging arrays (dict; first axis = capacity)."""

@@ -130,6 +130,14 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B,
                         const uint8_t* contact, const double* pcom,
                         double* P_out, double* q_out, double* l_out, double* ub_out);
 
+/* Longest-first scheduling hint for the DEVICE-buffer API: `device_iters_prev` = the iters[] array (device memory,
+ * length >= B) of the previous control step of the same batch, or NULL to switch the hint off.  Subsequent device
+ * solves first build a dispatch order from it (one tiny kernel on the same stream) so that QPs that needed many ADMM
+ * iterations last step start first and the straggler tail overlaps the bulk of the launch.  In a receding-horizon
+ * loop consecutive steps of a robot are strongly correlated; a wrong hint costs nothing but the reordering.  The
+ * pointer is read at every solve; results, status[] and iters[] stay in the caller's QP order. */
+int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev);
+
 /* Low-latency path for small batches (the single-robot control loop, B = 1): the library owns pinned, GPU-mapped host
  * staging arrays; the caller fills the inputs in place, calls srbdqp_solve_staged_f64 (one kernel launch that reads and
  * writes the staging memory directly over PCIe -- no hipMemcpy calls), and reads the outputs in place.  Shapes as in

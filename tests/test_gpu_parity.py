@@ -163,3 +163,30 @@ def test_ragged_horizons_bucketed_launch(torch_first, built_lib):
         if ref["status"] == orc.STATUS_SOLVED:
             xs, _ = orc.solve_reference(p, ref["qp"])
             assert np.abs(r["u"].reshape(-1) - xs * p.force_scale).max() <= TOL_EXACT_N
+
+
+def test_schedule_hint_only_reorders_work(torch_first, built_lib):
+    """Longest-first dispatch from the previous step's iteration counts: bit-identical results in the caller's order."""
+    torch = torch_first
+    from g1_locomotion_amd import BatchMPC
+    N, B = 10, 300
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=31, schedule="single")
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(v).to(dev) for v in (x0, xr, ft, ct)]
+    outs = []
+    with BatchMPC(horizon=N, max_contacts_per_step=2) as eng:
+        it_prev = None
+        for rep in range(3):
+            u = torch.zeros((B, N, 12), dtype=torch.float64, device=dev)
+            it = torch.zeros(B, dtype=torch.int32, device=dev)
+            st = torch.zeros(B, dtype=torch.int32, device=dev)
+            eng.set_schedule_hint(it_prev.data_ptr() if it_prev is not None else 0)
+            eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(),
+                             status=st.data_ptr(), iters=it.data_ptr())
+            eng.synchronize()
+            outs.append((u.cpu().numpy(), it.cpu().numpy(), st.cpu().numpy()))
+            it_prev = it if rep == 0 else (it_prev.flip(0).contiguous())      # second round: a deliberately wrong hint
+    for u, it, st in outs[1:]:
+        np.testing.assert_array_equal(u, outs[0][0])
+        np.testing.assert_array_equal(it, outs[0][1])
+        np.testing.assert_array_equal(st, outs[0][2])
