@@ -190,3 +190,28 @@ def test_schedule_hint_only_reorders_work(torch_first, built_lib):
         np.testing.assert_array_equal(u, outs[0][0])
         np.testing.assert_array_equal(it, outs[0][1])
         np.testing.assert_array_equal(st, outs[0][2])
+
+
+@pytest.mark.parametrize("N,pattern,B", [(10, "single", 2048), (10, "mixed", 1024), (10, "random", 1024), (8, "random", 512), (16, "single", 256)])
+def test_large_batch_against_c_oracle(torch_first, built_lib, N, pattern, B):
+    """Statistical parity at scale against the compiled oracle: every QP of a large seeded batch, including arbitrary
+    per-point contact patterns (steps with 0, 1 or 3 stance points, whole-horizon flight)."""
+    import c_oracle
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=4000 + N, schedule="single" if pattern == "random" else pattern)
+    if pattern == "random":
+        rng = np.random.default_rng(17)
+        ct = (rng.random(ct.shape) < 0.6).astype(np.uint8)
+        ct[0] = 0; ct[1] = 1; ct[2, :, 1:] = 0            # flight, full double support, a single heel point
+    p = orc.SrbdParams()
+    ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
+    with _engine(N) as eng:
+        out = eng.solve(x0, xr, ft, ct)
+        assert eng.kernel_name().startswith("compact_")
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
+    same = out["iters"] == ref["iters"]
+    assert same.mean() > 0.97
+    err = np.abs(out["u"] - ref["u"]).reshape(B, -1).max(1)
+    assert err[same].max() <= 1e-4 and err.max() <= TOL_TWIN_N, (err[same].max(), err.max())
+    assert np.abs(out["x"] - ref["x"]).max() <= 1e-5
+    assert np.all(out["u"].reshape(B, N, 4, 3)[ct == 0] == 0.0)
