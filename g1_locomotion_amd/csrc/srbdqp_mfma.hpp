@@ -120,6 +120,15 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return fma(r, e, r);
 }
 
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (d is a positive, normal pivot).
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d * r;
+    r = fma(r, fma(-h, r, 0.5), r);
+    h = 0.5 * d * r;
+    return fma(r, fma(-h, r, 0.5), r);
+}
+
 // One elimination step, P compile-time so that every t[] index is static.  The multipliers l_rP (one per lane)
 // reach the other lanes two ways: the one on the critical path (row P+1, which produces the next pivot) by
 // v_readlane, all the others by an LDS all-gather (one ds_write_b64 + broadcast ds_read_b128s) whose latency hides
@@ -175,7 +184,7 @@ __device__ __forceinline__ bool diag16_invert(double* tile, int lane) {
     double dsave = (lane == 0) ? d0 : 1.0;
     bool ok = d0 > 0.0;
     diag16_step<0>(t, dsave, ok, fast_rcp(d0), lane, tile);
-    const double rsv = 1.0 / sqrt(dsave);             // lane p: d_p^-1/2
+    const double rsv = fast_rsqrt(dsave);             // lane p: d_p^-1/2
     if (lane < 16) tile[lane] = rsv;
     asm volatile("" ::: "memory");
     double2 rs2[8];
