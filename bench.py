@@ -57,6 +57,7 @@ def main():
                          "(QPs that need many ADMM iterations) overlaps the bulk of the next; 1 = strictly serial steps")
     ap.add_argument("--no-sched-hint", action="store_true",
                     help="do not feed the previous step's iteration counts back as the longest-first dispatch hint")
+    ap.add_argument("--max-iter", type=int, default=0, help="override srbdqp_config.max_iter (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -97,7 +98,8 @@ def main():
 
     kid = {"auto": _lib.KERNEL_AUTO, "gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "compact": _lib.KERNEL_COMPACT}[args.kernel]
     # configs[1] is the 2-contact (single support) workload: at most 2 stance contact points per horizon step
-    eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=2)
+    eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=2,
+                   **({"max_iter": args.max_iter} if args.max_iter > 0 else {}))
     # non-default streams: the C-ABI treats a NULL stream as "the handle's own", and the HIP events that time a kernel
     # must sit on the stream the kernel is launched on
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
