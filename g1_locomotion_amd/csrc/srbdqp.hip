@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <atomic>
+#include <chrono>
 #include <string>
 
 #include "srbdqp.h"
@@ -36,6 +38,12 @@ struct srbdqp_handle {
     char* stage_dev = nullptr;
     srbdqp_stage stage_h{};        // host addresses
     srbdqp_stage stage_d{};        // device addresses of the same memory
+    // completion word of the staged path (last 64 bytes of the slab) + device counter of finished workgroups
+    volatile int32_t* done_host = nullptr;
+    int32_t* done_dev = nullptr;
+    int32_t* done_count = nullptr;
+    int32_t done_seq = 0;
+    bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
 };
 
 namespace {
@@ -232,7 +240,7 @@ int srbdqp_default_config(srbdqp_config* c) {
     for (int i = 0; i < 13; ++i) c->q_diag[i] = q[i];
     c->r_diag = 1.0e-4;
     c->force_scale = 100.0;
-    c->rho = 1.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
+    c->rho = 1.5; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.5;
     c->eps_abs = 1.0e-6; c->eps_rel = 1.0e-6;
     return SRBDQP_OK;
 }
@@ -261,6 +269,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         if (h->stage_host) (void)hipHostFree(h->stage_host);
+        if (h->done_count) (void)hipFree(h->done_count);
         delete h;
         return SRBDQP_E_HIP;
     };
@@ -281,12 +290,17 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
             return c.off;
         };
         srbdqp_stage tmp{};
-        const size_t bytes = carve(reinterpret_cast<char*>(4096), tmp);   // dry run for the size (non-null base)
-        if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->stage_host), bytes, hipHostMallocMapped)) != hipSuccess) return fail("hipHostMalloc(staging)", e);
+        const size_t body = (carve(reinterpret_cast<char*>(4096), tmp) + 255) & ~size_t(255);   // dry run for the size
+        const size_t bytes = body + 256;
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->stage_host), bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return fail("hipHostMalloc(staging)", e);
         if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->stage_dev), h->stage_host, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
         std::memset(h->stage_host, 0, bytes);
         carve(h->stage_host, h->stage_h);
         carve(h->stage_dev, h->stage_d);
+        h->done_host = reinterpret_cast<volatile int32_t*>(h->stage_host + body);
+        h->done_dev = reinterpret_cast<int32_t*>(h->stage_dev + body);
+        if ((e = hipMalloc(reinterpret_cast<void**>(&h->done_count), 64)) != hipSuccess) return fail("hipMalloc(done counter)", e);
+        if ((e = hipMemset(h->done_count, 0, 64)) != hipSuccess) return fail("hipMemset(done counter)", e);
     }
     *out = h;
     return SRBDQP_OK;
@@ -298,6 +312,7 @@ int srbdqp_destroy(srbdqp_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
     if (h->perm) (void)hipFree(h->perm);
+    if (h->done_count) (void)hipFree(h->done_count);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -330,11 +345,29 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
         }
         h->maxs_override = (worst <= 2) ? 2 : 4;
     }
+    // completion: the compact kernel publishes a sequence number in host memory after its outputs (signal_done());
+    // spinning on it skips the stream's completion interrupt (~15 us).  Other kernel variants: stream synchronise.
+    const bool spin = resolve_kernel(h->cfg) == SRBDQP_KERNEL_COMPACT && !(h->cfg.flags & SRBDQP_FLAG_NO_SPIN);
+    if (spin) { h->done_seq = (h->done_seq == INT32_MAX) ? 1 : h->done_seq + 1; h->signal_next = true; }
     int rc = srbdqp_solve_batch_device_f64(h, B, d.x0, d.x_ref, d.foot, d.contact, use_pcom ? d.pcom : nullptr,
                                            use_warm ? d.warm_u : nullptr, use_warm ? d.warm_y : nullptr, d.u,
                                            want_x ? d.x : nullptr, want_y ? d.y : nullptr, d.status, d.iters, h->stream);
     h->maxs_override = 0;
+    h->signal_next = false;
     if (rc != SRBDQP_OK) return rc;
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned polls = 0;
+        while (*h->done_host != h->done_seq) {
+            if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                // slow or failed launch: hand over to the runtime (reports a fault, or returns once the kernel is done)
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return SRBDQP_OK;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SRBDQP_OK;
 }
@@ -379,6 +412,7 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
     a.warm_u = warm_u; a.warm_y = warm_y;
     a.u_out = u_out; a.x_out = x_out; a.y_out = y_out; a.status = status; a.iters = iters;
     a.B = B; a.mode = 0; a.stamps = h->stamps;
+    if (h->signal_next) { a.done_flag = h->done_dev; a.done_count = h->done_count; a.done_value = h->done_seq; }
     hipStream_t lst = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
     if (h->sched_hint && B > 1) {
         if ((size_t)B > h->perm_cap) {

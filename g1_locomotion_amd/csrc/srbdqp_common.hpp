@@ -36,6 +36,9 @@ struct KArgs {
     double* ub_out;          // [B][m]
     const int32_t* perm;     // optional dispatch order: workgroup i solves QP perm[i] (longest-first scheduling), or null
     long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null
+    int32_t* done_flag;      // low-latency completion: GPU-mapped host word that receives done_value once every QP of the
+    int32_t* done_count;     //   launch has stored its outputs (done_count: device counter of finished workgroups), or null
+    int32_t done_value;
     int32_t B;
     int32_t mode;            // 0 = solve, 1 = assemble only
     int32_t max_iter, check_every;
@@ -50,6 +53,23 @@ struct KArgs {
 
 // diagnostic phase stamp (thread 0 only; leaves the kernel through a buffer nothing else reads)
 #define SRBDQP_STAMP(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+
+// Low-latency completion signal (srbdqp_solve_staged_f64): after a workgroup's outputs are stored, make them visible
+// to the host and let the last workgroup of the launch publish done_value in host memory; the host spins on that word
+// instead of waiting for the stream's completion interrupt.
+__device__ __forceinline__ void signal_done(const KArgs& a) {
+    if (!a.done_flag) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool last = true;
+        if (a.B > 1) {
+            last = (atomicAdd(a.done_count, 1) == a.B - 1);
+            if (last) *a.done_count = 0;
+        }
+        if (last) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 template <int N>
 struct Dims {

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
         }
         __syncthreads();
         rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+        signal_done(a);
         return;
     }
     SRBDQP_STAMP(a, b, 1);
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     }
     SRBDQP_STAMP(a, b, 10);
     rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+    signal_done(a);
     SRBDQP_STAMP(a, b, 11);
 #ifndef SRBDQP_PROFILE_ADMM
     if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();

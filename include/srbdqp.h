@@ -48,6 +48,8 @@ extern "C" {
 
 /* srbdqp_config.flags */
 #define SRBDQP_FLAG_TIMING 1      /* bracket every kernel launch with HIP events (srbdqp_last_kernel_ms) */
+#define SRBDQP_FLAG_NO_SPIN 2     /* srbdqp_solve_staged_f64: wait with hipStreamSynchronize instead of spinning on the
+                                     completion word the kernel writes to host memory */
 
 /* srbdqp_config.kernel: which implementation of the hot path runs */
 #define SRBDQP_KERNEL_AUTO  0     /* the fastest parity-green kernel */

@@ -1,0 +1,103 @@
+"""Batch-1 latency breakdown of the staged (zero-copy) path on the GPU box.
+
+  python tools/latency_probe.py [calls]
+
+Prints p50/p99 of (a) the bare C-ABI call srbdqp_solve_staged_f64(h, 1, ...) with inputs already staged, with the
+host spinning on the kernel's completion word and with hipStreamSynchronize, (b) the HIP-event kernel time,
+(c) the Python MPC.update() path, cold / warm, and on a closed-loop sequence (consecutive, similar QPs).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+
+
+def pct(ts):
+    ts = np.asarray(ts) * 1e6
+    return {"p50_us": round(float(np.percentile(ts, 50)), 2), "p99_us": round(float(np.percentile(ts, 99)), 2),
+            "min_us": round(float(ts.min()), 2)}
+
+
+def main():
+    calls = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    import torch  # noqa: F401  (same HIP runtime as the tests)
+    import srbd_oracle as orc
+    from g1_locomotion_amd import BatchMPC, MPC, _lib
+    x0, xr, ft, ct = orc.synthetic_batch(64, 10, seed=99, schedule="single")
+    out = {}
+    for name, kw in (("spin", {}), ("stream_sync", {"flags": _lib.FLAG_NO_SPIN}), ("spin_eps1e-3", {"eps_abs": 1e-3, "eps_rel": 1e-3})):
+        eng = BatchMPC(horizon=10, **kw)
+        st = eng.stage()
+        ts, its = [], []
+        for i in range(calls + 100):
+            b = i % 64
+            st["x0"][0] = x0[b]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]
+            t = time.perf_counter()
+            eng.solve_staged(1, want_x=True)
+            ts.append(time.perf_counter() - t)
+            its.append(int(st["iters"][0]))
+        out[f"c_abi_{name}"] = dict(pct(ts[100:]), mean_iters=float(np.mean(its[100:])))
+        eng.close()
+    eng = BatchMPC(horizon=10, timing=True)
+    st = eng.stage()
+    ks = []
+    for i in range(300):
+        b = i % 64
+        st["x0"][0] = x0[b]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]
+        eng.solve_staged(1, want_x=True)
+        ks.append(eng.last_kernel_ms() * 1e-3)
+    out["kernel_events"] = pct(ks[50:])
+    eng.close()
+    for warm in (False, True):
+        mpc = MPC(dt=0.04, horizon=10, warm_start=warm)
+        mpc.init_matrices()
+        ts = []
+        for i in range(calls + 100):
+            b = i % 64
+            mpc.x_ref_hor[:] = xr[b]
+            t = time.perf_counter()
+            mpc.update(list(ct[b]), list(ft[b]), xr[b][:, 3:6], x_current=x0[b].reshape(13, 1), one_rollout=True)
+            ts.append(time.perf_counter() - t)
+        out["mpc_update_" + ("warm" if warm else "cold")] = pct(ts[100:])
+        mpc.close()
+    # closed loop: consecutive QPs of one robot (standing with a push, then stepping in place)
+    from srbd_plant import SrbdPlant
+    from g1_locomotion_amd import msgs
+    FEET = np.array([[0.0, 0.0645, 0.0], [0.17, 0.0645, 0.0], [0.0, -0.0645, 0.0], [0.17, -0.0645, 0.0]])
+    COM = np.array([0.085, 0.0, 0.598])
+    for warm in (False, True):
+        for standing in (True, False):
+            mpc = MPC(dt=0.04, horizon=10, warm_start=warm)
+            mpc.init_matrices()
+            real_update = mpc.update
+            ts, its = [], []
+
+            def timed(*a, **k):
+                t = time.perf_counter()
+                r = real_update(*a, **k)
+                ts.append(time.perf_counter() - t); its.append(mpc.iters)
+                return r
+            mpc.update = timed
+            plant = SrbdPlant(orc.SrbdParams())
+            node = msgs.MpcNode(mpc, msgs.AlternatingGait(dt=0.04, standing=standing), com_target=COM)
+            x = np.zeros(13); x[3:6] = COM + np.array([0.01, -0.01, -0.01]); x[0] = 0.03; x[12] = -9.80665
+            t_sim, u0 = 0.0, np.zeros(12)
+            for k in range(200 if standing else 25):
+                xo, u0, act, land = msgs.unpack_mpc_solution(node.step(msgs.make_srbd_current(x, FEET, u0, stamp=t_sim)))
+                if standing and k % 40 == 5:
+                    x[9:12] += np.array([0.1, 0.05, 0.0])
+                for _ in range(10):
+                    x = plant.step(x, FEET, u0, 0.004)
+                t_sim += 0.04
+            out[f"closed_loop_{'standing' if standing else 'stepping'}_{'warm' if warm else 'cold'}"] = dict(pct(ts[5:]), mean_iters=float(np.mean(its[5:])))
+            mpc.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
