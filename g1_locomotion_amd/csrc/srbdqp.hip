@@ -240,7 +240,7 @@ int srbdqp_default_config(srbdqp_config* c) {
     for (int i = 0; i < 13; ++i) c->q_diag[i] = q[i];
     c->r_diag = 1.0e-4;
     c->force_scale = 100.0;
-    c->rho = 1.5; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.5;
+    c->rho = 1.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
     c->eps_abs = 1.0e-6; c->eps_rel = 1.0e-6;
     return SRBDQP_OK;
 }

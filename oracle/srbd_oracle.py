@@ -67,10 +67,10 @@ class SrbdParams:
     # fixed variable scaling u = force_scale * u_hat (stands in for OSQP's Ruiz equilibration)
     force_scale: float = 100.0
     # ADMM (OSQP Algorithm 1) constants
-    rho: float = 1.5
+    rho: float = 1.0
     rho_eq_scale: float = 1.0e3
     sigma: float = 1.0e-6
-    alpha: float = 1.5
+    alpha: float = 1.6
     eps_abs: float = 1.0e-6
     eps_rel: float = 1.0e-6
     max_iter: int = 250

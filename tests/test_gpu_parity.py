@@ -5,7 +5,7 @@ Tolerances (fp64 path), stated once:
   * forces vs the oracle's ADMM twin:            <= 2e-3 N when the iteration counts agree within one check interval
                                                  (the two differ only by summation order; an iterate landing within
                                                  rounding of the stopping threshold may stop one check later)
-  * forces vs the independent exact QP optimum:  <= 1e-1 N  (5e-4 of a nominal 200 N stance force; ADMM stops
+  * forces vs the independent exact QP optimum:  <= 5e-2 N  (2.5e-4 of a nominal 200 N stance force; ADMM stops
                                                  at eps_abs = eps_rel = 1e-6 in the scaled variables)
 """
 import numpy as np
@@ -16,7 +16,7 @@ import srbd_oracle as orc
 pytestmark = pytest.mark.gpu
 
 TOL_TWIN_N = 2e-3
-TOL_EXACT_N = 1e-1
+TOL_EXACT_N = 5e-2
 
 
 @pytest.fixture(scope="module")

@@ -86,7 +86,7 @@ def test_golden_vectors_are_reproduced(gold, name, N):
     tw = orc.update(p, x0, xr, ft, ct)
     assert tw["iters"] == int(gold[f"{name}/iters_admm"])
     assert np.abs(tw["u"] - gold[f"{name}/u_admm"]).max() < 1e-7
-    assert np.abs(tw["u"] - gold[f"{name}/u_exact"]).max() < 1e-1      # ADMM at eps 1e-6 vs exact optimum [N]
+    assert np.abs(tw["u"] - gold[f"{name}/u_exact"]).max() < 5e-2      # ADMM at eps 1e-6 vs exact optimum [N]
 
 
 @pytest.mark.parametrize("name,N", CASES)
@@ -112,7 +112,7 @@ def test_presolve_does_not_change_the_optimum(gold, name, N):
     x0, xr, ft, ct = _case(gold, name)
     a = orc.update(p, x0, xr, ft, ct)["u"]
     b = orc.update(orc.SrbdParams(**{**p.as_dict(), "eliminate_swing": False}), x0, xr, ft, ct)["u"]
-    assert np.abs(a - b).max() < 5e-3
+    assert np.abs(a - b).max() < 2e-3
 
 
 def test_force_scaling_is_only_a_change_of_variables(gold):
