@@ -6,7 +6,8 @@
 """
 from . import _lib  # noqa: F401
 from . import mpc  # noqa: F401
+from . import swing_trajectory  # noqa: F401
 from .mpc import MPC, BatchMPC, RaggedMPC  # noqa: F401
 from ._lib import SrbdqpError  # noqa: F401
 
-__all__ = ["mpc", "MPC", "BatchMPC", "RaggedMPC", "SrbdqpError"]
+__all__ = ["mpc", "swing_trajectory", "MPC", "BatchMPC", "RaggedMPC", "SrbdqpError"]

@@ -25,6 +25,8 @@ EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",
     "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_assemble_f64",
     "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_kernel_name", "srbdqp_version",
+    # include/srbdqp_cascade.h
+    "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
 )
 
 
@@ -120,6 +122,14 @@ def load():
     lib.srbdqp_last_kernel_ms.restype = C.c_double
     lib.srbdqp_kernel_name.argtypes = [H]
     lib.srbdqp_kernel_name.restype = C.c_char_p
+    lib.srbdqp_swing_f64.argtypes = [H, C.c_int64, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp]
+    lib.srbdqp_swing_f64.restype = C.c_int
+    lib.srbdqp_swing_device_f64.argtypes = [H, C.c_int64, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, C.c_void_p]
+    lib.srbdqp_swing_device_f64.restype = C.c_int
+    lib.srbdqp_wbid_reference_f64.argtypes = [H, C.c_int64, dp, dp, dp, C.c_int32, dp, dp, dp, dp]
+    lib.srbdqp_wbid_reference_f64.restype = C.c_int
+    lib.srbdqp_wbid_reference_device_f64.argtypes = [H, C.c_int64, dp, dp, dp, C.c_int32, dp, dp, dp, dp, C.c_void_p]
+    lib.srbdqp_wbid_reference_device_f64.restype = C.c_int
     lib.srbdqp_version.argtypes = []
     lib.srbdqp_version.restype = C.c_char_p
     _lib = lib

@@ -15,6 +15,8 @@
 #include "srbdqp_gj.hpp"
 #include "srbdqp_mfma.hpp"
 #include "srbdqp_compact.hpp"
+#include "srbdqp_cascade.hpp"
+#include "srbdqp_cascade.h"
 
 using srbdqp::KArgs;
 
@@ -524,6 +526,121 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const dou
     HIP_TRY(h, hipMemcpyAsync(q_out, dq, b * n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(l_out, dl, b * m * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(ub_out, du, b * m * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return SRBDQP_OK;
+}
+
+// ---- the steps either side of the QP (include/srbdqp_cascade.h) --------------------------------------------------
+namespace {
+inline unsigned elementwise_grid(long long B) {
+    // grid-stride kernels: enough 256-thread workgroups to fill 256 CUs several times over, no more
+    const long long want = (B + 255) / 256;
+    return (unsigned)(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
+}
+}  // namespace
+
+int srbdqp_swing_device_f64(srbdqp_handle* h, int64_t B, const double* p_start, const double* p_final,
+                            const double* z_middle, const double* progress, double final_velocity_z,
+                            double first_half_share, double* pos, double* vel_z, double* acc_z, double* coeff,
+                            void* stream) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!p_start || !p_final || !z_middle || !progress || !pos))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    srbdqp::SwingArgs a{p_start, p_final, z_middle, progress, pos, vel_z, acc_z, coeff, final_velocity_z, first_half_share, (long long)B};
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+    hipLaunchKernelGGL(srbdqp::srbdqp_swing_kernel, dim3(elementwise_grid(B)), dim3(256), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    h->kname = "swing_f64";
+    return SRBDQP_OK;
+}
+
+int srbdqp_swing_f64(srbdqp_handle* h, int64_t B, const double* p_start, const double* p_final, const double* z_middle,
+                     const double* progress, double final_velocity_z, double first_half_share, double* pos,
+                     double* vel_z, double* acc_z, double* coeff) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!p_start || !p_final || !z_middle || !progress || !pos))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t b = (size_t)B;
+    double *ds, *df, *dm, *dt, *dp, *dv, *da, *dc;
+    auto carve = [&](Carver& c) {
+        ds = c.take<double>(b * 3); df = c.take<double>(b * 3); dm = c.take<double>(b); dt = c.take<double>(b);
+        dp = c.take<double>(b * 3);
+        dv = vel_z ? c.take<double>(b) : nullptr; da = acc_z ? c.take<double>(b) : nullptr;
+        dc = coeff ? c.take<double>(b * 7) : nullptr;
+    };
+    Carver sz(nullptr);
+    carve(sz);
+    int rc = ensure_ws(h, sz.off);
+    if (rc != SRBDQP_OK) return rc;
+    Carver cv(h->ws);
+    carve(cv);
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(ds, p_start, b * 24, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(df, p_final, b * 24, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dm, z_middle, b * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dt, progress, b * 8, hipMemcpyHostToDevice, st));
+    rc = srbdqp_swing_device_f64(h, B, ds, df, dm, dt, final_velocity_z, first_half_share, dp, dv, da, dc, st);
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(pos, dp, b * 24, hipMemcpyDeviceToHost, st));
+    if (vel_z) HIP_TRY(h, hipMemcpyAsync(vel_z, dv, b * 8, hipMemcpyDeviceToHost, st));
+    if (acc_z) HIP_TRY(h, hipMemcpyAsync(acc_z, da, b * 8, hipMemcpyDeviceToHost, st));
+    if (coeff) HIP_TRY(h, hipMemcpyAsync(coeff, dc, b * 56, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return SRBDQP_OK;
+}
+
+int srbdqp_wbid_reference_device_f64(srbdqp_handle* h, int64_t B, const double* x_next, const double* u0,
+                                     const double* foot, int32_t as_written, double* R, double* base_vel,
+                                     double* base_acc, double* com_acc, void* stream) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!x_next || !u0 || !foot || !R || !base_vel || !base_acc || !com_acc))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    srbdqp::WbidRefArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x_next = x_next; a.u0 = u0; a.foot = foot; a.R = R; a.base_vel = base_vel; a.base_acc = base_acc; a.com_acc = com_acc;
+    for (int i = 0; i < 3; ++i) a.iinv[i] = 1.0 / h->cfg.inertia[i];
+    a.mass = h->cfg.mass;
+    a.gravity = -9.80665;   // wbid.py:286
+    a.as_written = as_written ? 1 : 0;
+    a.B = (long long)B;
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+    hipLaunchKernelGGL(srbdqp::srbdqp_wbid_reference_kernel, dim3(elementwise_grid(B)), dim3(256), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    h->kname = "wbid_reference_f64";
+    return SRBDQP_OK;
+}
+
+int srbdqp_wbid_reference_f64(srbdqp_handle* h, int64_t B, const double* x_next, const double* u0, const double* foot,
+                              int32_t as_written, double* R, double* base_vel, double* base_acc, double* com_acc) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!x_next || !u0 || !foot || !R || !base_vel || !base_acc || !com_acc))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t b = (size_t)B;
+    double *dx, *du, *df, *dR, *dv, *da, *dc;
+    auto carve = [&](Carver& c) {
+        dx = c.take<double>(b * 13); du = c.take<double>(b * 12); df = c.take<double>(b * 12);
+        dR = c.take<double>(b * 9); dv = c.take<double>(b * 6); da = c.take<double>(b * 6); dc = c.take<double>(b * 3);
+    };
+    Carver sz(nullptr);
+    carve(sz);
+    int rc = ensure_ws(h, sz.off);
+    if (rc != SRBDQP_OK) return rc;
+    Carver cv(h->ws);
+    carve(cv);
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(dx, x_next, b * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(du, u0, b * 12 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(df, foot, b * 12 * 8, hipMemcpyHostToDevice, st));
+    rc = srbdqp_wbid_reference_device_f64(h, B, dx, du, df, as_written, dR, dv, da, dc, st);
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(R, dR, b * 9 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(base_vel, dv, b * 6 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(base_acc, da, b * 6 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(com_acc, dc, b * 3 * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     return SRBDQP_OK;
 }

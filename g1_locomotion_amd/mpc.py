@@ -26,6 +26,13 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_p = _ptr
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
 def _as(a, dtype, shape, name):
     arr = np.ascontiguousarray(a, dtype=dtype)
     if arr.shape != tuple(shape):
@@ -172,6 +179,39 @@ class BatchMPC:
 
     def synchronize(self):
         _lib.check(self._lib.srbdqp_synchronize(self._h), self._h)
+
+    # -- the steps either side of the QP (include/srbdqp_cascade.h) ----------------------------------------
+    def swing(self, p_start, p_final, z_middle, progress, final_velocity_z=-0.02, first_half_share=0.80, want_coeff=False):
+        """Batched swing-foot trajectory (swing_trajectory.py:38-89): p_start, p_final (B,3); z_middle, progress (B,).
+        Returns dict(pos (B,3), vel_z (B,), acc_z (B,)[, coeff (B,7)])."""
+        ps, pf = _c(p_start, np.float64).reshape(-1, 3), _c(p_final, np.float64).reshape(-1, 3)
+        B = ps.shape[0]
+        zm = np.ascontiguousarray(np.broadcast_to(np.asarray(z_middle, np.float64).reshape(-1), (B,)))
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(progress, np.float64).reshape(-1), (B,)))
+        if pf.shape[0] != B:
+            raise ValueError("p_start and p_final must have the same number of rows")
+        pos, vz, az = np.empty((B, 3)), np.empty(B), np.empty(B)
+        co = np.empty((B, 7)) if want_coeff else None
+        rc = self._lib.srbdqp_swing_f64(self._h, B, _p(ps), _p(pf), _p(zm), _p(t), float(final_velocity_z),
+                                        float(first_half_share), _p(pos), _p(vz), _p(az), _p(co))
+        _lib.check(rc, self._h)
+        out = dict(pos=pos, vel_z=vz, acc_z=az)
+        if want_coeff:
+            out["coeff"] = co
+        return out
+
+    def wbid_reference(self, x_next, u0, foot, as_written=True):
+        """Batched MPC -> WBID reference mapping (wbid.py:243-296): x_next (B,13), u0 (B,12), foot (B,12) or (B,4,3).
+        Returns dict(R (B,3,3), base_vel (B,6), base_acc (B,6), com_acc (B,3), com_pos (B,3), com_vel (B,3), wrench (B,4,3))."""
+        x, u, f = _c(x_next, np.float64).reshape(-1, NX), _c(u0, np.float64).reshape(-1, NU), _c(foot, np.float64).reshape(-1, NU)
+        B = x.shape[0]
+        if u.shape[0] != B or f.shape[0] != B:
+            raise ValueError("x_next, u0 and foot must have the same number of rows")
+        R, bv, ba, ca = np.empty((B, 3, 3)), np.empty((B, 6)), np.empty((B, 6)), np.empty((B, 3))
+        rc = self._lib.srbdqp_wbid_reference_f64(self._h, B, _p(x), _p(u), _p(f), int(bool(as_written)), _p(R), _p(bv), _p(ba), _p(ca))
+        _lib.check(rc, self._h)
+        return dict(R=R, base_vel=bv, base_acc=ba, com_acc=ca, com_pos=x[:, 3:6].copy(), com_vel=x[:, 9:12].copy(),
+                    wrench=u.reshape(B, 4, 3).copy())
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.srbdqp_last_kernel_ms(self._h))

@@ -1,0 +1,75 @@
+"""SURVEY.md 8(f) rows 3-4 on CPU: the oracle's restatement of the swing-foot trajectory against vectors produced BY THE
+REFERENCE ITSELF (tests/golden/swing_golden.npz, see make_swing_golden.py), and first-principles checks of the MPC->WBID
+reference mapping (whose reference module cannot be imported anywhere: parity unpinned)."""
+import os
+
+import numpy as np
+import pytest
+
+import cascade_oracle as co
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "swing_golden.npz")
+TOL_SWING = 1e-12      # fp64; the reference solves its 7x7 system by LU, so coefficients differ in the last bits
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def test_swing_oracle_reproduces_the_reference_outputs(gold):
+    r = co.swing_eval(gold["p_start"], gold["p_final"], gold["z_middle"], gold["progress"])
+    assert gold["progress"].shape[0] >= 800
+    assert np.abs(r["coeff"] - gold["coeff"]).max() < 1e-11
+    assert np.abs(r["pos"] - gold["pos"]).max() < TOL_SWING
+    assert np.abs(r["vel_z"] - gold["vel_z"]).max() < TOL_SWING
+    assert np.abs(r["acc_z"] - gold["acc_z"]).max() < 1e-11
+
+
+def test_swing_reference_curves(gold):
+    t = np.linspace(0, 1, 100)
+    r = co.swing_eval(np.tile([0.0, 0.1, 0.0], (100, 1)), np.tile([0.2, 0.1, 0.0], (100, 1)), np.full(100, 0.05), t)
+    assert np.abs(r["pos"][:, 2] - gold["curve_z"]).max() < TOL_SWING
+    assert np.abs(r["vel_z"] - gold["curve_vz"]).max() < TOL_SWING and np.abs(r["acc_z"] - gold["curve_az"]).max() < 1e-11
+    assert np.abs(r["pos"][:, :2] - gold["curve_xy"]).max() < TOL_SWING
+
+
+def test_swing_boundary_conditions_and_constant_inverse():
+    """The polynomial meets the seven conditions it is defined by, and the integer inverse the HIP kernel uses is exact."""
+    zs, zm, zf = 0.01, 0.07, -0.005
+    c = co.swing_coeff(zs, zm, zf)
+    k = np.arange(7)
+    val = lambda t: (c * t ** k).sum()
+    d1 = lambda t: (c[1:] * k[1:] * t ** (k[1:] - 1)).sum()
+    d2 = lambda t: (c[2:] * k[2:] * (k[2:] - 1) * t ** (k[2:] - 2)).sum()
+    assert abs(val(0) - zs) < 1e-14 and abs(d1(0.0)) < 1e-14 and abs(d2(0.0)) < 1e-13
+    assert abs(val(0.5) - zm) < 1e-13 and abs(val(1.0) - zf) < 1e-12 and abs(d1(1.0) + 0.02) < 1e-12 and abs(d2(1.0)) < 1e-11
+    inv = np.linalg.inv(co.swing_system())
+    cols = np.array([[1, 0, 0, -42, 111, -102, 32], [0, 0, 0, 64, -192, 192, -64], [0, 0, 0, -22, 81, -90, 32], [0, 0, 0, 6, -23, 27, -10]], dtype=float).T
+    assert np.abs(inv[:, [0, 3, 4, 5]] - cols).max() < 1e-10
+    # x-y weight: continuous at the half cycle, ends at 1
+    assert abs(co.swing_phase(0.5) - 0.8) < 1e-15 and abs(co.swing_phase(1.0) - 1.0) < 1e-15 and co.swing_phase(0.0) == 0.0
+
+
+def test_wbid_reference_first_principles():
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-0.5, 0.5, 13); x[12] = -9.80665
+    u = rng.uniform(-50, 200, 12)
+    feet = rng.uniform(-0.2, 0.2, (4, 3))
+    mass = 34.13385728
+    r = co.wbid_reference(x, u, feet, mass)
+    R = r["R"]
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-14 and abs(np.linalg.det(R) - 1) < 1e-14
+    # 'sxyz' = rotate about fixed x, then fixed y, then fixed z
+    cx, sx, cy, sy, cz, sz = np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]), np.cos(x[2]), np.sin(x[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]); Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    assert np.abs(R - Rz @ Ry @ Rx).max() < 1e-15
+    assert np.array_equal(r["base_vel"], np.r_[x[9:12], x[6:9]]) and np.all(r["base_acc"][:3] == 0)
+    want = np.linalg.inv(np.diag(co.TORSO_INERTIA)) @ np.cross(feet - x[3:6], x[6:9]).sum(0)
+    assert np.abs(r["base_acc"][3:] - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+    # the force sum as written (wbid.py:290) vs per axis: they agree only on the total of all twelve entries
+    a_w = co.wbid_reference(x, u, feet, mass, as_written=True)["com_acc"]
+    a_c = co.wbid_reference(x, u, feet, mass, as_written=False)["com_acc"]
+    assert np.abs(a_w - (np.array([u[0:4].sum(), u[4:8].sum(), u[8:12].sum()]) / mass + [0, 0, -9.80665])).max() < 1e-12
+    assert np.abs(a_c - (u.reshape(4, 3).sum(0) / mass + [0, 0, -9.80665])).max() < 1e-12
+    assert abs((a_w - a_c).sum()) < 1e-10 and np.abs(a_w - a_c).max() > 1e-3
