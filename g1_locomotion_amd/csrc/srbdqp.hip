@@ -87,7 +87,7 @@ std::string g_create_err;
 
 // fp64 instantiations: N in {4, 8, 10} with up to 4 stance contacts per step; N in {12, 16} with at most 2 (the dense
 // 12N x 12N inverse of the larger cases does not fit on chip)
-bool horizon_supported(int N) { return N == 4 || N == 8 || N == 10 || N == 12 || N == 16; }
+bool horizon_supported(int N) { return N == 4 || N == 8 || N == 10 || N == 12 || N == 16 || N == 20; }
 
 int resolve_kernel(const srbdqp_config& c) {
     if (c.kernel == SRBDQP_KERNEL_GJ) return SRBDQP_KERNEL_GJ;
@@ -187,6 +187,7 @@ int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4) {
         case 10: rc = launch_n<10>(h, a, st, variant, maxs); break;
         case 12: rc = launch_long<12>(h, a, st, maxs); break;
         case 16: rc = launch_long<16>(h, a, st, maxs); break;
+        case 20: rc = launch_long<20>(h, a, st, maxs); break;
         default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
     }
     if (rc != SRBDQP_OK) return rc;
@@ -251,8 +252,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if (!cfg || !out) { g_create_err = "null argument"; return SRBDQP_E_INVALID; }
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(srbdqp_config)) { g_create_err = "srbdqp_config.struct_size mismatch"; return SRBDQP_E_INVALID; }
-    if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10}; {12, 16} with max_contacts_per_step <= 2)"; return SRBDQP_E_INVALID; }
-    if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons 12 and 16 exist only for the compact kernel"; return SRBDQP_E_INVALID; }
+    if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10}; {12, 16, 20} with max_contacts_per_step <= 2)"; return SRBDQP_E_INVALID; }
+    if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons 12, 16 and 20 exist only for the compact kernel"; return SRBDQP_E_INVALID; }
     if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) ||
         cfg->max_iter < 1 || cfg->check_every < 1 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     constexpr int TS = S::TS, CHMAX = S::CHMAX;
     static_assert(S::NT <= 8, "W phase assumes at most two tiles per wave per block row");
     static_assert(2 * S::nmax <= kThreads, "two threads per compact column / row");
-    static_assert(4 * N <= 64, "the presolve compacts the 4N contact flags with one wave-wide ballot");
+    static_assert(4 * N <= 128, "the presolve compacts the 4N contact flags with at most two wave-wide ballots");
     static_assert((S::o_R % 2) == 0 && (S::o_rhs % 2) == 0, "16-byte alignment");
     if ((int)blockIdx.x >= a.B) return;
     const int b = SRBDQP_QP_INDEX(a);
@@ -295,18 +295,45 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 12] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     load_and_linearise<N, S>(a, b, sm);
-    if (t < 64) {   // presolve: compact the stance contacts (wave 0)
+    if constexpr (4 * N <= 64) {
+        if (t < 64) {   // presolve: compact the stance contacts (wave 0)
+            const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
+            const bool flag = (t < 4 * N) && sct[t < 4 * N ? t : 0] != 0;
+            const unsigned long long bal = __ballot(flag);
+            if (flag) act[__popcll(bal & ((1ull << t) - 1ull))] = (uint8_t)t;
+            if (t < N) icnt[t] = __popcll(bal & ((4 * (t + 1) >= 64) ? ~0ull : ((1ull << (4 * (t + 1))) - 1ull)));
+            if (t == 0) {
+                imisc[0] = __popcll(bal);
+                sm[S::o_misc] = 0.0;
+            }
+        }
+        __syncthreads();
+    } else {            // 64 < 4N <= 128 flags: one ballot in each of waves 0 and 1, joined through LDS
+        unsigned long long* bals = reinterpret_cast<unsigned long long*>(imisc + 2);
         const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
         const bool flag = (t < 4 * N) && sct[t < 4 * N ? t : 0] != 0;
-        const unsigned long long bal = __ballot(flag);
-        if (flag) act[__popcll(bal & ((1ull << t) - 1ull))] = (uint8_t)t;
-        if (t < N) icnt[t] = __popcll(bal & ((4 * (t + 1) >= 64) ? ~0ull : ((1ull << (4 * (t + 1))) - 1ull)));
-        if (t == 0) {
-            imisc[0] = __popcll(bal);
-            sm[S::o_misc] = 0.0;
+        if (t < 128) {
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0) bals[w] = bal;
         }
+        __syncthreads();
+        if (t < 128) {
+            const unsigned long long b0 = bals[0], b1 = bals[1];
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (flag) act[(w ? __popcll(b0) : 0) + __popcll((w ? b1 : b0) & below)] = (uint8_t)t;
+            if (t < N) {
+                const int end = 4 * (t + 1);
+                icnt[t] = (end < 64) ? __popcll(b0 & ((1ull << end) - 1ull))
+                        : (end == 64) ? __popcll(b0)
+                        : __popcll(b0) + __popcll(b1 & ((end - 64 >= 64) ? ~0ull : ((1ull << (end - 64)) - 1ull)));
+            }
+            if (t == 0) {
+                imisc[0] = __popcll(b0) + __popcll(b1);
+                sm[S::o_misc] = 0.0;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (t == 0) {   // offsets of the block rows of G, and the per-step bound check
         int viol = 0, rb = 0;
         for (int i = 0; i < N; ++i) {

@@ -224,7 +224,7 @@ class RaggedMPC:
     """Mixed-horizon batches (BASELINE.json configs[4]): QPs are bucketed by horizon and every bucket is one kernel
     launch on its own engine / HIP stream, so the buckets run concurrently.  Per-QP contact schedules are free."""
 
-    def __init__(self, horizons=(8, 12, 16), dt: float = 0.04, device: int = 0, **overrides):
+    def __init__(self, horizons=(8, 12, 16, 20), dt: float = 0.04, device: int = 0, **overrides):
         self.engines = {int(N): BatchMPC(horizon=int(N), dt=dt, device=device, **overrides) for N in horizons}
 
     def solve(self, problems):

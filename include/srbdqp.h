@@ -31,7 +31,7 @@ extern "C" {
 #define SRBDQP_NU 12
 #define SRBDQP_NC 4
 #define SRBDQP_ROWS_PER_STEP 20   /* 4 contacts x (4 friction-pyramid rows + 1 normal-force row) */
-#define SRBDQP_MAX_HORIZON 16     /* fp64 instantiations: N in {4, 8, 10}; {12, 16} with <= 2 stance contacts per step */
+#define SRBDQP_MAX_HORIZON 20     /* fp64 instantiations: N in {4, 8, 10}; {12, 16, 20} with <= 2 stance contacts per step */
 
 /* return codes */
 #define SRBDQP_OK 0

@@ -142,16 +142,16 @@ def test_mpc_update_drop_in_path(torch_first, built_lib):
 
 
 def test_ragged_horizons_bucketed_launch(torch_first, built_lib):
-    """BASELINE.json configs[4] (fp64 subset): mixed horizons N in {8, 12, 16}, per-QP random-phase single-support
+    """BASELINE.json configs[4] (fp64 subset): mixed horizons N in {8, 12, 16, 20}, per-QP random-phase single-support
     schedule, one launch per horizon bucket; every QP against the oracle twin and the exact optimum."""
     from g1_locomotion_amd import RaggedMPC
     rng = np.random.default_rng(5)
     problems = []
-    for i in range(18):
-        N = int(rng.choice([8, 12, 16]))
+    for i in range(24):
+        N = int(rng.choice([8, 12, 16, 20]))
         x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=900 + i, schedule="single"))
         problems.append(dict(x0=x0, x_ref=xr, foot=ft, contact=ct))
-    eng = RaggedMPC(horizons=(8, 12, 16))
+    eng = RaggedMPC(horizons=(8, 12, 16, 20))
     res = eng.solve(problems)
     eng.close()
     p = orc.SrbdParams()
