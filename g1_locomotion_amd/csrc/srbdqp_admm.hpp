@@ -26,6 +26,13 @@ __device__ __forceinline__ double dpp_swap1(double v) {   // value of lane ^ 1 (
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double dpp_swap2(double v) {   // value of lane ^ 2 (quad_perm [2,3,0,1])
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double bperm_f64(double v, int src_lane) {   // value of lane src_lane
     const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));

@@ -31,7 +31,14 @@ struct CompactSmem {
     static constexpr int NT = (nmax + 15) / 16;
     static constexpr int NTT = NT * (NT + 1) / 2;
     static constexpr int TS = (NTT + 3) / 4;
-    static constexpr int CHMAX = 2 * ((nmax + 3) / 4);    // columns per mat-vec half (even)
+    // lanes per K^-1 row in the ADMM mat-vec: 4 when 4 nmax lanes fit the workgroup (a row fragment of nmax/4 doubles
+    // keeps the kernel inside the 128-register budget of 4 workgroups per CU), else 2
+#ifdef SRBDQP_FORCE_LPR2
+    static constexpr int LPR = 2;
+#else
+    static constexpr int LPR = (4 * nmax <= kThreads) ? 4 : 2;
+#endif
+    static constexpr int CHMAX = 2 * ((nmax + 2 * LPR - 1) / (2 * LPR));   // columns per mat-vec part (even)
     static constexpr int gmax = 36 * MAXS * (N * (N + 1) / 2);
     static constexpr int up2(int v) { return (v + 1) & ~1; }
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -41,42 +48,47 @@ struct CompactSmem {
     static constexpr int o_J = o_tm + up2(N * 9);
     static constexpr int o_q = o_J + N * 36;              // nmax (compact gradient)
     static constexpr int o_px0 = o_q + up2(nmax);         // nmax
-    static constexpr int o_red = o_px0 + up2(nmax);       // 64
-    static constexpr int o_ct = o_red + 64;
+    static constexpr int o_red = o_px0 + up2(nmax);       // 32 (block_max: 4 waves x 8; the ADMM's fp32 maxima + flags: 18)
+    static constexpr int o_ct = o_red + 32;
     static constexpr int o_misc = o_ct + up2((N * 4 + 7) / 8);
     static constexpr int o_sq = o_misc + 8;
     static constexpr int o_int = o_sq + 12;               // ints: cnt[N], rowbase[N], na, flags; bytes: act[4N]
     static constexpr int o_R = o_int + up2((2 * N + 8) / 2 + (4 * N + 7) / 8 + 1);
-    // phase A
+    // phase A.  Lifetimes let two pairs share storage: foot/pcom are dead after the linearisation and G x^0 (warm
+    // start, after the gradient) takes their place; x_ref is dead once the gradient's error vector is built and the
+    // compact warm start takes its place when it fits.
     static constexpr int o_G = o_R;
     static constexpr int o_xref = o_G + gmax;
     static constexpr int o_foot = o_xref + up2(N * 13);
     static constexpr int o_pcom = o_foot + N * 12;
     static constexpr int o_cp = o_pcom + up2(N * 3);
     static constexpr int o_eh = o_cp + up2(N * 9);
-    static constexpr int o_gx = o_eh + n;                 // n (row space): G x^0
-    static constexpr int o_x0c = o_gx + n;                // nmax: compact warm start
-    static constexpr int endA = o_x0c + up2(nmax) + 16;
+    static constexpr int o_gx = o_foot;                   // n (row space): G x^0
+    static constexpr bool x0c_in_xref = up2(nmax) + 16 <= up2(N * 13);
+    static constexpr int o_x0c = x0c_in_xref ? o_xref : o_eh + n;     // nmax (+16 padding): compact warm start
+    static constexpr int endA = x0c_in_xref ? o_eh + n : o_x0c + up2(nmax) + 16;
     // phase B
     static constexpr int o_T = o_R;
     static constexpr int endB = o_T + NTT * 256;
     // phase C
-    static constexpr int o_rhs = o_R;                     // 2 x (2 CHMAX + 8)
-    static constexpr int o_xs = o_rhs + 2 * (2 * CHMAX + 8);   // n (full variable vector, for the roll-out)
+    static constexpr int o_rhs = o_R;                     // 2 x (LPR CHMAX + 8)
+    static constexpr int o_xs = o_rhs + 2 * (LPR * CHMAX + 8);   // n (full variable vector, for the roll-out)
     static constexpr int endC = o_xs + n;
     static constexpr int o_end = cmax(endA, cmax(endB, endC));
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     // workgroups per CU that LDS admits (160 KiB per CU), capped at 3: the register budget the kernel is compiled for
     // (3 only for the small problems: a 168-register budget cannot hold a K^-1 row fragment of more than 30 doubles)
     static constexpr int lds_wgs = 163840 / (int)bytes;
-    static constexpr int waves_per_simd = (lds_wgs >= 3 && nmax <= 60) ? 3 : (lds_wgs >= 2 ? 2 : 1);
+    static constexpr int waves_per_simd = (lds_wgs >= 4 && LPR == 4 && nmax <= 60) ? 4 : (lds_wgs >= 3 && nmax <= 60) ? 3 : (lds_wgs >= 2 ? 2 : 1);
 };
 
-// Lane mapping of the presolved ADMM: the na stance contacts are packed into as FEW waves as possible (10 contacts =
-// 60 lanes per wave): the mat-vec is bound by the LDS broadcast of rhs, which every participating wave reads in
-// full, so 20 contacts on 2 waves cost half the LDS time of 20 contacts on 4 waves.  Idle waves only join barriers.
-__device__ __forceinline__ int admm_waves_used(int na) { return (na + 9) / 10; }
-__device__ __forceinline__ int admm_contacts_per_wave(int na) { const int wu = (na + 9) / 10; return (na + wu - 1) / wu; }
+// Lane mapping of the presolved ADMM: a contact owns 3 LPR consecutive lanes (variable ax on lanes LPR ax .. LPR ax +
+// LPR - 1, each holding 1/LPR of that K^-1 row; the contact's 5 constraint rows ride on the first two lanes of each
+// variable), and the na stance contacts are packed into as FEW waves as possible (64 / (3 LPR) contacts per wave): the
+// mat-vec is bound by the LDS broadcast of rhs, which every participating wave reads in full.  Idle waves only join
+// barriers.
+template <int LPR> __device__ __forceinline__ int admm_waves_used(int na) { constexpr int C = 64 / (3 * LPR); return (na + C - 1) / C; }
+template <int LPR> __device__ __forceinline__ int admm_contacts_per_wave(int na) { const int wu = admm_waves_used<LPR>(na); return (na + wu - 1) / wu; }
 
 // The presolved ADMM (OSQP Algorithm 1 on the compact contacts), arithmetic as oracle admm_solve().  Per iteration:
 //   x~ = K^-1 rhs      row fragment x rhs broadcast from LDS (all loads in flight, then the FMAs), halves summed by DPP
@@ -91,17 +103,20 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                                  const double (&kin)[CHMAX], int na, int CH, const uint8_t* act, int* status_out) {
     using S = L;
     constexpr int n = Dims<N>::n, m = Dims<N>::m;
-    constexpr int RB = 2 * CHMAX + 8;                  // one rhs buffer
+    constexpr int LPR = S::LPR;
+    constexpr int RB = LPR * CHMAX + 8;                // one rhs buffer
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-    const int lr = lane >> 1, h = lane & 1;
-    const int CPW = admm_contacts_per_wave(na);
+    const int lr = lane / LPR, hp = lane % LPR;        // row slot in the wave, part of the row this lane multiplies
+    const int h = hp & 1;
+    const bool prim = hp < 2;                          // the two lanes of a variable that carry constraint rows
+    const int CPW = admm_contacts_per_wave<LPR>(na);
     const int cg = lr / 3, ax = lr - 3 * cg;
     const int e = w * CPW + cg;
     const bool active = (cg < CPW) && (e < na);
-    const int base = 6 * cg;
+    const int base = 3 * LPR * cg;
     const int gc = active ? act[e] : 0;                // original contact index 4 k + ci
     const int r = active ? 3 * e + ax : 0;             // compact variable
-    const bool has_row = active && (ax < 2 || h == 0);
+    const bool has_row = active && prim && (ax < 2 || h == 0);
     const int j = (ax < 2) ? 2 * ax + h : 4;
     const int irow = 5 * gc + j;                       // original row index (for warm_y / y_out)
     const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu;
@@ -111,17 +126,19 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     const double sgn = (j < 4 && h == 1) ? -1.0 : 1.0;
     const double muc = (j < 4) ? mu : 0.0;
     const double rowm = has_row ? 1.0 : 0.0;
-    const bool wave_on = w < admm_waves_used(na);
+    const bool wave_on = w < admm_waves_used<LPR>(na);
 
+    // row values live on the prim lanes (0 elsewhere: rowm); the results are valid on the prim lanes and, for LPR = 4,
+    // only consumed there (x, c, s of the other two lanes of a variable are never read)
     auto At = [&](double v) -> double {
         const double other = dpp_swap1(v);
         const double s = v + other;
-        const double s01 = bperm_f64(s, base + 0), s23 = bperm_f64(s, base + 2);
+        const double s01 = bperm_f64(s, base + 0), s23 = bperm_f64(s, base + LPR);
         const double d = (h == 0) ? v - other : other - v;
         return (ax < 2) ? d : fma(-mu, s01 + s23, s);
     };
     auto Arow = [&](double v) -> double {
-        const double vf = bperm_f64(v, base + 4);
+        const double vf = bperm_f64(v, base + 2 * LPR);
         return fma(-muc, vf, sgn * v);
     };
 
@@ -138,7 +155,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     block_max<1>(qn, sm + S::o_red);                    // its barriers also order the zero fill above
     {
         const double rhs0 = sigma * x - qv + At(rowm * (rho * z - y));
-        if (active && h == 0) rhsbuf[r] = rhs0;
+        if (active && hp == 0) rhsbuf[r] = rhs0;
     }
     if (t < 4) reinterpret_cast<int*>(redf + 32)[t] = 0;
     __syncthreads();
@@ -150,6 +167,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     double e_prim_last = kInf * 1.0e10;                 // e_prim of the last full check (pre-test threshold)
     int* vflag = reinterpret_cast<int*>(redf + 32);     // [4] per-wave 'some row fails the pre-test' flags
     bool vote_ok = true;
+    int ph = 0;
     for (int k = 1; k <= a.max_iter + 1; ++k) {
         if (pending) {   // decision of the check made at iteration k - 1 (its maxima rode on that iteration's barrier)
             const float* buf = redf + ((nchk - 1) & 1) * 16;
@@ -164,10 +182,11 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
             pending = false;
         }
         if (k > a.max_iter) break;
-        const bool at_mark = (k % a.check_every == 0);
+        if (++ph == a.check_every) ph = 0;                  // ph = k mod check_every, without a division per iteration
+        const bool at_mark = (ph == 0);
         if (at_mark) vote_ok = (vflag[0] | vflag[1] | vflag[2] | vflag[3]) == 0;   // pre-test made at iteration k - 1
         const bool check = (at_mark && vote_ok) || (k == a.max_iter);
-        const bool pretest = ((k + 1) % a.check_every == 0);
+        const bool pretest = (ph == a.check_every - 1);     // k + 1 is a mark
         const double* rb = rhsbuf + ((k - 1) & 1) * RB;
         double* wb = rhsbuf + (k & 1) * RB;
         ADMM_T(tp0);
@@ -179,7 +198,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                 // round trip EVERY iteration).  Columns past CH read the zero padding and meet kin = 0.
                 constexpr int NV = CHMAX / 2, BL = (NV <= 8) ? NV : 8, NBMAX = (NV + BL - 1) / BL;   // 8 ds_read_b128 in flight
                 double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-                const double2* rv = reinterpret_cast<const double2*>(rb + CH * h);
+                const double2* rv = reinterpret_cast<const double2*>(rb + CH * hp);
 #pragma unroll
                 for (int blk = 0; blk < NBMAX; ++blk) {
                     if (blk == 0 || blk * 2 * BL < CH) {                       // wave-uniform
@@ -198,6 +217,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                 }
                 const double acc = (acc0 + acc1) + (acc2 + acc3);
                 xt = acc + dpp_swap1(acc);
+                if constexpr (LPR == 4) xt += dpp_swap2(xt);
             }
 #if defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 1 || SRBDQP_ABLATE == 5 || SRBDQP_ABLATE == 6)
             xt = kin[0] * rb[r];   // ablation: no mat-vec
@@ -223,7 +243,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
 #endif
             cpx = alpha * (sigma * (x - xt) - qv) + oma * cpx;
             x = alpha * xt + oma * x;
-            if (active && h == 0) wb[r] = sigma * x - qv + atw;
+            if (active && hp == 0) wb[r] = sigma * x - qv + atw;
             ADMM_T(tp3);
             if (pretest) {   // one ballot instead of a reduction: does any row still violate the last e_prim?
                 const unsigned long long bad = __ballot(has_row && !(fabs(axr - z) <= e_prim_last));
@@ -235,7 +255,8 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                 rd = (rd == rd) ? rd : kInf * 10.0;              // a NaN residual must survive the max
                 rp = (rp == rp) ? rp : kInf * 10.0;
                 const float v0 = (float)(rowm * rp), v1 = (float)(rowm * fmax(fabs(axr), fabs(z)));
-                const float v2 = active ? (float)rd : 0.0f, v3 = active ? (float)fmax(fabs(px), fabs(aty)) : 0.0f;
+                const bool varlane = active && prim;            // lanes on which A'(.) is the variable's value
+                const float v2 = varlane ? (float)rd : 0.0f, v3 = varlane ? (float)fmax(fabs(px), fabs(aty)) : 0.0f;
                 const float m0 = wave_maxf_nonneg(v0), m1 = wave_maxf_nonneg(v1), m2 = wave_maxf_nonneg(v2), m3 = wave_maxf_nonneg(v3);
                 if (lane == 63) {
                     float* buf = redf + (nchk & 1) * 16 + 4 * w;
@@ -260,7 +281,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
 #ifdef SRBDQP_PROFILE_ADMM
     if (a.stamps && t == 0) { long long* st = a.stamps + (size_t)b * 16; st[12] = seg0; st[13] = seg1; st[14] = seg2; st[15] = seg3; st[1] = seg4; }
 #endif
-    if (active && h == 0) xs_full[3 * gc + ax] = x;
+    if (active && hp == 0) xs_full[3 * gc + ax] = x;
     if (a.y_out && has_row) a.y_out[(size_t)b * m + irow] = y;
     __syncthreads();
     *status_out = status;
@@ -620,11 +641,12 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     SRBDQP_STAMP(a, b, 8);
 
     // K^-1 row fragments in the compact contact-local mapping
-    const int CH = 2 * ((n_eff + 3) >> 2);
+    constexpr int LPR = S::LPR;
+    const int CH = 2 * ((n_eff + 2 * LPR - 1) / (2 * LPR));
     double kin[CHMAX];
     {
-        const int lr = lane >> 1, h = lane & 1;
-        const int CPW = admm_contacts_per_wave(na);
+        const int lr = lane / LPR, h = lane % LPR;
+        const int CPW = admm_contacts_per_wave<LPR>(na);
         const int cg = lr / 3, e = w * CPW + cg;
         const bool rowok = (cg < CPW) && (e < na);
         const int rr = rowok ? 3 * e + (lr - 3 * cg) : 0;

@@ -16,7 +16,7 @@ for B in (1, 4096):
     u = torch.empty((B, 10, 12), dtype=torch.float64, device=dev)
     it = torch.empty(B, dtype=torch.int32, device=dev)
     st = torch.zeros((B, 16), dtype=torch.int64, device=dev)
-    eng = BatchMPC(horizon=10, max_contacts_per_step=int(os.environ.get("MAXS", "2")), kernel=int(os.environ.get("KERNEL", "0")), **({"max_iter": 35, "eps_abs": 0.0, "eps_rel": 0.0} if os.environ.get("FIXED_ITERS") else {}))
+    eng = BatchMPC(horizon=10, max_contacts_per_step=int(os.environ.get("MAXS", "2")), kernel=int(os.environ.get("KERNEL", "0")), **({"max_iter": 35, "eps_abs": 0.0, "eps_rel": 0.0, "check_every": int(os.environ.get("CHECK_EVERY", "5"))} if os.environ.get("FIXED_ITERS") else {}))
     eng._lib.srbdqp_set_stamp_buffer(eng._h, C.c_void_p(st.data_ptr()))
     for _ in range(3):
         eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(), iters=it.data_ptr())
