@@ -219,11 +219,31 @@ def latency_batch1(orc, calls=2000):
     return out
 
 
+def _cpu_share():
+    """Host threads this process may really run: the affinity mask capped by the cgroup CPU quota (a 1-GPU box exposes
+    every core of the node in the mask but grants only its share of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(orc, x0, xr, ft, ct):
     """oracle/srbd_oracle.c on this node's host cores, bounded sample of the same batch."""
     import c_oracle
     p = orc.SrbdParams()
-    cores = len(os.sched_getaffinity(0))
+    cores = _cpu_share()
     S1 = min(2048, x0.shape[0])
     t = time.perf_counter()
     c_oracle.solve_batch(p, x0[:S1], xr[:S1], ft[:S1], ct[:S1], nthreads=1)
@@ -235,7 +255,7 @@ def cpu_baseline(orc, x0, xr, ft, ct):
         c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=cores)
     tall = (time.perf_counter() - t) / reps
     return {"value": Sall / tall, "unit": "QP/s", "cores": cores, "kind": "port",
-            "sample": f"the {Sall} QPs of the rank-0 batch x {reps} repetitions on {cores} threads (plain-C port oracle/srbd_oracle.c of the same algorithm incl. presolve, gcc -O3 -mavx2)",
+            "sample": f"the {Sall} QPs of the rank-0 batch x {reps} repetitions on {cores} threads = this box's CPU quota (cgroup cpu.max; the affinity mask shows {len(os.sched_getaffinity(0))}) (plain-C port oracle/srbd_oracle.c of the same algorithm incl. presolve, gcc -O3 -mavx2)",
             "single_thread_value": S1 / t1, "single_thread_sample": f"first {S1} QPs, 1 thread",
             "single_thread_p50_us": 1e6 * t1 / S1}
 

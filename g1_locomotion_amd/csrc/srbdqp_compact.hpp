@@ -21,6 +21,12 @@
 
 namespace srbdqp {
 
+// With a 128-register budget the compiler otherwise hoists every lane-index expression of the later phases (swizzled
+// tile offsets, the identity pattern of the diagonal-tile inversion) to the top of the kernel and then spills them
+// across the factorisation: ~17 dwords per lane of scratch = 70 MB of HBM writes per 4096-QP launch.  Passing the lane
+// indices through an empty asm at each phase boundary makes those expressions local to their phase again.
+#define SRBDQP_PHASE_LOCAL(...) asm volatile("" : __VA_ARGS__)
+
 constexpr int kStatusContactBound = -2;
 
 template <int N, int MAXS>
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     const int b = SRBDQP_QP_INDEX(a);
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int mcol = lane & 15, kq = lane >> 4;
+    int mcol = lane & 15, kq = lane >> 4;                   // re-laundered per phase, see SRBDQP_PHASE_LOCAL
     double* G = sm + S::o_G;
     double* T = sm + S::o_T;
     int* icnt = reinterpret_cast<int*>(sm + S::o_int);          // cnt[i] = stance contacts in steps 0..i
@@ -510,6 +516,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     SRBDQP_STAMP(a, b, 5);
 
     // ================= phase F =================
+    SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
     for (int j = 0; j < NT; ++j) {
         double* Djj = T + tile_id(j, j) * 256;
 #pragma unroll
@@ -517,7 +524,9 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
             if (ta[s] == j && tb[s] == j) store_tile<false>(Djj, acc[s], lane);
         __syncthreads();
         if (w == (j & 3)) {
-            const bool ok = diag16_invert(Djj, lane);
+            int lane_j = lane;
+            SRBDQP_PHASE_LOCAL("+v"(lane_j));               // keeps the identity pattern inside this call (not hoisted + spilled)
+            const bool ok = diag16_invert(Djj, lane_j);
             if (!ok && lane == 0) sm[S::o_misc] = 1.0;
         }
         __syncthreads();
@@ -554,6 +563,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     SRBDQP_STAMP(a, b, 6);
 
     // ================= phase W =================
+    SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
     for (int i = 1; i < NT; ++i) {
         v4d res[2];
         const double* Dii = T + tile_id(i, i) * 256;
@@ -605,6 +615,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     SRBDQP_STAMP(a, b, 7);
 
     // ================= phase I =================
+    SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
         acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
