@@ -215,3 +215,42 @@ def test_large_batch_against_c_oracle(torch_first, built_lib, N, pattern, B):
     assert err[same].max() <= 1e-4 and err.max() <= TOL_TWIN_N, (err[same].max(), err.max())
     assert np.abs(out["x"] - ref["x"]).max() <= 1e-5
     assert np.all(out["u"].reshape(B, N, 4, 3)[ct == 0] == 0.0)
+
+
+def test_full_size_batch_properties(torch_first, built_lib):
+    """BASELINE.json's full per-GPU size (configs[3]: 65,536 QPs per GPU, N=10) through size-independent properties:
+    feasibility of every returned force, exact zeros on swing contacts, bitwise permutation invariance of the batch,
+    idempotence under a warm start from the own solution, and oracle parity on a seeded subset."""
+    import c_oracle
+    N, B = 10, 65536
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=4242, schedule="single")
+    p = orc.SrbdParams()
+    with _engine(N) as eng:
+        out = eng.solve(x0, xr, ft, ct, want_y=True)
+        perm = np.random.default_rng(3).permutation(B)
+        out_p = eng.solve(x0[perm], xr[perm], ft[perm], ct[perm])
+        warm = eng.solve(x0, xr, ft, ct, warm_u=out["u"].reshape(B, -1), warm_y=out["y"])
+    st, it = out["status"], out["iters"]
+    assert set(np.unique(st)) <= {orc.STATUS_SOLVED, orc.STATUS_MAX_ITER} and (st == orc.STATUS_SOLVED).mean() > 0.99
+    f = out["u"].reshape(B, N, 4, 3)
+    on = ct != 0
+    assert np.all(f[~on] == 0.0)
+    solved = (st == orc.STATUS_SOLVED)[:, None, None] & on
+    tol = 5e-3                                                   # N; ADMM's primal residual at eps 1e-6 is far below
+    assert np.all(np.abs(f[..., 0])[solved] <= p.mu * f[..., 2][solved] + tol)
+    assert np.all(np.abs(f[..., 1])[solved] <= p.mu * f[..., 2][solved] + tol)
+    assert f[..., 2][solved].min() >= p.fz_min - tol and f[..., 2][solved].max() <= p.fz_max + tol
+    # a batch is a set: permuting the QPs permutes the results bit for bit
+    np.testing.assert_array_equal(out_p["u"], out["u"][perm])
+    np.testing.assert_array_equal(out_p["iters"], it[perm])
+    np.testing.assert_array_equal(out_p["x"], out["x"][perm])
+    # restarting a solved QP from its own primal/dual solution stops at the first check with the same forces
+    ok = st == orc.STATUS_SOLVED
+    assert (warm["iters"][ok] == p.check_every).mean() > 0.999
+    assert np.abs(warm["u"][ok] - out["u"][ok]).max() < 1e-3
+    # seeded subset against the compiled oracle
+    idx = np.random.default_rng(4).choice(B, 512, replace=False)
+    ref = c_oracle.solve_batch(p, x0[idx], xr[idx], ft[idx], ct[idx], nthreads=8)
+    np.testing.assert_array_equal(st[idx], ref["status"])
+    assert np.abs(it[idx].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
+    assert np.abs(out["u"][idx] - ref["u"]).max() <= TOL_TWIN_N
