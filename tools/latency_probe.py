@@ -43,6 +43,17 @@ def main():
             its.append(int(st["iters"][0]))
         out[f"c_abi_{name}"] = dict(pct(ts[100:]), mean_iters=float(np.mean(its[100:])))
         eng.close()
+    # PCIe-inclusive batch rate: host (pageable NumPy) buffers in, host buffers out, B = 4096
+    xb, xrb, ftb, ctb = orc.synthetic_batch(4096, 10, seed=1000, schedule="single")
+    eng = BatchMPC(horizon=10, max_contacts_per_step=2)
+    for _ in range(3):
+        eng.solve(xb, xrb, ftb, ctb)
+    t = time.perf_counter()
+    for _ in range(10):
+        eng.solve(xb, xrb, ftb, ctb)
+    dt = (time.perf_counter() - t) / 10
+    out["host_buffers_batch4096"] = {"ms_per_call": round(dt * 1e3, 3), "qp_per_s": round(4096 / dt)}
+    eng.close()
     eng = BatchMPC(horizon=10, timing=True)
     st = eng.stage()
     ks = []
