@@ -519,15 +519,20 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
     for (int j = 0; j < NT; ++j) {
         double* Djj = T + tile_id(j, j) * 256;
+        {   // the wave that holds the diagonal tile inverts it in registers (blocked, on the matrix cores)
+            bool mine = false;
+            v4d d = acc[0];
 #pragma unroll
-        for (int s = 0; s < TS; ++s)
-            if (ta[s] == j && tb[s] == j) store_tile<false>(Djj, acc[s], lane);
-        __syncthreads();
-        if (w == (j & 3)) {
-            int lane_j = lane;
-            SRBDQP_PHASE_LOCAL("+v"(lane_j));               // keeps the identity pattern inside this call (not hoisted + spilled)
-            const bool ok = diag16_invert(Djj, lane_j);
-            if (!ok && lane == 0) sm[S::o_misc] = 1.0;
+            for (int s = 0; s < TS; ++s)
+                if (ta[s] == j && tb[s] == j) { mine = true; d = acc[s]; }
+            if (mine) {
+                int lane_j = lane;
+                SRBDQP_PHASE_LOCAL("+v"(lane_j));           // keeps the lane predicates of the inversion inside this block
+                bool ok;
+                const v4d winv = diag16_invert_mfma(d, lane_j, ok);
+                store_tile<true>(Djj, winv, lane_j);
+                if (!ok && lane == 0) sm[S::o_misc] = 1.0;
+            }
         }
         __syncthreads();
 #pragma unroll
