@@ -15,6 +15,7 @@
 #include "srbdqp_gj.hpp"
 #include "srbdqp_mfma.hpp"
 #include "srbdqp_compact.hpp"
+#include "srbdqp_split.hpp"
 #include "srbdqp_cascade.hpp"
 #include "srbdqp_cascade.h"
 
@@ -46,6 +47,10 @@ struct srbdqp_handle {
     int32_t* done_count = nullptr;
     int32_t done_seq = 0;
     bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
+    // split pipeline: per-QP hand-over workspace between the set-up kernel and the ADMM kernel
+    double* split_ws = nullptr;
+    size_t split_ws_doubles = 0;
+    std::string kname_store;
 };
 
 namespace {
@@ -124,8 +129,39 @@ int set_lds_once(srbdqp_handle* h, K kernel, size_t lds, bool& done) {
     return SRBDQP_OK;
 }
 
+// Large batches of the small instantiations run as two kernels (srbdqp_split.hpp): set-up at 4 workgroups per CU,
+// then the ADMM iterations with one wave per QP.  Small batches (latency), diagnostics and the staged path stay fused.
+constexpr int kSplitMinBatch = 512;
+
+template <int N, int MAXS>
+int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
+    using W = srbdqp::SplitWs<N, MAXS>;
+    const size_t need = (size_t)a.B * W::doubles;
+    if (need > h->split_ws_doubles) {
+        HIP_TRY(h, hipStreamSynchronize(st));               // a previous launch on this stream may still use the old buffer
+        if (h->split_ws) { HIP_TRY(h, hipFree(h->split_ws)); h->split_ws = nullptr; h->split_ws_doubles = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->split_ws), need * sizeof(double));
+        if (e != hipSuccess) { h->err = std::string("hipMalloc split workspace: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
+        h->split_ws_doubles = need;
+    }
+    a.ws = h->split_ws;
+    constexpr size_t ldsA = srbdqp::CompactTraits<N, MAXS>::lds_bytes, ldsB = srbdqp::SplitSmem<N, MAXS>::bytes;
+    static bool attr_set = false;
+    int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, true>, ldsA, attr_set);
+    if (rc != SRBDQP_OK) return rc;
+    static const std::string nm = "split_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
+    h->kname = nm.c_str();
+    hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), ldsA, st, a);
+    hipLaunchKernelGGL((srbdqp::srbdqp_admm_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), ldsB, st, a);
+    return SRBDQP_OK;
+}
+
 template <int N, int MAXS>
 int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
+    if constexpr (srbdqp::SplitWs<N, MAXS>::supported) {
+        const bool want = h->cfg.kernel == SRBDQP_KERNEL_SPLIT || (h->cfg.kernel == SRBDQP_KERNEL_AUTO && a.B >= kSplitMinBatch);
+        if (want && a.mode == 0 && !a.stamps && !a.done_flag) return launch_split<N, MAXS>(h, a, st);
+    }
     constexpr size_t lds = srbdqp::CompactTraits<N, MAXS>::lds_bytes;
     static bool attr_set = false;
     int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS>, lds, attr_set);
@@ -273,6 +309,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
         if (h->stream) (void)hipStreamDestroy(h->stream);
         if (h->stage_host) (void)hipHostFree(h->stage_host);
         if (h->done_count) (void)hipFree(h->done_count);
+    if (h->split_ws) (void)hipFree(h->split_ws);
         delete h;
         return SRBDQP_E_HIP;
     };

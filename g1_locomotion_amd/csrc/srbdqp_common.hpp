@@ -36,6 +36,7 @@ struct KArgs {
     double* ub_out;          // [B][m]
     const int32_t* perm;     // optional dispatch order: workgroup i solves QP perm[i] (longest-first scheduling), or null
     long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null
+    double* ws;              // split mode: per-QP workspace between the set-up kernel and the ADMM kernel, or null
     int32_t* done_flag;      // low-latency completion: GPU-mapped host word that receives done_value once every QP of the
     int32_t* done_count;     //   launch has stored its outputs (done_count: device counter of finished workgroups), or null
     int32_t done_value;
@@ -368,16 +369,16 @@ __device__ __forceinline__ void block_max(double (&v)[NV], double* red) {
 // a10: roll the linear model forward with the optimal forces and store u (newtons), x horizon, status.
 // xs (LDS, n doubles) holds the scaled solution u_hat.
 // ---------------------------------------------------------------------------------------------------------
-template <int N, class L>
+template <int N, class L, int BT = kThreads>
 __device__ void rollout_and_store(const KArgs& a, int b, double* sm, const double* uh, double* scratch /* >= 6N */) {
     using S = L;
     constexpr int n = Dims<N>::n;
     const int t = threadIdx.x;
-    for (int c = t; c < n; c += kThreads) a.u_out[(size_t)b * n + c] = a.s * uh[c];
+    for (int c = t; c < n; c += BT) a.u_out[(size_t)b * n + c] = a.s * uh[c];
     if (!a.x_out) return;
     const double* x0 = sm + S::o_x0;
     // phase A: omega_k, v_k for k = 1..N  (scratch[(k-1)*6 + comp])
-    for (int idx = t; idx < 6 * N; idx += kThreads) {
+    for (int idx = t; idx < 6 * N; idx += BT) {
         const int k = idx / 6 + 1, comp = idx % 6;
         double acc = 0.0;
         for (int j = 0; j < k; ++j) {
@@ -398,7 +399,7 @@ __device__ void rollout_and_store(const KArgs& a, int b, double* sm, const doubl
     }
     __syncthreads();
     double* xo = a.x_out + (size_t)b * (N + 1) * 13;
-    for (int idx = t; idx < 13 * (N + 1); idx += kThreads) {
+    for (int idx = t; idx < 13 * (N + 1); idx += BT) {
         const int k = idx / 13, comp = idx % 13;
         double v;
         if (k == 0) v = x0[comp];

@@ -294,7 +294,19 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     return iters;
 }
 
+// Split mode (SPLIT = true): the kernel stops after K^-1 and hands the QP to srbdqp_admm_kernel (srbdqp_split.hpp)
+// through a per-QP workspace in HBM: [0, o_R) = the persistent LDS strip as is, then K^-1 dense row-major
+// (n_eff rows of SplitWs::KS doubles).  strip[o_misc + 1] != 0 tells the second kernel the QP is already finished.
 template <int N, int MAXS>
+struct SplitWs {
+    using S = CompactSmem<N, MAXS>;
+    static constexpr bool supported = (S::nmax <= 64);     // one K^-1 row per lane of ONE wave
+    static constexpr int KS = (S::nmax + 1) & ~1;          // row stride (even: 16-byte loads)
+    static constexpr int o_kinv = (S::o_R + 1) & ~1;
+    static constexpr int doubles = o_kinv + S::nmax * KS;
+};
+
+template <int N, int MAXS, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) void srbdqp_compact_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     using S = CompactSmem<N, MAXS>;
@@ -332,6 +344,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
             if (t == 0) {
                 imisc[0] = __popcll(bal);
                 sm[S::o_misc] = 0.0;
+                sm[S::o_misc + 1] = 0.0;
             }
         }
         __syncthreads();
@@ -357,6 +370,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
             if (t == 0) {
                 imisc[0] = __popcll(b0) + __popcll(b1);
                 sm[S::o_misc] = 0.0;
+                sm[S::o_misc + 1] = 0.0;
             }
         }
         __syncthreads();
@@ -383,6 +397,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
         }
         __syncthreads();
         rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+        if constexpr (SPLIT) { if (t == 0) a.ws[(size_t)b * SplitWs<N, MAXS>::doubles + S::o_misc + 1] = 1.0; }
         signal_done(a);
         return;
     }
@@ -656,6 +671,21 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     __syncthreads();
     SRBDQP_STAMP(a, b, 8);
 
+    if constexpr (SPLIT) {   // hand the QP over: persistent strip + dense K^-1 (coalesced stores)
+        using W = SplitWs<N, MAXS>;
+        double* ws = a.ws + (size_t)b * W::doubles;
+        for (int i = t; i < S::o_R; i += kThreads) ws[i] = sm[i];
+        for (int idx = t; idx < n_eff * W::KS; idx += kThreads) {
+            const int rr = idx / W::KS, c = idx - rr * W::KS;
+            const int cs = (c < n_eff) ? c : 0;
+            const int lo = (rr <= cs) ? rr : cs, hi = (rr <= cs) ? cs : rr;
+            const int row = lo & 15, col = hi & 15;
+            const double v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
+            ws[W::o_kinv + idx] = (c < n_eff) ? v : 0.0;
+        }
+        return;
+    } else {
+
     // K^-1 row fragments in the compact contact-local mapping
     constexpr int LPR = S::LPR;
     const int CH = 2 * ((n_eff + 2 * LPR - 1) / (2 * LPR));
@@ -703,6 +733,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
 #ifndef SRBDQP_PROFILE_ADMM
     if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+    }   // !SPLIT
 }
 
 template <int N, int MAXS>

@@ -1,0 +1,188 @@
+// srbdqp_split.hpp -- second kernel of the split pipeline: the ADMM iterations and the roll-out of ONE QP on ONE wave.
+//
+// Why split: inside the fused kernel an ADMM iteration is a chain of ~75 dependent instructions on each of 4 waves plus
+// an LDS exchange and a barrier (1.45 k cycles, 4 x 115 issue slots); the set-up phases want 4 workgroups per CU and
+// therefore a 128-register budget, which is what forces the K^-1 row over 4 lanes.  Here a lane owns a whole K^-1 row
+// (n_eff <= 64 doubles in registers, 2 waves per SIMD), the right-hand side is exchanged inside the wave (one
+// ds_write + broadcast ds_reads, no barrier), a contact is 3 lanes that carry 2 + 2 + 1 rows, and the convergence
+// decision is a wave reduction: ~180 issue slots per iteration on one wave instead of 460 on four, 8 QPs in flight per
+// CU instead of 4.  The price is the hand-over of K^-1 (n_eff^2 doubles) and the persistent strip through HBM
+// (SplitWs, 34 KB per QP for N = 10): ~0.9 TB/s at the measured rate, far from the 8 TB/s bound.
+//
+// Arithmetic as oracle admm_solve() / admm_loop_compact(): same recursions (P x = c - A's), same fp32-rounded
+// maxima, same pre-test rule, so iteration counts agree with the fused kernel and the oracle.
+#pragma once
+#include "srbdqp_compact.hpp"
+
+namespace srbdqp {
+
+template <int N, int MAXS>
+struct SplitSmem {
+    using S = CompactSmem<N, MAXS>;
+    static constexpr int o_rhs = (S::o_R + 1) & ~1;        // 64 (+ padding to the row stride)
+    static constexpr int o_xs = o_rhs + 72;                // n: full variable vector for the roll-out
+    static constexpr int o_scr = o_xs + Dims<N>::n;        // 6N roll-out scratch
+    static constexpr int o_end = o_scr + 6 * N + 2;
+    static constexpr size_t bytes = (size_t)o_end * sizeof(double);
+};
+
+template <int N, int MAXS>
+__global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    using S = CompactSmem<N, MAXS>;
+    using W = SplitWs<N, MAXS>;
+    using L = SplitSmem<N, MAXS>;
+    constexpr int n = Dims<N>::n, m = Dims<N>::m, KS = W::KS;
+    static_assert(W::supported, "one K^-1 row per lane of one wave");
+    if ((int)blockIdx.x >= a.B) return;
+    const int b = SRBDQP_QP_INDEX(a);
+    const int lane = threadIdx.x;
+    const double* ws = a.ws + (size_t)b * W::doubles;
+    if (ws[S::o_misc + 1] != 0.0) return;                  // finished by the set-up kernel (no stance contact / bound)
+    for (int i = lane; i < S::o_R; i += 64) sm[i] = ws[i];
+    double* rb = sm + L::o_rhs;
+    double* xs_full = sm + L::o_xs;
+    for (int i = lane; i < n; i += 64) xs_full[i] = 0.0;
+    if (lane < 8) rb[64 + lane] = 0.0;
+    __syncthreads();
+    const int* icnt = reinterpret_cast<const int*>(sm + S::o_int);
+    const int* imisc = icnt + 2 * N;
+    const uint8_t* act = reinterpret_cast<const uint8_t*>(imisc + 8);
+    const int na = imisc[0], n_eff = 3 * na;
+    const bool failed = sm[S::o_misc] != 0.0;
+
+    // ---- lane mapping: contact cg = lane / 3 owns lanes 3 cg + {0, 1, 2} = its variables fx, fy, fz; rows: slot A of
+    // the fx / fy lanes = +f - mu fz <= 0, slot B = -f - mu fz <= 0, slot A of the fz lane = the normal-force bound
+    const int cg = lane / 3, ax = lane - 3 * cg;
+    const bool active = cg < na;
+    const int base = 3 * cg;
+    const int gc = active ? act[cg] : 0;
+    const bool rowA = active, rowB = active && ax < 2;
+    const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu, irho = 1.0 / a.rho;
+    const double rhoA = rowA ? a.rho : 0.0, rhoB = rowB ? a.rho : 0.0;      // rho = 0 freezes a slot at y = z = 0
+    const double loA = !rowA ? 0.0 : (ax < 2 ? -kInf : a.fzmin_s), hiA = !rowA ? 0.0 : (ax < 2 ? 0.0 : a.fzmax_s);
+    const double loB = rowB ? -kInf : 0.0, hiB = 0.0;
+    const double mucA = (ax < 2) ? mu : 0.0;
+    const int irowA = 5 * gc + ((ax < 2) ? 2 * ax : 4), irowB = 5 * gc + 2 * ax + 1;
+
+    // K^-1 row of this lane
+    double kin[KS];
+    {
+        const double2* src = reinterpret_cast<const double2*>(ws + W::o_kinv + (size_t)(lane < n_eff ? lane : 0) * KS);
+#pragma unroll
+        for (int c = 0; c < KS / 2; ++c) {
+            const double2 v = src[c];
+            kin[2 * c] = (lane < n_eff) ? v.x : 0.0;
+            kin[2 * c + 1] = (lane < n_eff) ? v.y : 0.0;
+        }
+    }
+
+    // A'(wA, wB) for the variable of this lane; (A v)_slot for the two slots
+    auto At = [&](double wA, double wB) -> double {
+        const double ssum = wA + wB;
+        const double s01 = bperm_f64(ssum, base), s23 = bperm_f64(ssum, base + 1);
+        return (ax < 2) ? wA - wB : fma(-mu, s01 + s23, wA);
+    };
+
+    int status = -1, iters = 0;
+    if (!failed) {
+        const double qv = active ? sm[S::o_q + lane] : 0.0;
+        double x = (active && a.warm_u) ? a.warm_u[(size_t)b * n + 3 * gc + ax] / a.s : 0.0;
+        double cpx = active ? sm[S::o_px0 + lane] : 0.0, spxA = 0.0, spxB = 0.0;
+        double yA = (rowA && a.warm_y) ? a.warm_y[(size_t)b * m + irowA] : 0.0;
+        double yB = (rowB && a.warm_y) ? a.warm_y[(size_t)b * m + irowB] : 0.0;
+        const double fz0 = bperm_f64(x, base + 2);
+        double axA = rowA ? fma(-mucA, fz0, x) : 0.0, axB = rowB ? fma(-mu, fz0, -x) : 0.0;     // (A x)_slot by recursion
+        double zA = fmin(fmax(axA, loA), hiA), zB = fmin(fmax(axB, loB), hiB);
+        const float qnf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg((float)fabs(qv))), 63));
+        rb[lane] = sigma * x - qv + At(rhoA * zA - yA, rhoB * zB - yB);
+        status = 2; iters = a.max_iter;
+        double e_prim_last = kInf * 1.0e10;
+        bool vote_ok = true;
+        int ph = 0;
+        for (int k = 1; k <= a.max_iter; ++k) {
+            if (++ph == a.check_every) ph = 0;
+            const bool at_mark = (ph == 0);
+            const bool check = (at_mark && vote_ok) || (k == a.max_iter);
+            const bool pretest = (ph == a.check_every - 1);
+            // x~ = K^-1 rhs: rhs broadcast from LDS in blocks of 8 ds_read_b128, four accumulators
+            asm volatile("" ::: "memory");                                  // rb is written as double, read as double2
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            {
+                const double2* rv = reinterpret_cast<const double2*>(rb);
+                constexpr int NV = KS / 2, BL = 8;
+#pragma unroll
+                for (int blk = 0; blk < (NV + BL - 1) / BL; ++blk) {
+                    double2 v[BL];
+#pragma unroll
+                    for (int i = 0; i < BL; ++i) v[i] = (blk * BL + i < NV) ? rv[blk * BL + i] : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int i = 0; i < BL; ++i) {
+                        const int c0 = 2 * (blk * BL + i);
+                        if (c0 + 1 < KS) {
+                            if (i & 1) { acc2 = fma(kin[c0], v[i].x, acc2); acc3 = fma(kin[c0 + 1], v[i].y, acc3); }
+                            else { acc0 = fma(kin[c0], v[i].x, acc0); acc1 = fma(kin[c0 + 1], v[i].y, acc1); }
+                        }
+                    }
+                }
+            }
+            const double xt = (acc0 + acc1) + (acc2 + acc3);
+            const double fzt = bperm_f64(xt, base + 2);
+            const double ztA = fma(-mucA, fzt, xt), ztB = fma(-mu, fzt, -xt);
+            // rows (two slots), relaxation, projection, dual update
+            const double nuA = fma(rhoA, ztA - zA, yA), nuB = fma(rhoB, ztB - zB, yB);
+            const double zhA = fma(alpha, ztA, oma * zA), zhB = fma(alpha, ztB, oma * zB);
+            const double znA = fmin(fmax(fma(yA, irho, zhA), loA), hiA), znB = fmin(fmax(fma(yB, irho, zhB), loB), hiB);
+            yA = fma(rhoA, zhA - znA, yA); yB = fma(rhoB, zhB - znB, yB);
+            zA = znA; zB = znB;
+            axA = fma(alpha, ztA, oma * axA); axB = fma(alpha, ztB, oma * axB);
+            spxA = fma(alpha, nuA, oma * spxA); spxB = fma(alpha, nuB, oma * spxB);
+            const double atw = At(fma(rhoA, zA, -yA), fma(rhoB, zB, -yB));
+            cpx = fma(alpha, fma(sigma, x - xt, -qv), oma * cpx);
+            x = fma(alpha, xt, oma * x);
+            rb[lane] = fma(sigma, x, -qv) + atw;                           // every lane writes (inactive lanes: 0)
+            asm volatile("" ::: "memory");
+            if (pretest) {
+                const bool bad = (rowA && !(fabs(axA - zA) <= e_prim_last)) || (rowB && !(fabs(axB - zB) <= e_prim_last));
+                vote_ok = __ballot(bad) == 0ull;
+            }
+            if (check) {
+                const double aty = At(yA, yB), px = cpx - At(spxA, spxB);
+                double rd = fabs(px + qv + aty);
+                double rp = fmax(rowA ? fabs(axA - zA) : 0.0, rowB ? fabs(axB - zB) : 0.0);
+                rd = (rd == rd) ? rd : kInf * 10.0;                        // a NaN residual must survive the max
+                rp = (rp == rp) ? rp : kInf * 10.0;
+                const double nr = fmax(rowA ? fmax(fabs(axA), fabs(zA)) : 0.0, rowB ? fmax(fabs(axB), fabs(zB)) : 0.0);
+                const float v0 = (float)rp, v1 = (float)nr;
+                const float v2 = active ? (float)rd : 0.0f, v3 = active ? (float)fmax(fabs(px), fabs(aty)) : 0.0f;
+                const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg(v0)), 63));
+                const float m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg(v1)), 63));
+                const float m2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg(v2)), 63));
+                const float m3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg(v3)), 63));
+                const double e_prim = a.eps_abs + a.eps_rel * (double)m1;
+                const double e_dual = a.eps_abs + a.eps_rel * fmax((double)m3, (double)qnf);
+                e_prim_last = e_prim;
+                if (!((double)m0 <= kInf) || !((double)m2 <= kInf)) { status = -1; iters = k; break; }
+                if ((double)m0 <= e_prim && (double)m2 <= e_dual) { status = 1; iters = k; break; }
+            }
+        }
+        if (active) xs_full[3 * gc + ax] = x;
+        if (a.y_out) {
+            if (rowA) a.y_out[(size_t)b * m + irowA] = yA;
+            if (rowB) a.y_out[(size_t)b * m + irowB] = yB;
+        }
+    }
+    __syncthreads();
+    if (a.y_out) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
+        const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
+        for (int i = lane; i < m; i += 64)
+            if (failed || sct[i / 5] == 0) a.y_out[(size_t)b * m + i] = 0.0;
+    }
+    if (lane == 0) {
+        if (a.status) a.status[b] = status;
+        if (a.iters) a.iters[b] = iters;
+    }
+    rollout_and_store<N, S, 64>(a, b, sm, xs_full, sm + L::o_scr);
+}
+
+}  // namespace srbdqp

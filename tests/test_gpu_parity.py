@@ -49,16 +49,20 @@ def test_assembly_matches_oracle(torch_first, built_lib, N, schedule):
 
 # kernel variants: gj / mfma keep all 12N variables (swing contacts clamped by their rows); compact (= auto) solves the
 # presolved QP.  The oracle twin runs the matching algorithm (SrbdParams.eliminate_swing).
-@pytest.mark.parametrize("kernel", ["gj", "mfma", "auto"])
+@pytest.mark.parametrize("kernel", ["gj", "mfma", "auto", "split"])
 @pytest.mark.parametrize("N,schedule,B", [(10, "single", 24), (10, "double", 8), (10, "mixed", 16), (8, "mixed", 8), (4, "single", 6)])
 def test_solve_matches_oracle_and_exact_optimum(torch_first, built_lib, kernel, N, schedule, B):
     from g1_locomotion_amd import _lib
-    kid = {"gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "auto": _lib.KERNEL_AUTO}[kernel]
+    kid = {"gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "auto": _lib.KERNEL_AUTO, "split": _lib.KERNEL_SPLIT}[kernel]
+    presolved = kernel in ("auto", "split")
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=200 + N, schedule=schedule)
     with _engine(N, kernel=kid) as eng:
         out = eng.solve(x0, xr, ft, ct, want_y=True)
-        assert eng.kernel_name().startswith({"gj": "gj_", "mfma": "mfma_", "auto": "compact_"}[kernel]), eng.kernel_name()
-    p = orc.SrbdParams(eliminate_swing=(kernel == "auto"))
+        # split = two kernels (set-up, then one wave per QP); it exists for <= 64 presolved variables, else falls back to compact
+        assert eng.kernel_name().startswith({"gj": ("gj_",), "mfma": ("mfma_",), "auto": ("compact_",), "split": ("split_", "compact_")}[kernel]), eng.kernel_name()
+        if kernel == "split" and schedule == "single":
+            assert eng.kernel_name().startswith("split_")
+    p = orc.SrbdParams(eliminate_swing=presolved)
     for b in range(B):
         ref = orc.update(p, x0[b], xr[b], ft[b], ct[b])
         assert out["status"][b] == ref["status"] and ref["status"] in (orc.STATUS_SOLVED, orc.STATUS_MAX_ITER)
@@ -71,12 +75,12 @@ def test_solve_matches_oracle_and_exact_optimum(torch_first, built_lib, kernel, 
         # solver-independent acceptance: KKT residuals of the GPU primal/dual pair in the scaled problem
         qp = ref["qp"]
         # (on the presolved problem: duals of the eliminated swing-contact rows are not returned)
-        kq = orc.presolve(qp, ct[b])[0] if kernel == "auto" else qp
-        vi = orc.presolve(qp, ct[b])[1] if kernel == "auto" else np.arange(12 * N)
-        ri = orc.presolve(qp, ct[b])[2] if kernel == "auto" else np.arange(20 * N)
+        kq = orc.presolve(qp, ct[b])[0] if presolved else qp
+        vi = orc.presolve(qp, ct[b])[1] if presolved else np.arange(12 * N)
+        ri = orc.presolve(qp, ct[b])[2] if presolved else np.arange(20 * N)
         kr = orc.kkt_residuals(kq["P"], kq["q"], kq["A"], kq["l"], kq["u"], out["u"][b].reshape(-1)[vi] / p.force_scale, out["y"][b][ri])
         assert kr["primal"] <= (1e-4 if solved else 1e-2) and kr["stationarity"] <= 1e-3 * max(1.0, np.abs(qp["q"]).max()), kr
-        if kernel == "auto":
+        if presolved:
             off = np.setdiff1d(np.arange(12 * N), vi)
             assert np.all(out["u"][b].reshape(-1)[off] == 0.0)          # swing contacts carry exactly zero force
 
@@ -206,7 +210,7 @@ def test_large_batch_against_c_oracle(torch_first, built_lib, N, pattern, B):
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     with _engine(N) as eng:
         out = eng.solve(x0, xr, ft, ct)
-        assert eng.kernel_name().startswith("compact_")
+        assert eng.kernel_name().startswith(("compact_", "split_"))
     np.testing.assert_array_equal(out["status"], ref["status"])
     assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
     same = out["iters"] == ref["iters"]
