@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="QPs per GPU per step (default: configs[1])")
-    ap.add_argument("--kernel", choices=["auto", "gj", "mfma", "compact"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "gj", "mfma", "compact", "split"], default="auto",
+                    help="auto = split pipeline (set-up kernel + one-wave ADMM kernel) for this batch size; compact = the fused kernel")
     ap.add_argument("--streams", type=int, default=2,
                     help="consecutive steps alternate over this many HIP streams, so the straggler tail of one batch "
                          "(QPs that need many ADMM iterations) overlaps the bulk of the next; 1 = strictly serial steps")
@@ -96,7 +97,8 @@ def main():
     d_it = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(S)]
     d_u0_all = [torch.empty((world * B, 12), dtype=torch.float64, device=dev) for _ in range(S)] if world > 1 else None
 
-    kid = {"auto": _lib.KERNEL_AUTO, "gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "compact": _lib.KERNEL_COMPACT}[args.kernel]
+    kid = {"auto": _lib.KERNEL_AUTO, "gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "compact": _lib.KERNEL_COMPACT,
+           "split": _lib.KERNEL_SPLIT}[args.kernel]
     # configs[1] is the 2-contact (single support) workload: at most 2 stance contact points per horizon step
     eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=2,
                    **({"max_iter": args.max_iter} if args.max_iter > 0 else {}))
@@ -183,7 +185,9 @@ def main():
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*_pmc_summary.json)",
                          "algorithmic_bytes_per_launch": algorithmic_bytes(N) * B,
                          "kernel": eng.kernel_name(), "kernel_ms": kernel_ms,
-                         "kernel_ms_note": "one launch at a time (5 isolated launches after warm-up, HIP events on the launch stream); the timed region overlaps consecutive steps on %d streams" % S,
+                         "kernel_ms_note": ("one solve at a time (5 isolated solves after warm-up, HIP events on the launch stream)"
+                                            + ("; a solve = the set-up kernel + the ADMM kernel back to back, the roofline is taken over the pair" if eng.kernel_name().startswith("split_") else "")
+                                            + "; the timed region overlaps consecutive steps on %d streams" % S),
                          "algorithmic_flops_per_qp": algorithmic_flops(N, mean_iters),
                          "hbm_algorithmic_GBps": hbm_gbs, "hbm_frac_of_8TBps": hbm_gbs / 8000.0},
         }
