@@ -34,8 +34,11 @@ struct srbdqp_handle {
     const char* kname = "none";
     long long* stamps = nullptr;   // diagnostic stamp buffer (device), see srbdqp_set_stamp_buffer
     const int32_t* sched_hint = nullptr;   // device: previous step's iters[] (srbdqp_set_schedule_hint)
-    int32_t* perm = nullptr;       // device: dispatch order built from the hint
-    size_t perm_cap = 0;
+    // per-launch-stream device scratch (a caller may pipeline solves of one handle over several streams: each stream
+    // needs its own dispatch order and its own split-pipeline hand-over workspace)
+    struct StreamSlot { hipStream_t st = nullptr; bool used = false; int32_t* perm = nullptr; size_t perm_cap = 0; double* ws = nullptr; size_t ws_doubles = 0; };
+    static constexpr int kMaxSlots = 8;
+    StreamSlot slots[kMaxSlots];
     // low-latency staging: one pinned, GPU-mapped slab carved into the arrays of srbdqp_stage
     char* stage_host = nullptr;
     char* stage_dev = nullptr;
@@ -47,11 +50,15 @@ struct srbdqp_handle {
     int32_t* done_count = nullptr;
     int32_t done_seq = 0;
     bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
-    // split pipeline: per-QP hand-over workspace between the set-up kernel and the ADMM kernel
-    double* split_ws = nullptr;
-    size_t split_ws_doubles = 0;
-    std::string kname_store;
 };
+
+// slot of a launch stream (at most kMaxSlots distinct streams per handle; null when exhausted)
+srbdqp_handle::StreamSlot* stream_slot(srbdqp_handle* h, hipStream_t st) {
+    for (auto& s : h->slots) if (s.used && s.st == st) return &s;
+    for (auto& s : h->slots) if (!s.used) { s.used = true; s.st = st; return &s; }
+    h->err = "more than 8 distinct launch streams on one handle";
+    return nullptr;
+}
 
 namespace {
 
@@ -137,14 +144,16 @@ template <int N, int MAXS>
 int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     using W = srbdqp::SplitWs<N, MAXS>;
     const size_t need = (size_t)a.B * W::doubles;
-    if (need > h->split_ws_doubles) {
+    auto* slot = stream_slot(h, st);
+    if (!slot) return SRBDQP_E_INVALID;
+    if (need > slot->ws_doubles) {
         HIP_TRY(h, hipStreamSynchronize(st));               // a previous launch on this stream may still use the old buffer
-        if (h->split_ws) { HIP_TRY(h, hipFree(h->split_ws)); h->split_ws = nullptr; h->split_ws_doubles = 0; }
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->split_ws), need * sizeof(double));
+        if (slot->ws) { HIP_TRY(h, hipFree(slot->ws)); slot->ws = nullptr; slot->ws_doubles = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&slot->ws), need * sizeof(double));
         if (e != hipSuccess) { h->err = std::string("hipMalloc split workspace: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
-        h->split_ws_doubles = need;
+        slot->ws_doubles = need;
     }
-    a.ws = h->split_ws;
+    a.ws = slot->ws;
     constexpr size_t ldsA = srbdqp::CompactTraits<N, MAXS>::lds_bytes, ldsB = srbdqp::SplitSmem<N, MAXS>::bytes;
     static bool attr_set = false;
     int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, true>, ldsA, attr_set);
@@ -309,7 +318,6 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
         if (h->stream) (void)hipStreamDestroy(h->stream);
         if (h->stage_host) (void)hipHostFree(h->stage_host);
         if (h->done_count) (void)hipFree(h->done_count);
-    if (h->split_ws) (void)hipFree(h->split_ws);
         delete h;
         return SRBDQP_E_HIP;
     };
@@ -351,7 +359,7 @@ int srbdqp_destroy(srbdqp_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
-    if (h->perm) (void)hipFree(h->perm);
+    for (auto& sl : h->slots) { if (sl.perm) (void)hipFree(sl.perm); if (sl.ws) (void)hipFree(sl.ws); }
     if (h->done_count) (void)hipFree(h->done_count);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -455,14 +463,17 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
     if (h->signal_next) { a.done_flag = h->done_dev; a.done_count = h->done_count; a.done_value = h->done_seq; }
     hipStream_t lst = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
     if (h->sched_hint && B > 1) {
-        if ((size_t)B > h->perm_cap) {
-            if (h->perm) HIP_TRY(h, hipFree(h->perm));
-            h->perm = nullptr; h->perm_cap = 0;
-            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->perm), sizeof(int32_t) * (size_t)B));
-            h->perm_cap = (size_t)B;
+        auto* slot = stream_slot(h, lst);
+        if (!slot) return SRBDQP_E_INVALID;
+        if ((size_t)B > slot->perm_cap) {
+            HIP_TRY(h, hipStreamSynchronize(lst));          // a previous launch on this stream may still read the old order
+            if (slot->perm) HIP_TRY(h, hipFree(slot->perm));
+            slot->perm = nullptr; slot->perm_cap = 0;
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&slot->perm), sizeof(int32_t) * (size_t)B));
+            slot->perm_cap = (size_t)B;
         }
-        hipLaunchKernelGGL(srbdqp_schedule_kernel, dim3(1), dim3(1024), 0, lst, h->sched_hint, h->perm, (int)B);
-        a.perm = h->perm;
+        hipLaunchKernelGGL(srbdqp_schedule_kernel, dim3(1), dim3(1024), 0, lst, h->sched_hint, slot->perm, (int)B);
+        a.perm = slot->perm;
     }
     int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
     return launch(h, a, lst, maxs);

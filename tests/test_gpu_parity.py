@@ -258,3 +258,41 @@ def test_full_size_batch_properties(torch_first, built_lib):
     np.testing.assert_array_equal(st[idx], ref["status"])
     assert np.abs(it[idx].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
     assert np.abs(out["u"][idx] - ref["u"]).max() <= TOL_TWIN_N
+
+
+def test_two_streams_pipeline_distinct_batches_through_one_handle(torch_first, built_lib):
+    """What bench.py does, with DIFFERENT batches in flight: consecutive solves of one handle alternate over two HIP
+    streams without synchronising in between (split pipeline + dispatch hint: per-stream hand-over workspace and
+    dispatch order).  Every result must equal, bit for bit, the result of the same batch solved alone."""
+    torch = torch_first
+    from g1_locomotion_amd import BatchMPC
+    N, B = 10, 1024
+    dev = torch.device("cuda", 0)
+    batches = [[torch.from_numpy(v).to(dev) for v in orc.synthetic_batch(B, N, seed=700 + i, schedule="single")] for i in range(4)]
+    with BatchMPC(horizon=N, max_contacts_per_step=2) as eng:
+        def solve(d, stream=0, hint=None):
+            u = torch.zeros((B, N, 12), dtype=torch.float64, device=dev)
+            it = torch.zeros(B, dtype=torch.int32, device=dev)
+            st = torch.zeros(B, dtype=torch.int32, device=dev)
+            eng.set_schedule_hint(hint.data_ptr() if hint is not None else 0)
+            eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(),
+                             status=st.data_ptr(), iters=it.data_ptr(), stream=stream)
+            return u, it, st
+        alone = []
+        for d in batches:
+            r = solve(d)
+            eng.synchronize()
+            alone.append([t.clone() for t in r])
+        assert eng.kernel_name().startswith("split_")
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        torch.cuda.synchronize(dev)
+        outs = []
+        for rep in range(3):
+            for i, d in enumerate(batches):
+                s = streams[i % 2]
+                with torch.cuda.stream(s):
+                    outs.append((i, solve(d, stream=s.cuda_stream, hint=alone[i][1])))
+        torch.cuda.synchronize(dev)
+        eng.set_schedule_hint(0)
+    for i, (u, it, st) in outs:
+        assert torch.equal(u, alone[i][0]) and torch.equal(it, alone[i][1]) and torch.equal(st, alone[i][2]), i
