@@ -225,15 +225,8 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                 xt = acc + dpp_swap1(acc);
                 if constexpr (LPR == 4) xt += dpp_swap2(xt);
             }
-#if defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 1 || SRBDQP_ABLATE == 5 || SRBDQP_ABLATE == 6)
-            xt = kin[0] * rb[r];   // ablation: no mat-vec
-#endif
             ADMM_T(tp1);
-#if defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 2 || SRBDQP_ABLATE == 5 || SRBDQP_ABLATE == 6)
-            const double zt = sgn * xt;   // ablation: no fz gather
-#else
             const double zt = Arow(xt);
-#endif
             const double nu = rowm * (rho * (zt - z) + y);
             const double zh = alpha * zt + oma * z;
             const double zn = fmin(fmax(zh + y * irho, lo), hi);
@@ -242,11 +235,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
             axr = rowm * (alpha * zt + oma * axr);          // A x^{k+1} = alpha A x~ + (1 - alpha) A x^k
             spx = alpha * nu + oma * spx;
             ADMM_T(tp2);
-#if defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 3 || SRBDQP_ABLATE == 5 || SRBDQP_ABLATE == 6)
-            const double atw = rho * z - y;   // ablation: no A' gather
-#else
             const double atw = At(rho * z - y);
-#endif
             cpx = alpha * (sigma * (x - xt) - qv) + oma * cpx;
             x = alpha * xt + oma * x;
             if (active && hp == 0) wb[r] = sigma * x - qv + atw;
@@ -278,9 +267,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
         }
         if (check) { ++nchk; pending = true; }
         ADMM_T(tp4);
-#if !(defined(SRBDQP_ABLATE) && (SRBDQP_ABLATE == 4 || SRBDQP_ABLATE == 6))
         __syncthreads();
-#endif
         ADMM_T(tp5);
         seg0 += tp1 - tp0; seg1 += tp2 - tp1; seg2 += tp3 - tp2; seg3 += tp4 - tp3; seg4 += tp5 - tp4;
     }

@@ -6,8 +6,8 @@
 //   H  : K = G'G (+ R s^2 + sigma + A' rho A on the diagonal), G = Q^1/2 s B_qp packed block-lower in LDS; the 36
 //        upper tiles (n = 120 -> 8x8 tiles) accumulate in registers, 9 tiles per wave.          [a7, MFMA contraction]
 //   F  : right-looking Cholesky K = U'U with the trailing tiles resident in registers; per block column one wave
-//        factors the 16x16 diagonal tile (LDL' elimination with the identity riding along in lanes 16..31, so it
-//        directly yields L_jj^-1), the panel is L_jj^-1 K_jb and the trailing update K_ab -= U_ja' U_jb.  [a9 factor]
+//        factors and inverts the 16x16 diagonal tile (diag16_invert_mfma: blocked 4x4, on the matrix cores), the
+//        panel is L_jj^-1 K_jb and the trailing update K_ab -= U_ja' U_jb.                          [a9 factor]
 //   W  : W = L^-1 row by row, in place over U (W_ij = -W_ii sum_k L_ik W_kj).
 //   I  : K^-1 = W'W, tiles swizzled into LDS, then every thread pulls its row fragment of K^-1 into registers.
 //   ADMM: shared admm_loop() -- the two triangular solves of each iteration are applied as one mat-vec with the
@@ -104,22 +104,6 @@ __device__ __forceinline__ void store_tile(double* tile, const v4d& v, int lane)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// 16x16 diagonal tile: T (SPD, row-major in LDS) -> L^-1 (lower triangular, XOR-swizzled, in place), T = L L'.
-// One wave.  Lanes 0..15 hold column c of T, lanes 16..31 column c of M (starts as I); the LDL' elimination
-// T <- E T applies the same row operations to M, so M ends as Ltilde^-1 (unit lower) for free; L^-1 = D^-1/2 M.
-// Returns false if a pivot is not positive.
-// ---------------------------------------------------------------------------------------------------------
-// 1/d to full double precision without the IEEE division sequence (d is a positive, normal pivot):
-// v_rcp_f64 seed + two Newton steps.
-__device__ __forceinline__ double fast_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-d, r, 1.0);
-    return fma(r, e, r);
-}
-
 // 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (d is a positive, normal pivot).
 __device__ __forceinline__ double fast_rsqrt(double d) {
     double r = __builtin_amdgcn_rsq(d);
@@ -138,7 +122,8 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 //   - U_kb = L_kk^-1 S_kb              one MFMA (L_kk^-1 embedded in rows 4kb..4kb+3 of the A operand),
 //   - S   -= U_kb' U_kb                one MFMA (trailing update of the whole tile),
 //   - W_kb = L_kk^-1 R_kb, R -= L[:,kb] W_kb   two MFMAs (block forward substitution L W = I riding along),
-// 14 MFMAs and ~350 other instructions per tile instead of ~1000 for the row-by-row elimination above.
+// 14 MFMAs and ~350 other instructions per tile (a row-by-row LDL' elimination with v_readlane broadcasts, the first
+// version of this routine, took ~1000 and twice the time).
 // ---------------------------------------------------------------------------------------------------------
 template <int KB>
 __device__ __forceinline__ void diag16_block(v4d& s, v4d& rr, v4d& w, double& pmin, int lane) {
@@ -200,76 +185,6 @@ __device__ __forceinline__ v4d diag16_invert_mfma(v4d s, int lane, bool& ok) {
     return w;
 }
 
-// One elimination step, P compile-time so that every t[] index is static.  The multipliers l_rP (one per lane)
-// reach the other lanes two ways: the one on the critical path (row P+1, which produces the next pivot) by
-// v_readlane, all the others by an LDS all-gather (one ds_write_b64 + broadcast ds_read_b128s) whose latency hides
-// behind the next pivot's reciprocal chain.  `scr` = 16 doubles of LDS scratch private to this wave.
-template <int P>
-__device__ __forceinline__ void diag16_step(double (&t)[16], double& dsave, bool& ok, double rd, int lane, double* scr) {
-    const double lvec = t[P] * rd;                    // lane r (< 16): l_rP = T[P][r] / d_P
-    if constexpr (P < 14) {
-        if (lane < 16) scr[lane] = lvec;
-        asm volatile("" ::: "memory");             // the double2 reads below must not be hoisted above this store
-    }
-    double rd_next = 0.0;
-    if constexpr (P < 15) {
-        const double l1 = readlane_f64(lvec, P + 1);
-        t[P + 1] = fma(-l1, t[P], t[P + 1]);
-        const double dn = readlane_f64(t[P + 1], P + 1);   // next pivot
-        ok = ok && (dn > 0.0);
-        dsave = (lane == P + 1) ? dn : dsave;
-        rd_next = fast_rcp(dn);
-    }
-    if constexpr (P < 14) {
-        constexpr int R0 = (P + 2) & ~1;              // first 16-byte aligned pair that holds a needed row
-        double2 lv[(16 - R0) / 2];
-#pragma unroll
-        for (int q = 0; q < (16 - R0) / 2; ++q) lv[q] = reinterpret_cast<const double2*>(scr + R0)[q];
-#pragma unroll
-        for (int r = P + 2; r < 16; ++r) {
-            const double lr = ((r - R0) & 1) ? lv[(r - R0) >> 1].y : lv[(r - R0) >> 1].x;
-            t[r] = fma(-lr, t[P], t[r]);              // T rows in lanes 0..15, M rows in lanes 16..31
-        }
-    }
-    // keep this step's row updates HERE: left alone, the compiler sinks each row's FMA chain to the step where the row
-    // becomes the pivot (left-looking order), which keeps every step's multipliers live at once and spills.  An empty
-    // asm with a read-write operand pins the value without emitting an instruction.
-#pragma unroll
-    for (int r = P + 2; r < 16; ++r) asm volatile("" : "+v"(t[r]));
-    if constexpr (P < 15) diag16_step<P + 1>(t, dsave, ok, rd_next, lane, scr);
-}
-
-__device__ __forceinline__ bool diag16_invert(double* tile, int lane) {
-    const int c = lane & 15;
-    const bool isT = lane < 16, isM = (lane >= 16) && (lane < 32);
-    double t[16];
-    const double tmask = isT ? 1.0 : 0.0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const double v = tile[r * 16 + c];            // every lane reads (same addresses); arithmetic select, no branch
-        t[r] = fma(v, tmask, (!isT && r == c) ? 1.0 : 0.0);
-    }
-    asm volatile("" ::: "memory");
-    // the tile now lives in registers: its LDS words are free scratch until the final store
-    const double d0 = readlane_f64(t[0], 0);
-    double dsave = (lane == 0) ? d0 : 1.0;
-    bool ok = d0 > 0.0;
-    diag16_step<0>(t, dsave, ok, fast_rcp(d0), lane, tile);
-    const double rsv = fast_rsqrt(dsave);             // lane p: d_p^-1/2
-    if (lane < 16) tile[lane] = rsv;
-    asm volatile("" ::: "memory");
-    double2 rs2[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) rs2[q] = reinterpret_cast<const double2*>(tile)[q];
-    asm volatile("" ::: "memory");
-    // overwrite the tile with L^-1, swizzled (the scratch words were read into registers above: same wave, in order)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const double rs = (r & 1) ? rs2[r >> 1].y : rs2[r >> 1].x;
-        if (isM) tile[r * 16 + (c ^ r)] = (r >= c) ? t[r] * rs : 0.0;
-    }
-    return ok;
-}
 
 template <int N>
 __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
@@ -373,8 +288,13 @@ __global__ __launch_bounds__(kThreads, 2) void srbdqp_mfma_kernel(KArgs a) {
             if (ta[s] == j && tb[s] == j) store_tile<false>(Djj, acc[s], lane);
         __syncthreads();
         F_T(ft1);
-        if (w == (j & 3)) {
-            const bool ok = diag16_invert(Djj, lane);
+        if (w == (j & 3)) {   // load the tile back in C layout, invert it on the matrix cores, store L_jj^-1 swizzled
+            v4d d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = Djj[((lane >> 4) + 4 * r) * 16 + (lane & 15)];
+            bool ok;
+            const v4d winv = diag16_invert_mfma(d, lane, ok);
+            store_tile<true>(Djj, winv, lane);
             if (!ok && lane == 0) sm[S::o_misc] = 1.0;
         }
         __syncthreads();
