@@ -24,7 +24,7 @@ KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT, KERNEL_SPLIT = 0, 1, 2, 3, 
 EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",
     "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_assemble_f64",
-    "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_kernel_name", "srbdqp_version",
+    "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
 )
@@ -120,6 +120,8 @@ def load():
     lib.srbdqp_synchronize.restype = C.c_int
     lib.srbdqp_last_kernel_ms.argtypes = [H]
     lib.srbdqp_last_kernel_ms.restype = C.c_double
+    lib.srbdqp_last_kernel_parts_ms.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.srbdqp_last_kernel_parts_ms.restype = C.c_int
     lib.srbdqp_kernel_name.argtypes = [H]
     lib.srbdqp_kernel_name.restype = C.c_char_p
     lib.srbdqp_swing_f64.argtypes = [H, C.c_int64, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp]

@@ -25,8 +25,8 @@ struct srbdqp_handle {
     srbdqp_config cfg;
     int maxs_override = 0;         // set by the host-buffer API after scanning the contact flags
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;   // ev_mid: between the two kernels of the split pipeline
+    bool ev_valid = false, ev_mid_valid = false;
     // device workspace for the host-buffer API
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -161,6 +161,7 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     static const std::string nm = "split_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
     hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), ldsA, st, a);
+    if (h->cfg.flags & SRBDQP_FLAG_TIMING) { HIP_TRY(h, hipEventRecord(h->ev_mid, st)); h->ev_mid_valid = true; }
     hipLaunchKernelGGL((srbdqp::srbdqp_admm_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), ldsB, st, a);
     return SRBDQP_OK;
 }
@@ -224,7 +225,7 @@ int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4) {
     if (a.B <= 0) return SRBDQP_OK;
     const int variant = (a.mode == 1) ? SRBDQP_KERNEL_GJ : resolve_kernel(h->cfg);
     const bool timing = (h->cfg.flags & SRBDQP_FLAG_TIMING) != 0;
-    if (timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    if (timing) { HIP_TRY(h, hipEventRecord(h->ev0, st)); h->ev_mid_valid = false; }
     int rc;
     switch (h->cfg.horizon) {
         case 4: rc = launch_n<4>(h, a, st, variant, maxs); break;
@@ -315,6 +316,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
         g_create_err = std::string(what) + ": " + hipGetErrorString(er);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
+        if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         if (h->stage_host) (void)hipHostFree(h->stage_host);
         if (h->done_count) (void)hipFree(h->done_count);
@@ -325,6 +328,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreate(&h->ev_mid)) != hipSuccess) return fail("hipEventCreate", e);
     {   // staging slab for the low-latency path
         const size_t N = (size_t)cfg->horizon, n = 12 * N, m = 20 * N, cap = 16;
         auto carve = [&](char* base, srbdqp_stage& st) {
@@ -364,6 +368,7 @@ int srbdqp_destroy(srbdqp_handle* h) {
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SRBDQP_OK;
@@ -444,6 +449,17 @@ double srbdqp_last_kernel_ms(srbdqp_handle* h) {
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
     return (double)ms;
+}
+
+int srbdqp_last_kernel_parts_ms(srbdqp_handle* h, double* setup_ms, double* admm_ms) {
+    if (!h || !setup_ms || !admm_ms) return SRBDQP_E_INVALID;
+    if (!h->ev_valid || !h->ev_mid_valid) { h->err = "the last solve was not a timed split-pipeline solve"; return SRBDQP_E_INVALID; }
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float a = -1.0f, b = -1.0f;
+    HIP_TRY(h, hipEventElapsedTime(&a, h->ev0, h->ev_mid));
+    HIP_TRY(h, hipEventElapsedTime(&b, h->ev_mid, h->ev1));
+    *setup_ms = (double)a; *admm_ms = (double)b;
+    return SRBDQP_OK;
 }
 
 int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref,

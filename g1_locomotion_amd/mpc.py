@@ -216,6 +216,13 @@ class BatchMPC:
     def last_kernel_ms(self) -> float:
         return float(self._lib.srbdqp_last_kernel_ms(self._h))
 
+    def last_kernel_parts_ms(self):
+        """(set-up ms, ADMM ms) of the last timed solve when it ran as the split pipeline, else None."""
+        a, b = C.c_double(), C.c_double()
+        if self._lib.srbdqp_last_kernel_parts_ms(self._h, C.byref(a), C.byref(b)) != _lib.OK:
+            return None
+        return float(a.value), float(b.value)
+
     def kernel_name(self) -> str:
         return self._lib.srbdqp_kernel_name(self._h).decode()
 

@@ -167,6 +167,10 @@ int srbdqp_synchronize(srbdqp_handle* h);
  * kernel launch, in milliseconds; synchronises that event.  Negative if unavailable. */
 double srbdqp_last_kernel_ms(srbdqp_handle* h);
 
+/* With SRBDQP_FLAG_TIMING, after a solve that ran as the split pipeline: device time of its two kernels (the set-up
+ * kernel incl. the dispatch-order kernel in front of it, and the ADMM + roll-out kernel).  SRBDQP_E_INVALID otherwise. */
+int srbdqp_last_kernel_parts_ms(srbdqp_handle* h, double* setup_ms, double* admm_ms);
+
 /* Name of the kernel variant the last solve launched ("gj_f64_n10", "mfma_f64_n10", ...). */
 const char* srbdqp_kernel_name(const srbdqp_handle* h);
 
