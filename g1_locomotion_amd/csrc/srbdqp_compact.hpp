@@ -45,7 +45,6 @@ struct CompactSmem {
     static constexpr int LPR = (4 * nmax <= kThreads) ? 4 : 2;
 #endif
     static constexpr int CHMAX = 2 * ((nmax + 2 * LPR - 1) / (2 * LPR));   // columns per mat-vec part (even)
-    static constexpr int gmax = 36 * MAXS * (N * (N + 1) / 2);
     static constexpr int up2(int v) { return (v + 1) & ~1; }
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     // ---- persistent
@@ -60,21 +59,25 @@ struct CompactSmem {
     static constexpr int o_sq = o_misc + 8;
     static constexpr int o_int = o_sq + 12;               // ints: cnt[N], rowbase[N], na, flags; bytes: act[4N]
     static constexpr int o_R = o_int + up2((2 * N + 8) / 2 + (4 * N + 7) / 8 + 1);
-    // phase A.  Lifetimes let two pairs share storage: foot/pcom are dead after the linearisation and G x^0 (warm
-    // start, after the gradient) takes their place; x_ref is dead once the gradient's error vector is built and the
-    // compact warm start takes its place when it fits.
-    static constexpr int o_G = o_R;
-    static constexpr int o_xref = o_G + gmax;
+    // phase A (closed-form assembly: inputs, C prefix sums, error vector, the small tables of the assembly)
+    static constexpr int NPAIR = N * (N + 1) / 2;
+    static constexpr int o_xref = o_R;
     static constexpr int o_foot = o_xref + up2(N * 13);
     static constexpr int o_pcom = o_foot + N * 12;
     static constexpr int o_cp = o_pcom + up2(N * 3);
-    static constexpr int o_eh = o_cp + up2(N * 9);
-    static constexpr int o_gx = o_foot;                   // n (row space): G x^0
-    static constexpr bool x0c_in_xref = up2(nmax) + 16 <= up2(N * 13);
-    static constexpr int o_x0c = x0c_in_xref ? o_xref : o_eh + n;     // nmax (+16 padding): compact warm start
-    static constexpr int endA = x0c_in_xref ? o_eh + n : o_x0c + up2(nmax) + 16;
-    // phase B
-    static constexpr int o_T = o_R;
+    static constexpr int o_eh = o_cp + up2(N * 9);        // n: Q^1/2 (A_qp x0 - x_ref)
+    static constexpr int o_t1 = o_eh + n;                 // 9N: T1(m)
+    static constexpr int o_t2 = o_t1 + up2(9 * N);        // 9N: T2(m)
+    static constexpr int o_mt = o_t2 + up2(9 * N);        // 9 NPAIR: M(j, m) at 9 (m (m + 1) / 2 + j), j <= m
+    static constexpr int o_gv = o_mt + up2(9 * NPAIR);    // 9N: G'v tables
+    static constexpr int o_gx = o_gv + up2(9 * N);        // n: G x^0 (warm start)
+    static constexpr int o_tf = o_gx + n;                 // 6N: per-step torque / force sums of x^0
+    static constexpr int o_x0c = o_tf + 6 * N;            // nmax (+16): compact warm start
+    static constexpr int endA = o_x0c + up2(nmax) + 16;
+    // phase B.  Small problems (<= 4 x 4 tiles) assemble K contact pair by contact pair straight into the tile store,
+    // which then sits behind the phase-A arrays; the big ones build their entries in registers and re-use region R.
+    static constexpr bool STAGE = (NT <= 4);
+    static constexpr int o_T = STAGE ? endA : o_R;
     static constexpr int endB = o_T + NTT * 256;
     // phase C
     static constexpr int o_rhs = o_R;                     // 2 x (LPR CHMAX + 8)
@@ -308,11 +311,9 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     int mcol = lane & 15, kq = lane >> 4;                   // re-laundered per phase, see SRBDQP_PHASE_LOCAL
-    double* G = sm + S::o_G;
     double* T = sm + S::o_T;
     int* icnt = reinterpret_cast<int*>(sm + S::o_int);          // cnt[i] = stance contacts in steps 0..i
-    int* irb = icnt + N;                                        // rowbase[i] = offset of block row i in G
-    int* imisc = irb + N;                                       // [0] na, [1] bound violated
+    int* imisc = icnt + 2 * N;                                  // [0] na, [1] bound violated
     uint8_t* act = reinterpret_cast<uint8_t*>(imisc + 8);       // compact contact -> original contact
 
     // ================= phase A =================
@@ -362,13 +363,11 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
         }
         __syncthreads();
     }
-    if (t == 0) {   // offsets of the block rows of G, and the per-step bound check
-        int viol = 0, rb = 0;
+    if (t == 0) {   // the per-step bound check
+        int viol = 0;
         for (int i = 0; i < N; ++i) {
             const int ci = icnt[i] - (i ? icnt[i - 1] : 0);
             viol |= (ci > MAXS);
-            irb[i] = rb;
-            rb += 36 * icnt[i];
         }
         imisc[1] = viol;
     }
@@ -389,83 +388,144 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
         return;
     }
     SRBDQP_STAMP(a, b, 1);
-    // ---- a6: compact G.  thread = (contact slot g of 14, row-pair type, rr, ax)
-    if (t < 252) {
-        const int g = t / 18, u = t - 18 * g;
-        const int type = u / 9, v = u - 9 * type;
-        const int rr = v / 3, ax = v - 3 * rr;
-        const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = a.dt * a.dt * a.inv_mass;
-        const double wA = sm[S::o_sq + (type ? 3 : 0) + rr] * a.s, wB = sm[S::o_sq + (type ? 9 : 6) + rr] * a.s;
-        const int rowA = (type ? 3 : 0) + rr, rowB = (type ? 9 : 6) + rr;
-        for (int e = g; e < na; e += 14) {
-            const int gc = act[e], j = gc >> 2, cc = 3 * (gc & 3) + ax;
-            const double* J = sm + S::o_J + j * 36 + cc;
-            const double j0 = J[0], j1 = J[12], j2 = J[24];
-            const double* Cj = sm + S::o_cp + j * 9 + rr * 3;
-            const double c0 = Cj[0], c1 = Cj[1], c2 = Cj[2];
-            const double jr = (rr == 0) ? j0 : (rr == 1) ? j1 : j2;
-            for (int i = j; i < N; ++i) {
-                const int len = 3 * icnt[i];
-                double* dst = G + irb[i] + 3 * e + ax;
-                double vA, vB;
-                if (type == 0) {
-                    const double* Ci = sm + S::o_cp + i * 9 + rr * 3;
-                    vA = dt2 * ((Ci[0] - c0) * j0 + (Ci[1] - c1) * j1 + (Ci[2] - c2) * j2);
-                    vB = dt * jr;
-                } else {
-                    vA = (rr == ax) ? (double)(i - j) * dt2m : 0.0;
-                    vB = (rr == ax) ? dtm : 0.0;
-                }
-                dst[len * rowA] = wA * vA;
-                dst[len * rowB] = wB * vB;
-            }
-        }
-    }
+    // ---- a6 + a7 in closed form.  G = Q^1/2 s B_qp is never materialised: with D_im = C_i - C_m the blocks of B_qp are
+    // theta: dt^2 D_ij J_j, p: (i-j) dt^2/m I, omega: dt J_j, v: dt/m I (bqp_entry()), so for contacts e (step j) and
+    // e' (step m >= j)
+    //   (G'G)[e,a][e',a'] = s^2 ( J_e[:,a]' M(j,m) J_e'[:,a'] + [a = a'] (w_p[a] dt^4/m^2 Sp(j,m) + w_v[a] dt^2/m^2 (N-m)) ),
+    //   M(j,m) = dt^4 (T2(m) + (C_m - C_j)' W_th T1(m)) + (N-m) dt^2 W_om,   T1(m) = sum_{i>=m} D_im,
+    //   T2(m) = sum_{i>=m} D_im' W_th D_im,   Sp(j,m) = sum_{i>=m} (i-j)(i-m),
+    // and G'v for a stacked vector v is a suffix sum per step followed by one 3-vector product per contact.  The
+    // differences D are formed before anything is multiplied, as in the dense products of the oracle (no cancellation).
+    const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = dt2 * a.inv_mass;
+    double* T1 = sm + S::o_t1;
+    double* T2 = sm + S::o_t2;
+    double* MT = sm + S::o_mt;
+    double* GV = sm + S::o_gv;
+    const double* CP = sm + S::o_cp;
+    const double* SQ = sm + S::o_sq;
     for (int k = t; k < n; k += kThreads) {   // Q^1/2 (A_qp x0 - x_ref), all 12 N rows
         const int i = k / 12, kk = k - 12 * i;
-        sm[S::o_eh + k] = sm[S::o_sq + kk] * (free_response<N, S>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
+        sm[S::o_eh + k] = SQ[kk] * (free_response<N, S>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
+    }
+    if (t < 9 * N) {
+        const int mm = t / 9, pq = t - 9 * mm, p = pq / 3, q = pq - 3 * p;
+        const double* Cm = CP + mm * 9;
+        const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2];
+        const double m0p = Cm[p], m1p = Cm[3 + p], m2p = Cm[6 + p], m0q = Cm[q], m1q = Cm[3 + q], m2q = Cm[6 + q], mpq = Cm[pq];
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {   // unrolled with a predicate: all the LDS reads are in flight together
+            const double* Ci = CP + i * 9;
+            const double on = (i >= mm) ? 1.0 : 0.0;
+            const double d0p = Ci[p] - m0p, d1p = Ci[3 + p] - m1p, d2p = Ci[6 + p] - m2p;
+            const double d0q = Ci[q] - m0q, d1q = Ci[3 + q] - m1q, d2q = Ci[6 + q] - m2q;
+            s1 = fma(on, Ci[pq] - mpq, s1);
+            s2 = fma(on, (w0 * d0p) * d0q + (w1 * d1p) * d1q + (w2 * d2p) * d2q, s2);
+        }
+        T1[t] = s1;
+        T2[t] = s2;
+    }
+    __syncthreads();
+    // G'v tables: per step j the 3-vector g (theta + omega rows) and the per-axis sums of the p and v rows
+    auto gt_tables = [&](const double* vec) {
+        if (t < 9 * N) {
+            const int j = t / 9, comp = t - 9 * j;
+            const double* Cj = CP + j * 9;
+            double acc = 0.0;
+            if (comp < 3) {
+                const double c0 = Cj[comp], c1 = Cj[3 + comp], c2 = Cj[6 + comp];
+                const double q0 = SQ[0] * dt2, q1 = SQ[1] * dt2, q2 = SQ[2] * dt2, qw = SQ[6 + comp] * dt;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double* Ci = CP + i * 9;
+                    const double* v = vec + 12 * i;
+                    const double on = (i >= j) ? 1.0 : 0.0;
+                    acc = fma(on, (Ci[comp] - c0) * (q0 * v[0]) + (Ci[3 + comp] - c1) * (q1 * v[1]) + (Ci[6 + comp] - c2) * (q2 * v[2]) + qw * v[6 + comp], acc);
+                }
+            } else {
+                const int kk = (comp < 6) ? comp : 3 + comp;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double wgt = (i >= j) ? ((comp < 6) ? (double)(i - j) : 1.0) : 0.0;
+                    acc = fma(wgt, vec[12 * i + kk], acc);
+                }
+            }
+            GV[t] = acc;
+        }
+    };
+    auto gt_eval = [&](int c) -> double {   // (G'v)[c] for compact variable c, from the tables
+        const int e = c / 3, ax = c - 3 * e, gc = act[e], j = gc >> 2;
+        const double* J = sm + S::o_J + j * 36 + 3 * (gc & 3) + ax;
+        const double* g = GV + 9 * j;
+        return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
+    };
+    gt_tables(sm + S::o_eh);
+    // M(j, m), j <= m, at MT[9 (m (m + 1) / 2 + j)]
+    for (int idx = t; idx < 9 * S::NPAIR; idx += kThreads) {
+        const int pair = idx / 9, pq = idx - 9 * pair, p = pq / 3, q = pq - 3 * p;
+        int mm = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
+        mm += ((mm + 1) * (mm + 2) / 2 <= pair) ? 1 : 0;
+        mm -= (mm * (mm + 1) / 2 > pair) ? 1 : 0;
+        const int j = pair - mm * (mm + 1) / 2;
+        const double* Cm = CP + mm * 9;
+        const double* Cj = CP + j * 9;
+        const double* t1 = T1 + mm * 9;
+        double v = T2[mm * 9 + pq];
+        v += (Cm[p] - Cj[p]) * (SQ[0] * SQ[0]) * t1[q] + (Cm[3 + p] - Cj[3 + p]) * (SQ[1] * SQ[1]) * t1[3 + q] + (Cm[6 + p] - Cj[6 + p]) * (SQ[2] * SQ[2]) * t1[6 + q];
+        v *= dt2 * dt2;
+        if (p == q) v += (double)(N - mm) * dt2 * SQ[6 + p] * SQ[6 + p];
+        MT[idx] = v;
     }
     __syncthreads();
     SRBDQP_STAMP(a, b, 2);
-    {   // ---- a7 gradient (compact columns), two threads per column
-        const int c = t >> 1, h = t & 1;
-        double acc = 0.0;
-        if (c < n_eff) {
-            for (int i = act[c / 3] >> 2; i < N; ++i) {
-                const int len = 3 * icnt[i];
-                const double* col = G + irb[i] + len * h + c;
-                const double* e = sm + S::o_eh + 12 * i + h;
-                double p0 = col[0] * e[0], p1 = col[2 * len] * e[2], p2 = col[4 * len] * e[4];
-                p0 = fma(col[6 * len], e[6], p0);
-                p1 = fma(col[8 * len], e[8], p1);
-                p2 = fma(col[10 * len], e[10], p2);
-                acc += (p0 + p1) + p2;
-            }
-        }
-        acc += dpp_swap1(acc);
-        if (c < n_eff && h == 0) sm[S::o_q + c] = acc;
-    }
-    if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0 on the compact columns
+    for (int c = t; c < n_eff; c += kThreads) sm[S::o_q + c] = gt_eval(c);
+    if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0 on the compact variables
+        double* TF = sm + S::o_tf;
         for (int c = t; c < n_eff; c += kThreads)
             sm[S::o_x0c + c] = a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)] / a.s;
         __syncthreads();
-        for (int k = t; k < n; k += kThreads) {
-            const int i = k / 12, kk = k - 12 * i, len = 3 * icnt[i];
-            const double* row = G + irb[i] + len * kk;
+        if (t < 6 * N) {   // per step: tau_j = sum_e J_e x_e (3), f_j = sum_e x_e (3)
+            const int j = t / 6, comp = t - 6 * j;
             double acc = 0.0;
-            for (int c = 0; c < len; ++c) acc = fma(row[c], sm[S::o_x0c + c], acc);
-            sm[S::o_gx + k] = acc;
+            for (int e = (j ? icnt[j - 1] : 0); e < icnt[j]; ++e) {
+                const double* x = sm + S::o_x0c + 3 * e;
+                if (comp < 3) {
+                    const double* J = sm + S::o_J + j * 36 + comp * 12 + 3 * (act[e] & 3);
+                    acc += J[0] * x[0] + J[1] * x[1] + J[2] * x[2];
+                } else {
+                    acc += x[comp - 3];
+                }
+            }
+            TF[t] = acc;
         }
         __syncthreads();
-        for (int c = t; c < n_eff; c += kThreads) {
-            double acc = a.rs2 * sm[S::o_x0c + c];
-            for (int i = act[c / 3] >> 2; i < N; ++i) {
-                const int len = 3 * icnt[i];
-                const double* col = G + irb[i] + c;
-                for (int kk = 0; kk < 12; ++kk) acc = fma(col[len * kk], sm[S::o_gx + 12 * i + kk], acc);
+        for (int k = t; k < n; k += kThreads) {   // G x^0, row kk of step i
+            const int i = k / 12, kk = k - 12 * i;
+            double acc = 0.0;
+            if (kk < 3) {
+                const double* Ci = CP + i * 9 + kk * 3;
+                for (int j = 0; j <= i; ++j) {
+                    const double* Cj = CP + j * 9 + kk * 3;
+                    const double* tau = TF + 6 * j;
+                    acc += (Ci[0] - Cj[0]) * tau[0] + (Ci[1] - Cj[1]) * tau[1] + (Ci[2] - Cj[2]) * tau[2];
+                }
+                acc *= dt2;
+            } else if (kk < 6) {
+                for (int j = 0; j <= i; ++j) acc += (double)(i - j) * TF[6 * j + kk];
+                acc *= dt2m;
+            } else if (kk < 9) {
+                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
+                acc *= dt;
+            } else {
+                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
+                acc *= dtm;
             }
-            sm[S::o_px0 + c] = acc;
+            sm[S::o_gx + k] = SQ[kk] * a.s * acc;
         }
+        __syncthreads();
+        gt_tables(sm + S::o_gx);
+        __syncthreads();
+        for (int c = t; c < n_eff; c += kThreads) sm[S::o_px0 + c] = gt_eval(c) + a.rs2 * sm[S::o_x0c + c];
     } else {
         for (int c = t; c < n_eff; c += kThreads) sm[S::o_px0 + c] = 0.0;
     }
@@ -484,32 +544,91 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
         ta[s] = (id < NTT) ? id - (bb * (bb + 1)) / 2 : -1;
     }
 
-    // ================= phase H =================
+    // ================= phase H: K = G'G + R s^2 + sigma + A' rho A, entry by entry into the C-layout register tiles ====
     v4d acc[TS];
+    if constexpr (S::STAGE) {
+        // one thread per contact pair (e1 <= e2): 3x3 block = J_e1' M(j, m) J_e2 (27 LDS reads for 9 entries), written
+        // into the row-major 16x16 tiles (upper tiles; both orders inside a diagonal tile), then every wave pulls its
+        // tiles into C-layout registers.  Rows / columns past n_eff are patched to the identity at that load.
+        const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
+        const int npair = (na * (na + 1)) >> 1;
+        for (int pr = t; pr < npair; pr += kThreads) {
+            int e2 = (int)((sqrtf(8.0f * (float)pr + 1.0f) - 1.0f) * 0.5f);
+            e2 += ((e2 + 1) * (e2 + 2) / 2 <= pr) ? 1 : 0;
+            e2 -= (e2 * (e2 + 1) / 2 > pr) ? 1 : 0;
+            const int e1 = pr - e2 * (e2 + 1) / 2;
+            const int g1 = act[e1], g2 = act[e2], j = g1 >> 2, mm = g2 >> 2;
+            const double* J1 = sm + S::o_J + j * 36 + 3 * (g1 & 3);
+            const double* J2 = sm + S::o_J + mm * 36 + 3 * (g2 & 3);
+            const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
+            double Bm[3][3];                                   // M J_e2
 #pragma unroll
-    for (int s = 0; s < TS; ++s) {
-        acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
-        if (ta[s] >= 0) {
-            const int ca = 16 * ta[s] + mcol, cb = 16 * tb[s] + mcol;
-            int i0 = 0;
-            while (i0 < N && 3 * icnt[i0] <= 16 * tb[s]) ++i0;      // first block row that reaches column block b
-            for (int i = i0; i < N; ++i) {
-                const int len = 3 * icnt[i];
-                const double* base = G + irb[i] + len * kq;
+            for (int l = 0; l < 3; ++l)
 #pragma unroll
-                for (int kk0 = 0; kk0 < 12; kk0 += 4) {
-                    const double* row = base + len * kk0;
-                    double av = row[ca], bv = row[cb];
-                    av = (ca < len) ? av : 0.0;
-                    bv = (cb < len) ? bv : 0.0;
-                    acc[s] = mfma_f64(av, bv, acc[s]);
+                for (int c2 = 0; c2 < 3; ++c2) Bm[l][c2] = M[3 * l] * J2[c2] + M[3 * l + 1] * J2[12 + c2] + M[3 * l + 2] * J2[24 + c2];
+            const int Ls = N - mm, d = mm - j;
+            const double sp = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2)), ls = (double)Ls;
+#pragma unroll
+            for (int a1 = 0; a1 < 3; ++a1) {
+                const double j0 = J1[a1], j1 = J1[12 + a1], j2 = J1[24 + a1];
+                const double same = SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls;
+#pragma unroll
+                for (int a2 = 0; a2 < 3; ++a2) {
+                    const int R = 3 * e1 + a1, Cc = 3 * e2 + a2, tr = R >> 4, tc = Cc >> 4;
+                    double v = j0 * Bm[0][a2] + j1 * Bm[1][a2] + j2 * Bm[2][a2];
+                    if (a1 == a2) v += same;
+                    v *= s2;
+                    if (R == Cc) v += a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * a.rho : (4.0 * a.mu * a.mu + 1.0) * a.rho);
+                    if (tr <= tc) T[tile_id(tr, tc) * 256 + (R & 15) * 16 + (Cc & 15)] = v;
+                    if (e1 != e2 && tc <= tr) T[tile_id(tc, tr) * 256 + (Cc & 15) * 16 + (R & 15)] = v;
                 }
             }
-            if (ta[s] == tb[s]) {   // + R s^2 + sigma + A' rho A (stance contacts only: uniform rho); padding -> identity
-                const int var = 16 * ta[s] + mcol;
-                const double dv = (var < n_eff) ? a.rs2 + a.sigma + (((var % 3) < 2) ? 2.0 * a.rho : (4.0 * a.mu * a.mu + 1.0) * a.rho) : 1.0;
+        }
+        __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (kq + 4 * r == mcol) acc[s][r] += dv;
+        for (int s = 0; s < TS; ++s) {
+            acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (ta[s] >= 0) {
+                const double* tl = T + tile_id(ta[s], tb[s]) * 256;
+                const int c = 16 * tb[s] + mcol;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 16 * ta[s] + kq + 4 * q;
+                    const double v = tl[(kq + 4 * q) * 16 + mcol];
+                    acc[s][q] = (r < n_eff && c < n_eff) ? v : ((r == c) ? 1.0 : 0.0);
+                }
+            }
+        }
+    } else {
+        const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (ta[s] >= 0) {
+                const int c = 16 * tb[s] + mcol;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // branch-free (clamped indices, selects) so that the LDS reads of the 12 entries of a thread overlap
+                    const int r = 16 * ta[s] + kq + 4 * q;
+                    const bool in = (r < n_eff) && (c < n_eff);
+                    const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;   // contact order = index order
+                    const int e1 = lo / 3, a1 = lo - 3 * e1, e2 = hi / 3, a2 = hi - 3 * e2;
+                    const int g1 = act[e1], g2 = act[e2], j = g1 >> 2, mm = g2 >> 2;
+                    const double* J1 = sm + S::o_J + j * 36 + 3 * (g1 & 3) + a1;
+                    const double* J2 = sm + S::o_J + mm * 36 + 3 * (g2 & 3) + a2;
+                    const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
+                    const double x0 = J2[0], x1 = J2[12], x2 = J2[24];
+                    double v = J1[0] * (M[0] * x0 + M[1] * x1 + M[2] * x2) + J1[12] * (M[3] * x0 + M[4] * x1 + M[5] * x2) +
+                               J1[24] * (M[6] * x0 + M[7] * x1 + M[8] * x2);
+                    const int Ls = N - mm, d = mm - j;
+                    const int sp = ((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2);
+                    const double same = (a1 == a2) ? 1.0 : 0.0;
+                    v = fma(same, SQ[3 + a1] * SQ[3 + a1] * dt4m2 * (double)sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * (double)Ls, v);
+                    double val = s2 * v;
+                    val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * a.rho : (4.0 * a.mu * a.mu + 1.0) * a.rho) : 0.0;
+                    val = in ? val : ((r == c) ? 1.0 : 0.0);                // padding -> identity
+                    acc[s][q] = val;
+                }
             }
         }
     }
