@@ -1,19 +1,22 @@
-// srbdqp_compact.hpp -- kernel variant v2 ("compact"): v1's fp64-MFMA pipeline on the PRESOLVED QP.
+// srbdqp_compact.hpp -- kernel variant v2 ("compact"): the fp64 pipeline on the PRESOLVED QP, assembled in closed form.
 //
 // Presolve = fixed-variable elimination: a swing contact's force is clamped to zero by its constraint rows, so its
 // 3 variables and 5 rows are dropped before anything dense is built.  With na stance contact points over the
 // horizon the QP has n_eff = 3 na variables and 5 na rows (2-contact single support: n_eff = 6 N instead of 12 N):
-// 4x less Hessian / factor work, a 4x smaller ADMM mat-vec, and (measured on the oracle) a much shorter tail of
+// 4x less factor work, a 4x smaller ADMM mat-vec, and (measured on the oracle) a much shorter tail of
 // slow-converging QPs, because the rho_eq-weighted clamp rows no longer ill-condition K.
 //
 // Template parameter MAXS = bound on stance contact points per horizon step (2 = single support classes,
-// 4 = anything): it sizes LDS (G has at most 3 MAXS (i+1) columns in block row i) and the register tile slots.
-// A QP that violates the bound is reported with status SRBDQP_CONTACT_BOUND, never silently mis-solved.
+// 4 = anything): it sizes LDS and the register tile slots.  A QP that violates the bound is reported with status
+// SRBDQP_CONTACT_BOUND, never silently mis-solved.
 //
 // Compact ordering: stance contacts sorted by (step, contact index) -> e = 0..na-1; variable 3e+ax, row 5e+j.
-// Because the order is by step, G restricted to the compact columns is still block lower triangular and all of
-// v1's machinery (packed G rows, masked MFMA operand reads, register-resident tiled Cholesky, in-place W, K^-1)
-// carries over with run-time tile counts.
+//
+// Assembly: the condensed input matrix G = Q^1/2 s B_qp is never built.  Its blocks have the SRBD structure
+// theta: dt^2 (C_i - C_j) J_j, p: (i-j) dt^2/m I, omega: dt J_j, v: dt/m I (C = prefix sums of R_z'), so K = G'G + ...
+// is J_e' M(j,m) J_e' per contact pair with small per-step-pair tables, and G'v is a suffix sum per step (see phase A
+// in the kernel).  From K on it is v1's machinery with run-time tile counts: register-resident tiled Cholesky with
+// the diagonal tiles inverted on the matrix cores, in-place W = L^-1, K^-1 = W'W.
 #pragma once
 #include "srbdqp_common.hpp"
 #include "srbdqp_admm.hpp"
