@@ -186,6 +186,65 @@ def build_qp(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None):
     return dict(P=P, q=q, A=A, l=l, u=u, A_qp=A_qp, B_qp=B_qp)
 
 
+def closed_form_hessian_gradient(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None):
+    """The assembly the compact HIP kernel uses, restated in NumPy for the tests: P and q of the PRESOLVED QP (stance
+    contacts only, ordered by step then contact index) without ever forming B_qp.
+
+    With T_k = R_z(psi_k)', C_k = sum_{l<=k} T_l and J_j = I_w^-1 [r]x per contact, block (i, j) of B_qp is
+    theta: dt^2 (C_i - C_j) J_j, p: (i-j) dt^2/m I, omega: dt J_j, v: dt/m I (gravity row zero), so for contacts e
+    (step j) and e' (step m >= j)
+        (Bs'Q Bs)[e, e'] = s^2 ( J_e' M(j,m) J_e' + diag(w_p dt^4/m^2 Sp(j,m) + w_v dt^2/m^2 (N-m)) ),
+        M(j,m) = dt^4 (T2(m) + (C_m - C_j)' W_th T1(m)) + (N-m) dt^2 W_om,
+        T1(m) = sum_{i>=m} (C_i - C_m),  T2(m) = sum_{i>=m} (C_i - C_m)' W_th (C_i - C_m),  Sp = sum_{i>=m} (i-j)(i-m),
+    and Bs'Q v is a suffix sum per step followed by one 3-vector product per contact.
+    Returns (P (n_eff, n_eff), q (n_eff,), vi) with vi = indices of the kept variables in the full 12N vector."""
+    x0 = np.asarray(x0, dtype=np.float64).reshape(NX)
+    x_ref = np.asarray(x_ref, dtype=np.float64)
+    N = x_ref.shape[0]
+    foot_hor = np.asarray(foot_hor, dtype=np.float64).reshape(N, NC, 3)
+    contact_hor = np.asarray(contact_hor).reshape(N, NC) != 0
+    pcom = x_ref[:, 3:6] if pcom_hor is None else np.asarray(pcom_hor, dtype=np.float64).reshape(N, 3)
+    dt, s, inv_m = p.dt, p.force_scale, 1.0 / p.mass
+    w = np.asarray(p.q_diag, dtype=np.float64)
+    W_th, W_p, W_om, W_v = np.diag(w[0:3]), w[3:6], np.diag(w[6:9]), w[9:12]
+    T = [rot_z(float(x_ref[k, 2])).T for k in range(N)]
+    C = np.cumsum(np.array(T), axis=0)
+    Ib_inv = np.diag(1.0 / np.asarray(p.inertia, dtype=np.float64))
+    contacts = [(k, i) for k in range(N) for i in range(NC) if contact_hor[k, i]]
+    J = []
+    for k, i in contacts:
+        Rz = T[k].T
+        J.append(Rz @ Ib_inv @ Rz.T @ skew(foot_hor[k, i] - pcom[k]))
+    T1 = [sum((C[i] - C[m] for i in range(m, N)), np.zeros((3, 3))) for m in range(N)]
+    T2 = [sum(((C[i] - C[m]).T @ W_th @ (C[i] - C[m]) for i in range(m, N)), np.zeros((3, 3))) for m in range(N)]
+    na = len(contacts)
+    P = np.zeros((3 * na, 3 * na))
+    for e in range(na):
+        for e2 in range(e, na):
+            j, m = contacts[e][0], contacts[e2][0]
+            M = dt ** 4 * (T2[m] + (C[m] - C[j]).T @ W_th @ T1[m]) + (N - m) * dt ** 2 * W_om
+            sp = sum((i - j) * (i - m) for i in range(m, N))
+            blk = J[e].T @ M @ J[e2] + np.diag(W_p * dt ** 4 * inv_m ** 2 * sp + W_v * dt ** 2 * inv_m ** 2 * (N - m))
+            P[3 * e:3 * e + 3, 3 * e2:3 * e2 + 3] = s * s * blk
+            P[3 * e2:3 * e2 + 3, 3 * e:3 * e + 3] = s * s * blk.T
+    P += p.r_diag * s * s * np.eye(3 * na)
+    # gradient: e_i = Q (free response - x_ref) per step, then the suffix sums
+    xf = x0.copy()
+    err = np.zeros((N, 12))
+    Ak = [linearise(p, float(x_ref[k, 2]), np.zeros((NC, 3)))[0] for k in range(N)]
+    for i in range(N):
+        xf = Ak[i] @ xf
+        err[i] = w[:12] * (xf[:12] - x_ref[i, :12])
+    q = np.zeros(3 * na)
+    for e, (j, _) in enumerate(contacts):
+        g = sum((dt ** 2 * (C[i] - C[j]).T @ err[i, 0:3] + dt * err[i, 6:9] for i in range(j, N)), np.zeros(3))
+        hp = sum(((i - j) * err[i, 3:6] for i in range(j, N)), np.zeros(3))
+        hv = sum((err[i, 9:12] for i in range(j, N)), np.zeros(3))
+        q[3 * e:3 * e + 3] = s * (J[e].T @ g + dt ** 2 * inv_m * hp + dt * inv_m * hv)
+    vi = np.array([NU * k + 3 * i + a for k, i in contacts for a in range(3)], dtype=int)
+    return P, q, vi
+
+
 def rho_vector(p: SrbdParams, l, u):
     """Per-row ADMM penalty: rho for inequalities, rho*rho_eq_scale for equalities (OSQP's rule)."""
     rho = np.full(l.shape, p.rho)

@@ -173,3 +173,18 @@ def test_flight_phase_and_status_codes():
     assert abs(r["x"][10, 11] - (x0[11] + 10 * p.dt * x0[12])) < 1e-12          # free fall: v_z += N dt g
     r = orc.update(orc.SrbdParams(max_iter=5), x0, xr, ft, ct)
     assert r["status"] == orc.STATUS_MAX_ITER and r["iters"] == 5
+
+
+@pytest.mark.parametrize("N,schedule,seed", [(10, "single", 11), (10, "double", 12), (8, "mixed", 13), (16, "single", 14)])
+def test_closed_form_assembly_equals_the_dense_products(N, schedule, seed):
+    """The compact kernel never forms B_qp: K and the gradient come from the SRBD block structure (per-step suffix
+    tables + one 3x3 product per contact pair).  Its NumPy restatement must reproduce the dense Bs'Q Bs and Bs'Q e of
+    build_qp() on the presolved variables."""
+    p = orc.SrbdParams()
+    x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed, schedule))
+    qp = orc.build_qp(p, x0, xr, ft, ct)
+    red, vi, ri = orc.presolve(qp, ct)
+    P, q, vi2 = orc.closed_form_hessian_gradient(p, x0, xr, ft, ct)
+    np.testing.assert_array_equal(vi, vi2)
+    assert np.abs(P - red["P"]).max() <= 1e-12 * np.abs(red["P"]).max()
+    assert np.abs(q - red["q"]).max() <= 1e-12 * max(1.0, np.abs(red["q"]).max())
