@@ -8,7 +8,7 @@ import torch
 from g1_locomotion_amd import BatchMPC
 import srbd_oracle as orc
 
-names = ["linearise", "build_G", "gradient", "H(mfma)", "barrier", "F(chol)", "W", "I", "frag", "ADMM", "rollout"]
+names = ["linearise", "tables", "gradient", "K assembly", "barrier", "F(chol)", "W", "I", "frag", "ADMM", "rollout"]
 for B in (1, 4096):
     x0, xr, ft, ct = orc.synthetic_batch(B, 10, 2000, "single")
     dev = torch.device("cuda", 0)
