@@ -36,7 +36,16 @@ struct srbdqp_handle {
     const int32_t* sched_hint = nullptr;   // device: previous step's iters[] (srbdqp_set_schedule_hint)
     // per-launch-stream device scratch (a caller may pipeline solves of one handle over several streams: each stream
     // needs its own dispatch order and its own split-pipeline hand-over workspace)
-    struct StreamSlot { hipStream_t st = nullptr; bool used = false; int32_t* perm = nullptr; size_t perm_cap = 0; double* ws = nullptr; size_t ws_doubles = 0; };
+    struct StreamSlot {
+        hipStream_t st = nullptr; bool used = false;
+        int32_t* perm = nullptr; size_t perm_cap = 0;
+        double* ws = nullptr; size_t ws_doubles = 0;
+        // rho restart: fp32 maxima of the capped QPs, their list + count, their new rho, and y / status when the caller
+        // passes none (the second pass warm-starts from the first pass's outputs)
+        char* rs = nullptr; size_t rs_items = 0, rs_rows = 0;
+        float* resid = nullptr; int32_t* list = nullptr; int32_t* count = nullptr; double* rho = nullptr; double* ybuf = nullptr;
+        int32_t* stbuf = nullptr;
+    };
     static constexpr int kMaxSlots = 8;
     StreamSlot slots[kMaxSlots];
     // low-latency staging: one pinned, GPU-mapped slab carved into the arrays of srbdqp_stage
@@ -50,6 +59,8 @@ struct srbdqp_handle {
     int32_t* done_count = nullptr;
     int32_t done_seq = 0;
     bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
+    bool lazy_restart = false;     // staged path: run only the first pass; the host starts the second one if a status asks for it
+    KArgs last_args;               // arguments of that first pass (for the lazily started second pass)
 };
 
 // slot of a launch stream (at most kMaxSlots distinct streams per handle; null when exhausted)
@@ -143,7 +154,7 @@ constexpr int kSplitMinBatch = 512;
 template <int N, int MAXS>
 int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     using W = srbdqp::SplitWs<N, MAXS>;
-    const size_t need = (size_t)a.B * W::doubles;
+    const size_t need = (size_t)(a.qp_span > a.B ? a.qp_span : a.B) * W::doubles;   // indexed by QP, not by workgroup
     auto* slot = stream_slot(h, st);
     if (!slot) return SRBDQP_E_INVALID;
     if (need > slot->ws_doubles) {
@@ -161,7 +172,7 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     static const std::string nm = "split_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
     hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), ldsA, st, a);
-    if (h->cfg.flags & SRBDQP_FLAG_TIMING) { HIP_TRY(h, hipEventRecord(h->ev_mid, st)); h->ev_mid_valid = true; }
+    if ((h->cfg.flags & SRBDQP_FLAG_TIMING) && !a.count_ptr) { HIP_TRY(h, hipEventRecord(h->ev_mid, st)); h->ev_mid_valid = true; }
     hipLaunchKernelGGL((srbdqp::srbdqp_admm_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), ldsB, st, a);
     return SRBDQP_OK;
 }
@@ -221,11 +232,12 @@ int launch_long(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
     return SRBDQP_OK;
 }
 
-int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4) {
+// pass: 0 = the only launch of a solve, 1 = first of two (restart follows), 2 = second of two
+int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4, int pass = 0) {
     if (a.B <= 0) return SRBDQP_OK;
     const int variant = (a.mode == 1) ? SRBDQP_KERNEL_GJ : resolve_kernel(h->cfg);
     const bool timing = (h->cfg.flags & SRBDQP_FLAG_TIMING) != 0;
-    if (timing) { HIP_TRY(h, hipEventRecord(h->ev0, st)); h->ev_mid_valid = false; }
+    if (timing && pass != 2) { HIP_TRY(h, hipEventRecord(h->ev0, st)); h->ev_mid_valid = false; }
     int rc;
     switch (h->cfg.horizon) {
         case 4: rc = launch_n<4>(h, a, st, variant, maxs); break;
@@ -237,7 +249,7 @@ int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4) {
         default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
     }
     if (rc != SRBDQP_OK) return rc;
-    if (timing) {
+    if (timing && pass != 1) {
         HIP_TRY(h, hipEventRecord(h->ev1, st));
         h->ev_valid = true;
     }
@@ -263,6 +275,78 @@ struct Carver {
         return p;
     }
 };
+
+// Restart selection: the QPs whose first pass ended at its cap (status 2), their new rho from the fp32 maxima of their
+// last check (OSQP's rule, oracle restart_rho()).  One workgroup; the order of the list is arbitrary, every QP's
+// result is independent of it.
+__global__ __launch_bounds__(1024) void srbdqp_restart_select_kernel(const int32_t* status, const float* resid, int B, double rho0,
+                                                                     int32_t* list, int32_t* count, double* rho_qp, int cap) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 1024) {
+        if (status[i] != SRBDQP_MAX_ITER) continue;
+        const int pos = atomicAdd(&cnt, 1);
+        if (pos >= cap) continue;
+        list[pos] = i;
+        const float* r = resid + (size_t)i * 4;
+        const double num = (double)r[0] / fmax((double)r[1], 1e-30), den = (double)r[2] / fmax((double)r[3], 1e-30);
+        double r1 = rho0;
+        if (num > 0.0 && den > 0.0 && num <= 1.0e30 && den <= 1.0e30) r1 = fmin(fmax(rho0 * sqrt(num / den), rho0 * 0.1), rho0 * 10.0);
+        rho_qp[i] = r1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *count = cnt < cap ? cnt : cap;
+}
+
+inline int restart_iter_of(const srbdqp_config& c) {
+    const bool family = resolve_kernel(c) == SRBDQP_KERNEL_COMPACT;   // AUTO, COMPACT and SPLIT
+    return (family && c.rho_restart_iter > 0 && c.rho_restart_iter < c.max_iter) ? c.rho_restart_iter : 0;
+}
+
+// per-stream restart buffers for batches of up to B QPs with m rows
+int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, size_t m) {
+    if (slot->rs && slot->rs_items >= B && slot->rs_rows >= m) return SRBDQP_OK;
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if (slot->rs) { HIP_TRY(h, hipFree(slot->rs)); slot->rs = nullptr; }
+    auto carve = [&](Carver& c) {
+        slot->resid = c.take<float>(B * 4); slot->list = c.take<int32_t>(B); slot->count = c.take<int32_t>(16);
+        slot->rho = c.take<double>(B); slot->ybuf = c.take<double>(B * m); slot->stbuf = c.take<int32_t>(B);
+    };
+    Carver sz(nullptr);
+    carve(sz);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&slot->rs), sz.off);
+    if (e != hipSuccess) { h->err = std::string("hipMalloc restart buffers: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
+    Carver cv(slot->rs);
+    carve(cv);
+    slot->rs_items = B; slot->rs_rows = m;
+    return SRBDQP_OK;
+}
+
+// second pass of a two-pass solve: select the capped QPs, then re-run them with their own rho from their own (x, y).
+// a1 = the arguments of the first pass (status / y_out / resid_out set).
+int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int maxs, bool signal) {
+    auto* slot = stream_slot(h, st);
+    if (!slot) return SRBDQP_E_INVALID;
+    const int B = a1.B;
+    const int grid2 = (B <= 64) ? B : ((B / 4 > 64) ? B / 4 : 64);
+    hipLaunchKernelGGL(srbdqp_restart_select_kernel, dim3(1), dim3(1024), 0, st, a1.status, slot->resid, B, h->cfg.rho,
+                       slot->list, slot->count, slot->rho, grid2);
+    KArgs a2 = a1;
+    a2.perm = slot->list;
+    a2.count_ptr = slot->count;
+    a2.rho_qp = slot->rho;
+    a2.warm_u = a1.u_out;                                   // newtons, as a caller's warm start would be
+    a2.warm_y = a1.y_out;
+    a2.max_iter = h->cfg.max_iter;
+    a2.iters_base = a1.max_iter;
+    a2.resid_out = nullptr;
+    a2.qp_span = B;
+    a2.B = grid2;
+    if (signal) { a2.done_flag = h->done_dev; a2.done_count = h->done_count; a2.done_value = h->done_seq; }
+    else { a2.done_flag = nullptr; a2.done_count = nullptr; }
+    return launch(h, a2, st, maxs, 2);
+}
 
 }  // namespace
 
@@ -291,6 +375,7 @@ int srbdqp_default_config(srbdqp_config* c) {
     c->force_scale = 100.0;
     c->rho = 1.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
     c->eps_abs = 1.0e-6; c->eps_rel = 1.0e-6;
+    c->rho_restart_iter = 0; c->reserved0 = 0;
     return SRBDQP_OK;
 }
 
@@ -301,7 +386,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10}; {12, 16, 20} with max_contacts_per_step <= 2)"; return SRBDQP_E_INVALID; }
     if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons 12, 16 and 20 exist only for the compact kernel"; return SRBDQP_E_INVALID; }
     if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) ||
-        cfg->max_iter < 1 || cfg->check_every < 1 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
+        cfg->max_iter < 1 || cfg->check_every < 1 || cfg->rho_restart_iter < 0 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -363,7 +448,7 @@ int srbdqp_destroy(srbdqp_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
-    for (auto& sl : h->slots) { if (sl.perm) (void)hipFree(sl.perm); if (sl.ws) (void)hipFree(sl.ws); }
+    for (auto& sl : h->slots) { if (sl.perm) (void)hipFree(sl.perm); if (sl.ws) (void)hipFree(sl.ws); if (sl.rs) (void)hipFree(sl.rs); }
     if (h->done_count) (void)hipFree(h->done_count);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -401,28 +486,46 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     // completion: the compact kernel publishes a sequence number in host memory after its outputs (signal_done());
     // spinning on it skips the stream's completion interrupt (~15 us).  Other kernel variants: stream synchronise.
     const bool spin = resolve_kernel(h->cfg) == SRBDQP_KERNEL_COMPACT && !(h->cfg.flags & SRBDQP_FLAG_NO_SPIN);
+    auto wait_done = [&]() -> int {
+        if (spin) {
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned polls = 0;
+            while (*h->done_host != h->done_seq) {
+                if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    // slow or failed launch: hand over to the runtime (reports a fault, or returns once the kernel is done)
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return SRBDQP_OK;
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return SRBDQP_OK;
+    };
     if (spin) { h->done_seq = (h->done_seq == INT32_MAX) ? 1 : h->done_seq + 1; h->signal_next = true; }
+    const int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
+    h->lazy_restart = true;                                 // the rho restart costs two more launches: only when needed
     int rc = srbdqp_solve_batch_device_f64(h, B, d.x0, d.x_ref, d.foot, d.contact, use_pcom ? d.pcom : nullptr,
                                            use_warm ? d.warm_u : nullptr, use_warm ? d.warm_y : nullptr, d.u,
                                            want_x ? d.x : nullptr, want_y ? d.y : nullptr, d.status, d.iters, h->stream);
+    h->lazy_restart = false;
     h->maxs_override = 0;
     h->signal_next = false;
     if (rc != SRBDQP_OK) return rc;
-    if (spin) {
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned polls = 0;
-        while (*h->done_host != h->done_seq) {
-            if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
-                // slow or failed launch: hand over to the runtime (reports a fault, or returns once the kernel is done)
-                HIP_TRY(h, hipStreamSynchronize(h->stream));
-                break;
-            }
+    rc = wait_done();
+    if (rc != SRBDQP_OK) return rc;
+    if (restart_iter_of(h->cfg) && !h->stamps) {
+        bool capped = false;
+        for (int32_t q = 0; q < B; ++q) capped |= (h->stage_h.status[q] == SRBDQP_MAX_ITER);
+        if (capped) {
+            if (spin) h->done_seq = (h->done_seq == INT32_MAX) ? 1 : h->done_seq + 1;
+            rc = srbdqp_restart_pass(h, h->last_args, h->stream, maxs, spin);
+            if (rc != SRBDQP_OK) return rc;
+            rc = wait_done();
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        return SRBDQP_OK;
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return SRBDQP_OK;
+    return rc;
 }
 
 int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev) {
@@ -492,7 +595,26 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
         a.perm = slot->perm;
     }
     int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
-    return launch(h, a, lst, maxs);
+    const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h->cfg);
+    if (!restart) return launch(h, a, lst, maxs);
+
+    // ---- two passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those
+    auto* slot = stream_slot(h, lst);
+    if (!slot) return SRBDQP_E_INVALID;
+    const size_t m = 20 * (size_t)h->cfg.horizon;
+    int rc = ensure_restart_buffers(h, slot, lst, (size_t)B, m);
+    if (rc != SRBDQP_OK) return rc;
+    const bool lazy = h->lazy_restart;                      // staged path: the host looks at status[] before a second pass
+    KArgs a1 = a;
+    a1.max_iter = restart;
+    a1.resid_out = slot->resid;
+    if (!a1.y_out) a1.y_out = slot->ybuf;
+    if (!a1.status) a1.status = slot->stbuf;
+    if (!lazy) { a1.done_flag = nullptr; a1.done_count = nullptr; }
+    rc = launch(h, a1, lst, maxs, lazy ? 0 : 1);
+    if (lazy) h->last_args = a1;
+    if (rc != SRBDQP_OK || lazy) return rc;
+    return srbdqp_restart_pass(h, a1, lst, maxs, a.done_flag != nullptr);
 }
 
 int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,

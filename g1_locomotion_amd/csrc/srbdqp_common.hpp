@@ -37,6 +37,13 @@ struct KArgs {
     const int32_t* perm;     // optional dispatch order: workgroup i solves QP perm[i] (longest-first scheduling), or null
     long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null
     double* ws;              // split mode: per-QP workspace between the set-up kernel and the ADMM kernel, or null
+    // rho re-balancing (one OSQP-style restart of the QPs that reach the cap of the first pass, see srbdqp.hip)
+    const double* rho_qp;    // second pass: rho of QP b, or null (= rho)
+    float* resid_out;        // first pass: [B][4] fp32 maxima (r_prim, n_prim, r_dual, n_dual) of the last check of a QP
+                             //   that ends at the cap, or null
+    const int32_t* count_ptr;   // second pass: number of valid entries of perm[]; workgroups beyond it exit at once
+    int32_t iters_base;      // second pass: iterations of the first pass, added to iters[] on output
+    int32_t qp_span;         // host only: number of QP slots the per-QP workspaces must hold (second pass: original B)
     int32_t* done_flag;      // low-latency completion: GPU-mapped host word that receives done_value once every QP of the
     int32_t* done_count;     //   launch has stored its outputs (done_count: device counter of finished workgroups), or null
     int32_t done_value;

@@ -112,7 +112,7 @@ template <int LPR> __device__ __forceinline__ int admm_contacts_per_wave(int na)
 // is read at the top of the next iteration (no extra barrier, no extra iteration).
 template <int N, class L, int CHMAX>
 __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsbuf, double* xs_full,
-                                 const double (&kin)[CHMAX], int na, int CH, const uint8_t* act, int* status_out) {
+                                 const double (&kin)[CHMAX], int na, int CH, const uint8_t* act, double rho_b, int* status_out) {
     using S = L;
     constexpr int n = Dims<N>::n, m = Dims<N>::m;
     constexpr int LPR = S::LPR;
@@ -134,7 +134,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu;
     float* redf = reinterpret_cast<float*>(sm + S::o_red);
     const double lo = (j < 4) ? -kInf : a.fzmin_s, hi = (j < 4) ? 0.0 : a.fzmax_s;
-    const double rho = a.rho, irho = 1.0 / rho;
+    const double rho = rho_b, irho = 1.0 / rho;
     const double sgn = (j < 4 && h == 1) ? -1.0 : 1.0;
     const double muc = (j < 4) ? mu : 0.0;
     const double rowm = has_row ? 1.0 : 0.0;
@@ -180,6 +180,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     int* vflag = reinterpret_cast<int*>(redf + 32);     // [4] per-wave 'some row fails the pre-test' flags
     bool vote_ok = true;
     int ph = 0;
+    float lastv0 = 0.0f, lastv1 = 0.0f, lastv2 = 0.0f, lastv3 = 0.0f;   // maxima of the last full check (restart rule)
     for (int k = 1; k <= a.max_iter + 1; ++k) {
         if (pending) {   // decision of the check made at iteration k - 1 (its maxima rode on that iteration's barrier)
             const float* buf = redf + ((nchk - 1) & 1) * 16;
@@ -189,6 +190,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
             const double e_prim = a.eps_abs + a.eps_rel * v[1];
             const double e_dual = a.eps_abs + a.eps_rel * fmax(v[3], (double)(float)qn[0]);
             e_prim_last = e_prim;
+            lastv0 = (float)v[0]; lastv1 = (float)v[1]; lastv2 = (float)v[2]; lastv3 = (float)fmax(v[3], (double)(float)qn[0]);
             if (!(v[0] <= kInf) || !(v[2] <= kInf)) { status = -1; iters = k - 1; break; }
             if (v[0] <= e_prim && v[2] <= e_dual) { status = 1; iters = k - 1; break; }
             pending = false;
@@ -282,6 +284,10 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
 #endif
     if (active && hp == 0) xs_full[3 * gc + ax] = x;
     if (a.y_out && has_row) a.y_out[(size_t)b * m + irow] = y;
+    if (a.resid_out && status == 2 && t == 0) {
+        float* ro = a.resid_out + (size_t)b * 4;
+        ro[0] = lastv0; ro[1] = lastv1; ro[2] = lastv2; ro[3] = lastv3;
+    }
     __syncthreads();
     *status_out = status;
     return iters;
@@ -310,7 +316,12 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     static_assert(4 * N <= 128, "the presolve compacts the 4N contact flags with at most two wave-wide ballots");
     static_assert((S::o_R % 2) == 0 && (S::o_rhs % 2) == 0, "16-byte alignment");
     if ((int)blockIdx.x >= a.B) return;
+    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) {   // restart pass: nothing listed for this workgroup
+        signal_done(a);
+        return;
+    }
     const int b = SRBDQP_QP_INDEX(a);
+    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     int mcol = lane & 15, kq = lane >> 4;                   // re-laundered per phase, see SRBDQP_PHASE_LOCAL
@@ -581,7 +592,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
                     double v = j0 * Bm[0][a2] + j1 * Bm[1][a2] + j2 * Bm[2][a2];
                     if (a1 == a2) v += same;
                     v *= s2;
-                    if (R == Cc) v += a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * a.rho : (4.0 * a.mu * a.mu + 1.0) * a.rho);
+                    if (R == Cc) v += a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b);
                     if (tr <= tc) T[tile_id(tr, tc) * 256 + (R & 15) * 16 + (Cc & 15)] = v;
                     if (e1 != e2 && tc <= tr) T[tile_id(tc, tr) * 256 + (Cc & 15) * 16 + (R & 15)] = v;
                 }
@@ -628,7 +639,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
                     const double same = (a1 == a2) ? 1.0 : 0.0;
                     v = fma(same, SQ[3 + a1] * SQ[3 + a1] * dt4m2 * (double)sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * (double)Ls, v);
                     double val = s2 * v;
-                    val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * a.rho : (4.0 * a.mu * a.mu + 1.0) * a.rho) : 0.0;
+                    val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b) : 0.0;
                     val = in ? val : ((r == c) ? 1.0 : 0.0);                // padding -> identity
                     acc[s][q] = val;
                 }
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
 
     SRBDQP_STAMP(a, b, 9);
     int status = -1, iters = 0;
-    if (!failed) iters = admm_loop_compact<N, S, CHMAX>(a, b, sm, sm + S::o_rhs, sm + S::o_xs, kin, na, CH, act, &status);
+    if (!failed) iters = admm_loop_compact<N, S, CHMAX>(a, b, sm, sm + S::o_rhs, sm + S::o_xs, kin, na, CH, act, rho_b, &status);
     else {
         for (int c = t; c < n; c += kThreads) sm[S::o_xs + c] = 0.0;
         __syncthreads();
@@ -833,7 +844,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     }
     if (t == 0) {
         if (a.status) a.status[b] = status;
-        if (a.iters) a.iters[b] = iters;
+        if (a.iters) a.iters[b] = iters + a.iters_base;
     }
     SRBDQP_STAMP(a, b, 10);
     rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);

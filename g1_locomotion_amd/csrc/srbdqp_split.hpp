@@ -35,7 +35,9 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
     constexpr int n = Dims<N>::n, m = Dims<N>::m, KS = W::KS;
     static_assert(W::supported, "one K^-1 row per lane of one wave");
     if ((int)blockIdx.x >= a.B) return;
+    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) return;   // restart pass: nothing listed for this workgroup
     const int b = SRBDQP_QP_INDEX(a);
+    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
     const int lane = threadIdx.x;
     const double* ws = a.ws + (size_t)b * W::doubles;
     if (ws[S::o_misc + 1] != 0.0) return;                  // finished by the set-up kernel (no stance contact / bound)
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
     const int base = 3 * cg;
     const int gc = active ? act[cg] : 0;
     const bool rowA = active, rowB = active && ax < 2;
-    const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu, irho = 1.0 / a.rho;
-    const double rhoA = rowA ? a.rho : 0.0, rhoB = rowB ? a.rho : 0.0;      // rho = 0 freezes a slot at y = z = 0
+    const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu, irho = 1.0 / rho_b;
+    const double rhoA = rowA ? rho_b : 0.0, rhoB = rowB ? rho_b : 0.0;      // rho = 0 freezes a slot at y = z = 0
     const double loA = !rowA ? 0.0 : (ax < 2 ? -kInf : a.fzmin_s), hiA = !rowA ? 0.0 : (ax < 2 ? 0.0 : a.fzmax_s);
     const double loB = rowB ? -kInf : 0.0, hiB = 0.0;
     const double mucA = (ax < 2) ? mu : 0.0;
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
         double e_prim_last = kInf * 1.0e10;
         bool vote_ok = true;
         int ph = 0;
+        float lastv0 = 0.0f, lastv1 = 0.0f, lastv2 = 0.0f, lastv3 = 0.0f;   // maxima of the last full check (restart rule)
         for (int k = 1; k <= a.max_iter; ++k) {
             if (++ph == a.check_every) ph = 0;
             const bool at_mark = (ph == 0);
@@ -162,9 +165,14 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
                 const double e_prim = a.eps_abs + a.eps_rel * (double)m1;
                 const double e_dual = a.eps_abs + a.eps_rel * fmax((double)m3, (double)qnf);
                 e_prim_last = e_prim;
+                lastv0 = m0; lastv1 = m1; lastv2 = m2; lastv3 = fmaxf(m3, qnf);
                 if (!((double)m0 <= kInf) || !((double)m2 <= kInf)) { status = -1; iters = k; break; }
                 if ((double)m0 <= e_prim && (double)m2 <= e_dual) { status = 1; iters = k; break; }
             }
+        }
+        if (a.resid_out && status == 2 && lane == 0) {
+            float* ro = a.resid_out + (size_t)b * 4;
+            ro[0] = lastv0; ro[1] = lastv1; ro[2] = lastv2; ro[3] = lastv3;
         }
         if (active) xs_full[3 * gc + ax] = x;
         if (a.y_out) {
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
     }
     if (lane == 0) {
         if (a.status) a.status[b] = status;
-        if (a.iters) a.iters[b] = iters;
+        if (a.iters) a.iters[b] = iters + a.iters_base;
     }
     rollout_and_store<N, S, 64>(a, b, sm, xs_full, sm + L::o_scr);
 }

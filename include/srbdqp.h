@@ -73,6 +73,12 @@ typedef struct srbdqp_config {
     int32_t max_contacts_per_step; /* bound on stance contact points per horizon step: 1..4; 0 = decide per call
                                     * (host-buffer API scans the contact flags, device API assumes 4).  A bound of
                                     * <= 2 selects the smaller, higher-occupancy kernel instantiation. */
+    int32_t rho_restart_iter;     /* one OSQP-style re-balancing of rho: a QP that has not converged after this many
+                                   * iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual))
+                                   * (clipped to [rho/10, 10 rho]) and continues from its own (x, y) for up to max_iter
+                                   * more iterations; iters[] counts both passes.  0 (default) or >= max_iter = off.  Compact and
+                                   * split kernels only.  Per device-API launch at most max(64, B/4) QPs are restarted. */
+    int32_t reserved0;
     double dt;                    /* run_simulation.py:169 */
     double mass;                  /* wbid.py:291 model.getMass() */
     double inertia[3];            /* wbid.py:261-266 torso inertia diagonal */

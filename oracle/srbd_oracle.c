@@ -30,6 +30,7 @@ typedef struct {
     double q_diag[NX], r_diag, force_scale;
     double rho, rho_eq_scale, sigma, alpha, eps_abs, eps_rel;
     int max_iter, check_every;
+    int rho_restart_iter;  /* presolved path: one OSQP-style re-balancing of rho after this many iterations (0 = off) */
     int eliminate_swing;   /* presolve: drop the variables/rows of swing contacts (kernel v2); 0 = clamp via bounds */
 } srbd_oracle_params;
 
@@ -176,12 +177,17 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
     }
     /* a9: K (compact), Cholesky, inverse */
 #define VIDX(v) (3 * cmap[(v) / 3] + (v) % 3)       /* compact variable -> original variable */
-    for (int i = 0; i < nr; ++i) for (int j = 0; j < nr; ++j) K[(size_t)i * nr + j] = P[(size_t)VIDX(i) * n + VIDX(j)];
     for (int i = 0; i < nr; ++i) tmpn[i] = q[VIDX(i)];   /* compact gradient */
     double* qc = tmpn; double* tmp2 = Atw;               /* note: Atw is reused below only after qc is copied */
     (void)tmp2;
     double* qcv = e;                                     /* e[] (length s >= nr) is free now: keep the compact q there */
     for (int i = 0; i < nr; ++i) qcv[i] = qc[i];
+    double qn = 0.0, e_prim_last = INFINITY, last_rp = 0, last_np = 0, last_rd = 0, last_nd = 0;
+    int status = 2, iters = 0, vote_ok = 1, iters_base = 0;
+    const int restart = (p->eliminate_swing && p->rho_restart_iter > 0 && p->rho_restart_iter < p->max_iter) ? p->rho_restart_iter : 0;
+    for (int pass = 0; pass < 2; ++pass) {
+    const int cap = (pass == 0 && restart) ? restart : p->max_iter;
+    for (int i = 0; i < nr; ++i) for (int j = 0; j < nr; ++j) K[(size_t)i * nr + j] = P[(size_t)VIDX(i) * n + VIDX(j)];
     for (int e_ = 0; e_ < nc; ++e_) {
         const int r0 = 5 * e_, c0 = 3 * e_;
         K[(size_t)(c0) * nr + c0] += p->sigma + rho[r0] + rho[r0 + 1];
@@ -230,16 +236,25 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
         po[0] = pw[0] - pw[1]; po[1] = pw[2] - pw[3];                                              \
         po[2] = -mu * (pw[0] + pw[1] + pw[2] + pw[3]) + pw[4];                                     \
     }
-    memset(x, 0, sizeof(double) * n);
-    memset(y, 0, sizeof(double) * m);
-    memset(Px, 0, sizeof(double) * n);
-    for (int i = 0; i < mr; ++i) { z[i] = fmin(fmax(0.0, lo[i]), hi[i]); }
-    double qn = 0.0;
+    if (pass == 0) {
+        memset(x, 0, sizeof(double) * n);
+        memset(y, 0, sizeof(double) * m);
+        memset(Px, 0, sizeof(double) * n);
+    } else {   /* continue from the first pass: x re-read in newtons, P x and z recomputed, y kept */
+        for (int i = 0; i < nr; ++i) x[i] = (sc * x[i]) / sc;
+        for (int i = 0; i < nr; ++i) {
+            double v = 0.0;
+            for (int j = 0; j < nr; ++j) v += P[(size_t)VIDX(i) * n + VIDX(j)] * x[j];
+            Px[i] = v;
+        }
+    }
+    for (int i = 0; i < mr; ++i) { const double* v = x + 3 * (i / 5); z[i] = fmin(fmax(A_ROW(v, i % 5), lo[i]), hi[i]); }
+    qn = 0.0;
     for (int i = 0; i < nr; ++i) qn = fmax(qn, fabs(qcv[i]));
-    int status = 2, iters = p->max_iter, vote_ok = 1;
-    double e_prim_last = INFINITY;
+    status = 2; iters = cap; vote_ok = 1;
+    e_prim_last = INFINITY;
     if (nr == 0) { status = 1; iters = 0; }
-    for (int k = 1; k <= p->max_iter && nr > 0; ++k) {
+    for (int k = 1; k <= cap && nr > 0; ++k) {
         for (int i = 0; i < mr; ++i) wv[i] = rho[i] * z[i] - y[i];
         AT_APPLY(Atw, wv);
         for (int i = 0; i < nr; ++i) rhs[i] = p->sigma * x[i] - qcv[i] + Atw[i];
@@ -275,7 +290,7 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
             }
             vote_ok = (rpm <= e_prim_last);
         }
-        if ((k % p->check_every == 0 && vote_ok) || k == p->max_iter) {
+        if ((k % p->check_every == 0 && vote_ok) || k == cap) {
             double rp = 0, rd = 0, nax = 0, nz = 0, npx = 0, naty = 0;
             for (int i = 0; i < mr; ++i) {
                 const double* v = x + 3 * (i / 5);
@@ -294,9 +309,20 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
             const double ep = p->eps_abs + p->eps_rel * (double)(float)fmax(nax, nz);
             e_prim_last = ep;
             const double ed = p->eps_abs + p->eps_rel * fmax((double)(float)fmax(npx, naty), (double)(float)qn);
+            last_rp = rp; last_np = (double)(float)fmax(nax, nz); last_rd = rd; last_nd = fmax((double)(float)fmax(npx, naty), (double)(float)qn);
             if (rp <= ep && rd <= ed) { status = 1; iters = k; break; }
         }
     }
+    if (!(pass == 0 && restart && status == 2)) break;
+    {   /* OSQP's re-balancing from the fp32 maxima of the last check (srbd_oracle.py restart_rho) */
+        const double num = last_rp / fmax(last_np, 1e-30), den = last_rd / fmax(last_nd, 1e-30);
+        double r1 = p->rho;
+        if (num > 0.0 && den > 0.0 && num <= INF && den <= INF) r1 = fmin(fmax(p->rho * sqrt(num / den), p->rho * 0.1), p->rho * 10.0);
+        for (int i = 0; i < mr; ++i) rho[i] = r1;
+        iters_base = restart;
+    }
+    }   /* pass */
+    iters += iters_base;
     /* expand the compact solution (x is compact here) into the full variable vector */
     for (int i = 0; i < n; ++i) rhs[i] = 0.0;
     for (int i = 0; i < nr; ++i) rhs[VIDX(i)] = x[i];

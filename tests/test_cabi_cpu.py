@@ -37,7 +37,7 @@ def test_config_struct_and_defaults_match_the_oracle(built_lib):
     cfg = _lib.default_config()
     assert cfg.struct_size == C.sizeof(_lib.Config)
     p = orc.SrbdParams()
-    assert cfg.horizon == 10 and cfg.max_iter == p.max_iter and cfg.check_every == p.check_every
+    assert cfg.horizon == 10 and cfg.max_iter == p.max_iter and cfg.check_every == p.check_every and cfg.rho_restart_iter == p.rho_restart_iter
     for k in ("dt", "mass", "mu", "fz_min", "fz_max", "r_diag", "force_scale", "rho", "rho_eq_scale", "sigma", "alpha", "eps_abs", "eps_rel"):
         assert getattr(cfg, k) == getattr(p, k), k
     assert tuple(cfg.inertia) == tuple(p.inertia) and tuple(cfg.q_diag) == tuple(p.q_diag)

@@ -296,3 +296,51 @@ def test_two_streams_pipeline_distinct_batches_through_one_handle(torch_first, b
         eng.set_schedule_hint(0)
     for i, (u, it, st) in outs:
         assert torch.equal(u, alone[i][0]) and torch.equal(it, alone[i][1]) and torch.equal(st, alone[i][2]), i
+
+
+@pytest.mark.parametrize("kernel", ["compact", "split"])
+def test_rho_restart_matches_the_oracle(torch_first, built_lib, kernel):
+    """rho_restart_iter = 100: QPs that reach the cap of the first pass are re-factored with the re-balanced rho and
+    continue from their own (x, y).  Same rule in the oracle (solve_with_restart / srbd_oracle.c), so statuses and
+    iteration counts agree, nearly every QP ends solved, and the forces stay within the exact-optimum tolerance."""
+    import c_oracle
+    from g1_locomotion_amd import _lib
+    N, B = 10, 2048
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=1000, schedule="single")
+    p = orc.SrbdParams(rho_restart_iter=100)
+    ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
+    assert (ref["iters"] > 100).sum() >= 20 and (ref["status"] == orc.STATUS_SOLVED).mean() > 0.998
+    kid = {"compact": _lib.KERNEL_COMPACT, "split": _lib.KERNEL_SPLIT}[kernel]
+    with _engine(N, kernel=kid, rho_restart_iter=100) as eng:
+        out = eng.solve(x0, xr, ft, ct)
+        assert eng.kernel_name().startswith(kernel + "_")
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
+    same = out["iters"] == ref["iters"]
+    assert same.mean() > 0.97
+    err = np.abs(out["u"] - ref["u"]).reshape(B, -1).max(1)
+    assert err[same].max() <= 1e-3 and err.max() <= 2 * TOL_TWIN_N, (err[same].max(), err.max())
+    # the restarted QPs against the exact optimum (rho' is clipped to [rho/10, 10 rho] for exactly this)
+    for b in np.where((ref["iters"] > 100) & (ref["status"] == orc.STATUS_SOLVED))[0][:12]:
+        xs, _ = orc.solve_reference(p, orc.build_qp(p, x0[b], xr[b], ft[b], ct[b]))
+        assert np.abs(out["u"][b].reshape(-1) - xs * p.force_scale).max() <= TOL_EXACT_N
+
+
+def test_rho_restart_on_the_staged_batch1_path(torch_first, built_lib):
+    """MPC.update() (staged, fused kernel): the second pass is started by the host only when a status asks for it."""
+    from g1_locomotion_amd import mpc
+    N = 10
+    x0, xr, ft, ct = orc.synthetic_batch(400, N, seed=1000, schedule="single")
+    p = orc.SrbdParams(rho_restart_iter=100)
+    refs = [orc.update(p, x0[b], xr[b], ft[b], ct[b]) for b in range(400)]
+    hard = [b for b in range(400) if refs[b]["iters"] > 100][:4]
+    easy = [b for b in range(400) if refs[b]["iters"] <= 40][:2]
+    assert len(hard) >= 2
+    MPC = mpc.MPC(dt=0.04, warm_start=False, rho_restart_iter=100)
+    MPC.init_matrices()
+    for b in hard + easy + hard:
+        MPC.x_ref_hor[:] = xr[b]
+        u0, xo = MPC.update(list(ct[b]), list(ft[b]), xr[b][:, 3:6], x_current=x0[b].reshape(13, 1), one_rollout=True)
+        assert MPC.status == refs[b]["status"] and abs(MPC.iters - refs[b]["iters"]) <= p.check_every, (b, MPC.iters, refs[b]["iters"])
+        assert np.abs(MPC.u_opt - refs[b]["u"]).max() <= 2 * TOL_TWIN_N
+    MPC.close()
