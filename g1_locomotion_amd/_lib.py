@@ -19,6 +19,7 @@ E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
 SOLVED, MAX_ITER, NUMERICAL, CONTACT_BOUND = 1, 2, -1, -2
 FLAG_TIMING = 1
 FLAG_NO_SPIN = 2
+FLAG_SETUP4 = 4
 KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT, KERNEL_SPLIT = 0, 1, 2, 3, 4
 
 EXPORTS = (

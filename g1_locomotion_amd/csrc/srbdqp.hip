@@ -16,6 +16,7 @@
 #include "srbdqp_mfma.hpp"
 #include "srbdqp_compact.hpp"
 #include "srbdqp_split.hpp"
+#include "srbdqp_setup1.hpp"
 #include "srbdqp_cascade.hpp"
 #include "srbdqp_cascade.h"
 
@@ -171,7 +172,16 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     if (rc != SRBDQP_OK) return rc;
     static const std::string nm = "split_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
-    hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), ldsA, st, a);
+    if constexpr (srbdqp::Setup1Smem<N, MAXS>::supported) {
+        if (!(h->cfg.flags & SRBDQP_FLAG_SETUP4)) {          // set-up with one wave per QP (default)
+            constexpr size_t lds1 = srbdqp::Setup1Smem<N, MAXS>::bytes;
+            hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
+        } else {
+            hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), ldsA, st, a);
+        }
+    } else {
+        hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), ldsA, st, a);
+    }
     if ((h->cfg.flags & SRBDQP_FLAG_TIMING) && !a.count_ptr) { HIP_TRY(h, hipEventRecord(h->ev_mid, st)); h->ev_mid_valid = true; }
     hipLaunchKernelGGL((srbdqp::srbdqp_admm_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), ldsB, st, a);
     return SRBDQP_OK;

@@ -1,0 +1,383 @@
+// srbdqp_setup1.hpp -- set-up kernel of the split pipeline with ONE WAVE PER QP (first kernel; srbdqp_admm_kernel is
+// the second).
+//
+// The 4-wave set-up kernel is latency-bound (61 % of its wave time parked on s_waitcnt / barriers) and holds only 4 QPs
+// per CU, because a QP owns 4 waves x 118 registers and 38 KB of LDS (mostly the tile store).  Since the assembly is
+// closed form (srbdqp_compact.hpp) nothing needs 256 threads: here the 10 upper 16x16 tiles of K are 80 registers of one
+// wave in MFMA C layout and the whole factorisation stays in that wave's registers --
+//   F  right-looking Cholesky K = U'U: diagonal tile inverted on the matrix cores (diag16_invert_mfma), panel
+//      U_jb = L_jj^-1 K_jb (the A operand L_jj^-1 goes through a 2 KB wave-private LDS tile to be transposed),
+//      trailing update K_ab -= U_ja' U_jb with both operands straight from registers (register r of a C-layout tile is
+//      the A operand of K-step r of a product that contracts over the tile's row index, and the B operand as well);
+//   W  L^-1 block row by block row, in place over the U tiles (W_ij takes the slot of U_ji);
+//   I  K^-1 = W'W tile by tile, stored to the hand-over workspace as it is produced --
+// with no barrier anywhere (a workgroup is one wave) and 3x the QPs in flight per CU.  Produces exactly the workspace
+// (persistent strip + dense K^-1) the 4-wave set-up kernel produces; everything else is shared with it.
+#pragma once
+#include "srbdqp_compact.hpp"
+
+namespace srbdqp {
+
+template <int N, int MAXS>
+struct Setup1Smem {
+    using S = CompactSmem<N, MAXS>;
+    static constexpr int o_scr = (S::endA + 1) & ~1;       // 256: one 16x16 tile, wave-private (operand transposes)
+    static constexpr int o_end = o_scr + 256;
+    static constexpr size_t bytes = (size_t)o_end * sizeof(double);
+    static constexpr bool supported = SplitWs<N, MAXS>::supported && S::NT <= 4;
+};
+
+template <int N, int MAXS>
+__global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    using S = CompactSmem<N, MAXS>;
+    using W = SplitWs<N, MAXS>;
+    using L1 = Setup1Smem<N, MAXS>;
+    constexpr int n = Dims<N>::n, m = Dims<N>::m, NT = S::NT;
+    static_assert(L1::supported, "one wave holds all tiles: at most 4 x 4 tiles");
+    static_assert(4 * N <= 64, "one ballot compacts the contact flags");
+    if ((int)blockIdx.x >= a.B) return;
+    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) return;
+    const int b = SRBDQP_QP_INDEX(a);
+    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+    const int lane = threadIdx.x;
+    int mcol = lane & 15, kq = lane >> 4;
+    double* ws = a.ws + (size_t)b * W::doubles;
+    int* icnt = reinterpret_cast<int*>(sm + S::o_int);
+    int* imisc = icnt + 2 * N;
+    uint8_t* act = reinterpret_cast<uint8_t*>(imisc + 8);
+    uint8_t* sct = reinterpret_cast<uint8_t*>(sm + S::o_ct);
+    const double* SQ = sm + S::o_sq;
+    const double* CP = sm + S::o_cp;
+
+    // ================= load + linearise (a5) =================
+    {
+        const double* gx0 = a.x0 + (size_t)b * 13;
+        const double* gxr = a.xref + (size_t)b * N * 13;
+        const double* gft = a.foot + (size_t)b * N * 12;
+        const uint8_t* gct = a.contact + (size_t)b * N * 4;
+        if (lane < 13) sm[S::o_x0 + lane] = gx0[lane];
+        if (lane >= 32 && lane < 44) sm[S::o_sq + lane - 32] = a.sqrtq[lane - 32];
+        for (int i = lane; i < N * 13; i += 64) sm[S::o_xref + i] = gxr[i];
+        for (int i = lane; i < N * 12; i += 64) sm[S::o_foot + i] = gft[i];
+        if (lane < N * 4) sct[lane] = gct[lane] ? 1 : 0;
+        if (a.pcom) {
+            const double* gpc = a.pcom + (size_t)b * N * 3;
+            if (lane < N * 3) sm[S::o_pcom + lane] = gpc[lane];
+        }
+        __syncthreads();
+        if (!a.pcom && lane < N * 3) sm[S::o_pcom + lane] = sm[S::o_xref + (lane / 3) * 13 + 3 + (lane % 3)];
+        if (lane < N) {   // Rz(yaw_k)'
+            double sn, cs;
+            sincos(sm[S::o_xref + lane * 13 + 2], &sn, &cs);
+            double* T = sm + S::o_tm + lane * 9;
+            T[0] = cs;  T[1] = sn;  T[2] = 0.0;
+            T[3] = -sn; T[4] = cs;  T[5] = 0.0;
+            T[6] = 0.0; T[7] = 0.0; T[8] = 1.0;
+        }
+        {   // presolve: compact the stance contacts
+            const bool flag = (lane < 4 * N) && sct[lane < 4 * N ? lane : 0] != 0;
+            const unsigned long long bal = __ballot(flag);
+            if (flag) act[__popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+            if (lane < N) icnt[lane] = __popcll(bal & ((4 * (lane + 1) >= 64) ? ~0ull : ((1ull << (4 * (lane + 1))) - 1ull)));
+            if (lane == 0) {
+                imisc[0] = __popcll(bal);
+                sm[S::o_misc] = 0.0;
+                sm[S::o_misc + 1] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (lane < 9) {   // prefix sums C_k = sum_{l<=k} T_l
+            double acc = 0.0;
+            for (int k = 0; k < N; ++k) { acc += sm[S::o_tm + k * 9 + lane]; sm[S::o_cp + k * 9 + lane] = acc; }
+        }
+        if (lane == 16) {   // per-step bound check
+            int viol = 0;
+            for (int i = 0; i < N; ++i) viol |= ((icnt[i] - (i ? icnt[i - 1] : 0)) > MAXS);
+            imisc[1] = viol;
+        }
+        for (int tt = lane; tt < N * 12; tt += 64) {   // J_k[:, 3 ci + ax] = Iw^-1 * skew(r)[:, ax]
+            const int k = tt / 12, cc = tt % 12, ci = cc / 3, ax = cc % 3;
+            const double cs = sm[S::o_tm + k * 9 + 0], sn = sm[S::o_tm + k * 9 + 1];
+            const double i0 = a.iinv[0], i1 = a.iinv[1], i2 = a.iinv[2];
+            const double w00 = cs * cs * i0 + sn * sn * i1, w01 = cs * sn * (i0 - i1), w11 = sn * sn * i0 + cs * cs * i1;
+            const double rx = sm[S::o_foot + k * 12 + 3 * ci + 0] - sm[S::o_pcom + k * 3 + 0];
+            const double ry = sm[S::o_foot + k * 12 + 3 * ci + 1] - sm[S::o_pcom + k * 3 + 1];
+            const double rz = sm[S::o_foot + k * 12 + 3 * ci + 2] - sm[S::o_pcom + k * 3 + 2];
+            double s0, s1, s2;   // column ax of skew(r)
+            if (ax == 0) { s0 = 0.0; s1 = rz;  s2 = -ry; }
+            else if (ax == 1) { s0 = -rz; s1 = 0.0; s2 = rx; }
+            else { s0 = ry;  s1 = -rx; s2 = 0.0; }
+            double* J = sm + S::o_J + k * 36;
+            J[0 * 12 + cc] = w00 * s0 + w01 * s1;
+            J[1 * 12 + cc] = w01 * s0 + w11 * s1;
+            J[2 * 12 + cc] = i2 * s2;
+        }
+        __syncthreads();
+    }
+    const int na = imisc[0];
+    const int n_eff = 3 * na;
+    double* xs0 = sm + S::o_eh;                              // scratch vectors of the early exit (n + 6N fit behind o_eh)
+    if (imisc[1] != 0 || na == 0) {   // bound violated (status -2) or nothing to solve (all forces 0): finished here
+        for (int c = lane; c < n; c += 64) xs0[c] = 0.0;
+        if (a.y_out) for (int i = lane; i < m; i += 64) a.y_out[(size_t)b * m + i] = 0.0;
+        if (lane == 0) {
+            if (a.status) a.status[b] = (imisc[1] != 0) ? kStatusContactBound : 1;
+            if (a.iters) a.iters[b] = a.iters_base;
+            ws[S::o_misc + 1] = 1.0;
+        }
+        __syncthreads();
+        rollout_and_store<N, S, 64>(a, b, sm, xs0, xs0 + n);
+        return;
+    }
+
+    // ================= closed-form tables, gradient, warm-start P x^0 (see srbdqp_compact.hpp, phase A) =================
+    const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = dt2 * a.inv_mass;
+    double* T1 = sm + S::o_t1;
+    double* T2 = sm + S::o_t2;
+    double* MT = sm + S::o_mt;
+    double* GV = sm + S::o_gv;
+    for (int k = lane; k < n; k += 64) {
+        const int i = k / 12, kk = k - 12 * i;
+        sm[S::o_eh + k] = SQ[kk] * (free_response<N, S>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
+    }
+    for (int tt = lane; tt < 9 * N; tt += 64) {
+        const int mm = tt / 9, pq = tt - 9 * mm, p = pq / 3, q = pq - 3 * p;
+        const double* Cm = CP + mm * 9;
+        const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2];
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = mm; i < N; ++i) {
+            const double* Ci = CP + i * 9;
+            s1 += Ci[pq] - Cm[pq];
+            const double d0p = Ci[p] - Cm[p], d1p = Ci[3 + p] - Cm[3 + p], d2p = Ci[6 + p] - Cm[6 + p];
+            const double d0q = Ci[q] - Cm[q], d1q = Ci[3 + q] - Cm[3 + q], d2q = Ci[6 + q] - Cm[6 + q];
+            s2 += (w0 * d0p) * d0q + (w1 * d1p) * d1q + (w2 * d2p) * d2q;
+        }
+        T1[tt] = s1;
+        T2[tt] = s2;
+    }
+    __syncthreads();
+    auto gt_tables = [&](const double* vec) {
+        for (int tt = lane; tt < 9 * N; tt += 64) {
+            const int j = tt / 9, comp = tt - 9 * j;
+            const double* Cj = CP + j * 9;
+            double acc = 0.0;
+            if (comp < 3) {
+                for (int i = j; i < N; ++i) {
+                    const double* Ci = CP + i * 9;
+                    const double* v = vec + 12 * i;
+                    acc += dt2 * ((Ci[comp] - Cj[comp]) * (SQ[0] * v[0]) + (Ci[3 + comp] - Cj[3 + comp]) * (SQ[1] * v[1]) +
+                                  (Ci[6 + comp] - Cj[6 + comp]) * (SQ[2] * v[2])) + dt * (SQ[6 + comp] * v[6 + comp]);
+                }
+            } else if (comp < 6) {
+                for (int i = j; i < N; ++i) acc += (double)(i - j) * vec[12 * i + comp];
+            } else {
+                for (int i = j; i < N; ++i) acc += vec[12 * i + 3 + comp];
+            }
+            GV[tt] = acc;
+        }
+    };
+    auto gt_eval = [&](int c) -> double {
+        const int e = c / 3, ax = c - 3 * e, gc = act[e], j = gc >> 2;
+        const double* J = sm + S::o_J + j * 36 + 3 * (gc & 3) + ax;
+        const double* g = GV + 9 * j;
+        return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
+    };
+    gt_tables(sm + S::o_eh);
+    for (int idx = lane; idx < 9 * S::NPAIR; idx += 64) {
+        const int pair = idx / 9, pq = idx - 9 * pair, p = pq / 3, q = pq - 3 * p;
+        int mm = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
+        mm += ((mm + 1) * (mm + 2) / 2 <= pair) ? 1 : 0;
+        mm -= (mm * (mm + 1) / 2 > pair) ? 1 : 0;
+        const int j = pair - mm * (mm + 1) / 2;
+        const double* Cm = CP + mm * 9;
+        const double* Cj = CP + j * 9;
+        const double* t1 = T1 + mm * 9;
+        double v = T2[mm * 9 + pq];
+        v += (Cm[p] - Cj[p]) * (SQ[0] * SQ[0]) * t1[q] + (Cm[3 + p] - Cj[3 + p]) * (SQ[1] * SQ[1]) * t1[3 + q] + (Cm[6 + p] - Cj[6 + p]) * (SQ[2] * SQ[2]) * t1[6 + q];
+        v *= dt2 * dt2;
+        if (p == q) v += (double)(N - mm) * dt2 * SQ[6 + p] * SQ[6 + p];
+        MT[idx] = v;
+    }
+    __syncthreads();
+    for (int c = lane; c < n_eff; c += 64) sm[S::o_q + c] = gt_eval(c);
+    if (a.warm_u) {
+        double* TF = sm + S::o_tf;
+        for (int c = lane; c < n_eff; c += 64)
+            sm[S::o_x0c + c] = a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)] / a.s;
+        __syncthreads();
+        for (int tt = lane; tt < 6 * N; tt += 64) {
+            const int j = tt / 6, comp = tt - 6 * j;
+            double acc = 0.0;
+            for (int e = (j ? icnt[j - 1] : 0); e < icnt[j]; ++e) {
+                const double* x = sm + S::o_x0c + 3 * e;
+                if (comp < 3) {
+                    const double* J = sm + S::o_J + j * 36 + comp * 12 + 3 * (act[e] & 3);
+                    acc += J[0] * x[0] + J[1] * x[1] + J[2] * x[2];
+                } else {
+                    acc += x[comp - 3];
+                }
+            }
+            TF[tt] = acc;
+        }
+        __syncthreads();
+        for (int k = lane; k < n; k += 64) {
+            const int i = k / 12, kk = k - 12 * i;
+            double acc = 0.0;
+            if (kk < 3) {
+                const double* Ci = CP + i * 9 + kk * 3;
+                for (int j = 0; j <= i; ++j) {
+                    const double* Cj = CP + j * 9 + kk * 3;
+                    const double* tau = TF + 6 * j;
+                    acc += (Ci[0] - Cj[0]) * tau[0] + (Ci[1] - Cj[1]) * tau[1] + (Ci[2] - Cj[2]) * tau[2];
+                }
+                acc *= dt2;
+            } else if (kk < 6) {
+                for (int j = 0; j <= i; ++j) acc += (double)(i - j) * TF[6 * j + kk];
+                acc *= dt2m;
+            } else if (kk < 9) {
+                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
+                acc *= dt;
+            } else {
+                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
+                acc *= dtm;
+            }
+            sm[S::o_gx + k] = SQ[kk] * a.s * acc;
+        }
+        __syncthreads();
+        gt_tables(sm + S::o_gx);
+        __syncthreads();
+        for (int c = lane; c < n_eff; c += 64) sm[S::o_px0 + c] = gt_eval(c) + a.rs2 * sm[S::o_x0c + c];
+    } else {
+        for (int c = lane; c < n_eff; c += 64) sm[S::o_px0 + c] = 0.0;
+    }
+
+    // ================= K = G'G + R s^2 + sigma + A' rho A: every entry of the upper tiles straight into registers =========
+    v4d Kt[NT][NT];
+    {
+        const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb) {
+            const int c = 16 * tb + mcol;
+#pragma unroll
+            for (int ta = 0; ta <= tb; ++ta) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 16 * ta + kq + 4 * q;
+                    const bool in = (r < n_eff) && (c < n_eff);
+                    const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;
+                    const int e1 = lo / 3, a1 = lo - 3 * e1, e2 = hi / 3, a2 = hi - 3 * e2;
+                    const int g1 = act[e1], g2 = act[e2], j = g1 >> 2, mm = g2 >> 2;
+                    const double* J1 = sm + S::o_J + j * 36 + 3 * (g1 & 3) + a1;
+                    const double* J2 = sm + S::o_J + mm * 36 + 3 * (g2 & 3) + a2;
+                    const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
+                    const double x0 = J2[0], x1 = J2[12], x2 = J2[24];
+                    double v = J1[0] * (M[0] * x0 + M[1] * x1 + M[2] * x2) + J1[12] * (M[3] * x0 + M[4] * x1 + M[5] * x2) +
+                               J1[24] * (M[6] * x0 + M[7] * x1 + M[8] * x2);
+                    const int Ls = N - mm, d = mm - j;
+                    const int sp = ((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2);
+                    const double same = (a1 == a2) ? 1.0 : 0.0;
+                    v = fma(same, SQ[3 + a1] * SQ[3 + a1] * dt4m2 * (double)sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * (double)Ls, v);
+                    double val = s2 * v;
+                    val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b) : 0.0;
+                    Kt[ta][tb][q] = in ? val : ((r == c) ? 1.0 : 0.0);     // padding -> identity
+                }
+            }
+        }
+    }
+    __syncthreads();   // the phase-A arrays are dead; the scratch tile is used from here on
+
+    // A-operand form of a C-layout tile X (operand[r] at lane (i, k') = X[i][4r + k']): through the wave-private tile
+    double* scr = sm + L1::o_scr;
+    auto a_operand = [&](const v4d& x, double (&op)[4]) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = kq + 4 * q;
+            scr[row * 16 + (mcol ^ row)] = x[q];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[r] = scr[mcol * 16 + ((4 * r + kq) ^ mcol)];
+        asm volatile("" ::: "memory");
+    };
+    const v4d zero4 = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // ================= F: K = U'U, tiles (j, b > j) become U_jb, tile (j, j) becomes L_jj^-1 =================
+    bool all_ok = true;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        bool ok;
+        v4d w = diag16_invert_mfma(Kt[j][j], lane, ok);
+        all_ok = all_ok && ok;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (mcol <= kq + 4 * q) ? w[q] : 0.0;     // exact zeros above the diagonal
+        Kt[j][j] = w;
+        if (j + 1 < NT) {
+            double wa[4];
+            a_operand(w, wa);
+#pragma unroll
+            for (int bb = j + 1; bb < NT; ++bb) {   // panel: U_jb = L_jj^-1 K_jb
+                v4d o = zero4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o = mfma_f64(wa[r], Kt[j][bb][r], o);
+                Kt[j][bb] = o;
+            }
+#pragma unroll
+            for (int aa = j + 1; aa < NT; ++aa)      // trailing: K_ab -= U_ja' U_jb
+#pragma unroll
+                for (int bb = aa; bb < NT; ++bb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Kt[aa][bb] = mfma_f64(-Kt[j][aa][r], Kt[j][bb][r], Kt[aa][bb]);
+        }
+    }
+    if (!all_ok && lane == 0) sm[S::o_misc] = 1.0;
+
+    // ================= W = L^-1, block row by block row, W_ij (i > j) into the slot of U_ji =================
+#pragma unroll
+    for (int i = 1; i < NT; ++i) {
+        double wa[4];
+        a_operand(Kt[i][i], wa);                             // W_ii as the left factor
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            v4d sacc = zero4;                                // sum_{k=j}^{i-1} L_ik W_kj, L_ik = U_ki'
+#pragma unroll
+            for (int k = j; k < i; ++k) {
+                const v4d& wkj = (k == j) ? Kt[j][j] : Kt[j][k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc = mfma_f64(Kt[k][i][r], wkj[r], sacc);
+            }
+            v4d o = zero4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o = mfma_f64(-wa[r], sacc[r], o);
+            Kt[j][i] = o;                                    // U_ji is not needed any more (j' > j use U_j'i only)
+        }
+    }
+
+    // ================= I: K^-1 = W'W, stored as it is produced; then the persistent strip =================
+    for (int i = lane; i < S::o_R; i += 64) ws[i] = sm[i];
+    double* kinv = ws + W::o_kinv;
+#pragma unroll
+    for (int aa = 0; aa < NT; ++aa) {
+#pragma unroll
+        for (int bb = aa; bb < NT; ++bb) {
+            v4d o = zero4;                                   // sum_{k >= b} W_ka' W_kb
+#pragma unroll
+            for (int k = bb; k < NT; ++k) {
+                const v4d& wka = (k == aa) ? Kt[aa][aa] : Kt[aa][k];
+                const v4d& wkb = (k == bb) ? Kt[bb][bb] : Kt[bb][k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o = mfma_f64(wka[r], wkb[r], o);
+            }
+            const int col = 16 * bb + mcol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 16 * aa + kq + 4 * q;
+                if (row < n_eff && col < W::KS) kinv[row * W::KS + col] = (col < n_eff) ? o[q] : 0.0;
+                if (aa != bb && col < n_eff && row < W::KS) kinv[col * W::KS + row] = (row < n_eff) ? o[q] : 0.0;
+            }
+        }
+    }
+}
+
+}  // namespace srbdqp

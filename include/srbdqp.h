@@ -48,6 +48,7 @@ extern "C" {
 
 /* srbdqp_config.flags */
 #define SRBDQP_FLAG_TIMING 1      /* bracket every kernel launch with HIP events (srbdqp_last_kernel_ms) */
+#define SRBDQP_FLAG_SETUP4 4      /* split pipeline: set-up kernel with 4 waves per QP instead of one wave per QP (A/B) */
 #define SRBDQP_FLAG_NO_SPIN 2     /* srbdqp_solve_staged_f64: wait with hipStreamSynchronize instead of spinning on the
                                      completion word the kernel writes to host memory */
 
