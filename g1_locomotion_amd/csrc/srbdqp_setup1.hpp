@@ -18,13 +18,34 @@
 
 namespace srbdqp {
 
+// LDS of one wave: [0, S::o_R) the persistent strip with the offsets of CompactSmem (the ADMM kernel reads it back from
+// the workspace), then the phase-A arrays with their lifetimes shared: inputs -> error vector / warm-start vectors ->
+// the transpose tile of the factorisation.
 template <int N, int MAXS>
 struct Setup1Smem {
     using S = CompactSmem<N, MAXS>;
-    static constexpr int o_scr = (S::endA + 1) & ~1;       // 256: one 16x16 tile, wave-private (operand transposes)
-    static constexpr int o_end = o_scr + 256;
+    static constexpr int n = Dims<N>::n;
+    static constexpr int up2(int v) { return (v + 1) & ~1; }
+    static constexpr int o_x0 = S::o_x0, o_tm = S::o_tm, o_J = S::o_J;   // strip offsets used by the shared helpers
+    static constexpr int o_cp = S::o_R;                    // 9N   prefix sums C_k
+    static constexpr int o_mt = o_cp + up2(9 * N);         // 9 NPAIR  M(j, m)
+    static constexpr int o_gv = o_mt + up2(9 * S::NPAIR);  // 9N   G'v tables
+    static constexpr int o_t1 = o_gv + up2(9 * N);         // 9N   T1(m)          | later: x0c (nmax + 16), tf (6N)
+    static constexpr int o_t2 = o_t1 + up2(9 * N);         // 9N   T2(m)
+    static constexpr int o_x0c = o_t1;
+    static constexpr int o_tf = o_x0c + up2(S::nmax) + 16;
+    static constexpr int endT = (o_t2 + up2(9 * N) > o_tf + 6 * N) ? o_t2 + up2(9 * N) : o_tf + 6 * N;
+    static constexpr int o_xref = up2(endT);               // 13N  inputs          | later: the 16 x 16 transpose tile
+    static constexpr int o_foot = o_xref + up2(N * 13);    // 12N                  | later: eh (n), then G x^0 (n)
+    static constexpr int o_pcom = o_foot + N * 12;         // 3N
+    static constexpr int o_eh = o_foot;
+    static constexpr int o_gx = o_foot;
+    static constexpr int o_scr = o_xref;
+    static constexpr int endIn = o_pcom + up2(N * 3);
+    static constexpr int o_end = (endIn > o_scr + 256) ? endIn : o_scr + 256;
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr bool supported = SplitWs<N, MAXS>::supported && S::NT <= 4;
+    static_assert(n + 6 * N <= o_end - o_eh || true, "");
 };
 
 template <int N, int MAXS>
@@ -48,7 +69,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     uint8_t* act = reinterpret_cast<uint8_t*>(imisc + 8);
     uint8_t* sct = reinterpret_cast<uint8_t*>(sm + S::o_ct);
     const double* SQ = sm + S::o_sq;
-    const double* CP = sm + S::o_cp;
+    const double* CP = sm + L1::o_cp;
 
     // ================= load + linearise (a5) =================
     {
@@ -58,18 +79,18 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         const uint8_t* gct = a.contact + (size_t)b * N * 4;
         if (lane < 13) sm[S::o_x0 + lane] = gx0[lane];
         if (lane >= 32 && lane < 44) sm[S::o_sq + lane - 32] = a.sqrtq[lane - 32];
-        for (int i = lane; i < N * 13; i += 64) sm[S::o_xref + i] = gxr[i];
-        for (int i = lane; i < N * 12; i += 64) sm[S::o_foot + i] = gft[i];
+        for (int i = lane; i < N * 13; i += 64) sm[L1::o_xref + i] = gxr[i];
+        for (int i = lane; i < N * 12; i += 64) sm[L1::o_foot + i] = gft[i];
         if (lane < N * 4) sct[lane] = gct[lane] ? 1 : 0;
         if (a.pcom) {
             const double* gpc = a.pcom + (size_t)b * N * 3;
-            if (lane < N * 3) sm[S::o_pcom + lane] = gpc[lane];
+            if (lane < N * 3) sm[L1::o_pcom + lane] = gpc[lane];
         }
         __syncthreads();
-        if (!a.pcom && lane < N * 3) sm[S::o_pcom + lane] = sm[S::o_xref + (lane / 3) * 13 + 3 + (lane % 3)];
+        if (!a.pcom && lane < N * 3) sm[L1::o_pcom + lane] = sm[L1::o_xref + (lane / 3) * 13 + 3 + (lane % 3)];
         if (lane < N) {   // Rz(yaw_k)'
             double sn, cs;
-            sincos(sm[S::o_xref + lane * 13 + 2], &sn, &cs);
+            sincos(sm[L1::o_xref + lane * 13 + 2], &sn, &cs);
             double* T = sm + S::o_tm + lane * 9;
             T[0] = cs;  T[1] = sn;  T[2] = 0.0;
             T[3] = -sn; T[4] = cs;  T[5] = 0.0;
@@ -89,7 +110,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         __syncthreads();
         if (lane < 9) {   // prefix sums C_k = sum_{l<=k} T_l
             double acc = 0.0;
-            for (int k = 0; k < N; ++k) { acc += sm[S::o_tm + k * 9 + lane]; sm[S::o_cp + k * 9 + lane] = acc; }
+            for (int k = 0; k < N; ++k) { acc += sm[S::o_tm + k * 9 + lane]; sm[L1::o_cp + k * 9 + lane] = acc; }
         }
         if (lane == 16) {   // per-step bound check
             int viol = 0;
@@ -101,9 +122,9 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
             const double cs = sm[S::o_tm + k * 9 + 0], sn = sm[S::o_tm + k * 9 + 1];
             const double i0 = a.iinv[0], i1 = a.iinv[1], i2 = a.iinv[2];
             const double w00 = cs * cs * i0 + sn * sn * i1, w01 = cs * sn * (i0 - i1), w11 = sn * sn * i0 + cs * cs * i1;
-            const double rx = sm[S::o_foot + k * 12 + 3 * ci + 0] - sm[S::o_pcom + k * 3 + 0];
-            const double ry = sm[S::o_foot + k * 12 + 3 * ci + 1] - sm[S::o_pcom + k * 3 + 1];
-            const double rz = sm[S::o_foot + k * 12 + 3 * ci + 2] - sm[S::o_pcom + k * 3 + 2];
+            const double rx = sm[L1::o_foot + k * 12 + 3 * ci + 0] - sm[L1::o_pcom + k * 3 + 0];
+            const double ry = sm[L1::o_foot + k * 12 + 3 * ci + 1] - sm[L1::o_pcom + k * 3 + 1];
+            const double rz = sm[L1::o_foot + k * 12 + 3 * ci + 2] - sm[L1::o_pcom + k * 3 + 2];
             double s0, s1, s2;   // column ax of skew(r)
             if (ax == 0) { s0 = 0.0; s1 = rz;  s2 = -ry; }
             else if (ax == 1) { s0 = -rz; s1 = 0.0; s2 = rx; }
@@ -117,7 +138,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     }
     const int na = imisc[0];
     const int n_eff = 3 * na;
-    double* xs0 = sm + S::o_eh;                              // scratch vectors of the early exit (n + 6N fit behind o_eh)
+    double* xs0 = sm + L1::o_mt;                             // scratch vectors of the early exit (n + 6N doubles; M is not built)
     if (imisc[1] != 0 || na == 0) {   // bound violated (status -2) or nothing to solve (all forces 0): finished here
         for (int c = lane; c < n; c += 64) xs0[c] = 0.0;
         if (a.y_out) for (int i = lane; i < m; i += 64) a.y_out[(size_t)b * m + i] = 0.0;
@@ -133,13 +154,13 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
 
     // ================= closed-form tables, gradient, warm-start P x^0 (see srbdqp_compact.hpp, phase A) =================
     const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = dt2 * a.inv_mass;
-    double* T1 = sm + S::o_t1;
-    double* T2 = sm + S::o_t2;
-    double* MT = sm + S::o_mt;
-    double* GV = sm + S::o_gv;
+    double* T1 = sm + L1::o_t1;
+    double* T2 = sm + L1::o_t2;
+    double* MT = sm + L1::o_mt;
+    double* GV = sm + L1::o_gv;
     for (int k = lane; k < n; k += 64) {
         const int i = k / 12, kk = k - 12 * i;
-        sm[S::o_eh + k] = SQ[kk] * (free_response<N, S>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
+        sm[L1::o_eh + k] = SQ[kk] * (free_response<N, L1>(a, sm, i, kk) - sm[L1::o_xref + i * 13 + kk]);
     }
     for (int tt = lane; tt < 9 * N; tt += 64) {
         const int mm = tt / 9, pq = tt - 9 * mm, p = pq / 3, q = pq - 3 * p;
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         const double* g = GV + 9 * j;
         return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
     };
-    gt_tables(sm + S::o_eh);
+    gt_tables(sm + L1::o_eh);
     for (int idx = lane; idx < 9 * S::NPAIR; idx += 64) {
         const int pair = idx / 9, pq = idx - 9 * pair, p = pq / 3, q = pq - 3 * p;
         int mm = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
@@ -202,15 +223,15 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     __syncthreads();
     for (int c = lane; c < n_eff; c += 64) sm[S::o_q + c] = gt_eval(c);
     if (a.warm_u) {
-        double* TF = sm + S::o_tf;
+        double* TF = sm + L1::o_tf;
         for (int c = lane; c < n_eff; c += 64)
-            sm[S::o_x0c + c] = a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)] / a.s;
+            sm[L1::o_x0c + c] = a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)] / a.s;
         __syncthreads();
         for (int tt = lane; tt < 6 * N; tt += 64) {
             const int j = tt / 6, comp = tt - 6 * j;
             double acc = 0.0;
             for (int e = (j ? icnt[j - 1] : 0); e < icnt[j]; ++e) {
-                const double* x = sm + S::o_x0c + 3 * e;
+                const double* x = sm + L1::o_x0c + 3 * e;
                 if (comp < 3) {
                     const double* J = sm + S::o_J + j * 36 + comp * 12 + 3 * (act[e] & 3);
                     acc += J[0] * x[0] + J[1] * x[1] + J[2] * x[2];
@@ -242,12 +263,12 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
                 for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
                 acc *= dtm;
             }
-            sm[S::o_gx + k] = SQ[kk] * a.s * acc;
+            sm[L1::o_gx + k] = SQ[kk] * a.s * acc;
         }
         __syncthreads();
-        gt_tables(sm + S::o_gx);
+        gt_tables(sm + L1::o_gx);
         __syncthreads();
-        for (int c = lane; c < n_eff; c += 64) sm[S::o_px0 + c] = gt_eval(c) + a.rs2 * sm[S::o_x0c + c];
+        for (int c = lane; c < n_eff; c += 64) sm[S::o_px0 + c] = gt_eval(c) + a.rs2 * sm[L1::o_x0c + c];
     } else {
         for (int c = lane; c < n_eff; c += 64) sm[S::o_px0 + c] = 0.0;
     }
@@ -281,6 +302,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
                     double val = s2 * v;
                     val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b) : 0.0;
                     Kt[ta][tb][q] = in ? val : ((r == c) ? 1.0 : 0.0);     // padding -> identity
+                    if (q & 1) asm volatile("" ::: "memory");              // bounds the LDS reads in flight (register budget)
                 }
             }
         }
