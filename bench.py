@@ -51,8 +51,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="QPs per GPU per step (default: configs[1])")
-    ap.add_argument("--kernel", choices=["auto", "gj", "mfma", "compact", "split"], default="auto",
-                    help="auto = split pipeline (set-up kernel + one-wave ADMM kernel) for this batch size; compact = the fused kernel")
+    ap.add_argument("--kernel", choices=["auto", "gj", "mfma", "compact", "split", "wave"], default="auto",
+                    help="auto = wave (one wave per QP) for this batch size; split = the same as two kernels; compact = the 4-wave fused kernel")
     ap.add_argument("--streams", type=int, default=2,
                     help="consecutive steps alternate over this many HIP streams, so the straggler tail of one batch "
                          "(QPs that need many ADMM iterations) overlaps the bulk of the next; 1 = strictly serial steps")
@@ -98,7 +98,7 @@ def main():
     d_u0_all = [torch.empty((world * B, 12), dtype=torch.float64, device=dev) for _ in range(S)] if world > 1 else None
 
     kid = {"auto": _lib.KERNEL_AUTO, "gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "compact": _lib.KERNEL_COMPACT,
-           "split": _lib.KERNEL_SPLIT}[args.kernel]
+           "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE}[args.kernel]
     # configs[1] is the 2-contact (single support) workload: at most 2 stance contact points per horizon step
     eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=2,
                    **({"max_iter": args.max_iter} if args.max_iter > 0 else {}))

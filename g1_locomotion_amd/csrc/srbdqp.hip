@@ -175,7 +175,7 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     if constexpr (srbdqp::Setup1Smem<N, MAXS>::supported) {
         if (!(h->cfg.flags & SRBDQP_FLAG_SETUP4)) {          // set-up with one wave per QP (default)
             constexpr size_t lds1 = srbdqp::Setup1Smem<N, MAXS>::bytes;
-            hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
+            hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, false>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
         } else {
             hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), ldsA, st, a);
         }
@@ -187,11 +187,25 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     return SRBDQP_OK;
 }
 
+// One wave per QP for the whole solve (srbdqp_setup1.hpp, FUSED): the default for large batches of the small
+// instantiations; nothing but inputs and outputs touches HBM.
+template <int N, int MAXS>
+int launch_wave(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
+    constexpr size_t lds1 = srbdqp::Setup1Smem<N, MAXS>::bytes;
+    static const std::string nm = "wave_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
+    h->kname = nm.c_str();
+    hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
+    return SRBDQP_OK;
+}
+
 template <int N, int MAXS>
 int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
+    if constexpr (srbdqp::Setup1Smem<N, MAXS>::supported) {
+        const bool want = h->cfg.kernel == SRBDQP_KERNEL_WAVE || (h->cfg.kernel == SRBDQP_KERNEL_AUTO && a.B >= kSplitMinBatch);
+        if (want && a.mode == 0 && !a.stamps && !a.done_flag) return launch_wave<N, MAXS>(h, a, st);
+    }
     if constexpr (srbdqp::SplitWs<N, MAXS>::supported) {
-        const bool want = h->cfg.kernel == SRBDQP_KERNEL_SPLIT || (h->cfg.kernel == SRBDQP_KERNEL_AUTO && a.B >= kSplitMinBatch);
-        if (want && a.mode == 0 && !a.stamps && !a.done_flag) return launch_split<N, MAXS>(h, a, st);
+        if (h->cfg.kernel == SRBDQP_KERNEL_SPLIT && a.mode == 0 && !a.stamps && !a.done_flag) return launch_split<N, MAXS>(h, a, st);
     }
     constexpr size_t lds = srbdqp::CompactTraits<N, MAXS>::lds_bytes;
     static bool attr_set = false;

@@ -14,7 +14,7 @@
 // with no barrier anywhere (a workgroup is one wave) and 3x the QPs in flight per CU.  Produces exactly the workspace
 // (persistent strip + dense K^-1) the 4-wave set-up kernel produces; everything else is shared with it.
 #pragma once
-#include "srbdqp_compact.hpp"
+#include "srbdqp_split.hpp"
 
 namespace srbdqp {
 
@@ -48,7 +48,11 @@ struct Setup1Smem {
     static_assert(n + 6 * N <= o_end - o_eh || true, "");
 };
 
-template <int N, int MAXS>
+// FUSED = false: first kernel of the split pipeline (stores the persistent strip + K^-1 to the hand-over workspace).
+// FUSED = true : the whole solve on this wave ("wave" kernel): the K^-1 tiles are turned into one row per lane through
+//                the 2 KB transpose tile, then the ADMM iterations and the roll-out of srbdqp_split.hpp follow in place --
+//                nothing but the inputs and the outputs touches HBM.
+template <int N, int MAXS, bool FUSED>
 __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     using S = CompactSmem<N, MAXS>;
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
     const int lane = threadIdx.x;
     int mcol = lane & 15, kq = lane >> 4;
-    double* ws = a.ws + (size_t)b * W::doubles;
+    double* ws = FUSED ? nullptr : a.ws + (size_t)b * W::doubles;
     int* icnt = reinterpret_cast<int*>(sm + S::o_int);
     int* imisc = icnt + 2 * N;
     uint8_t* act = reinterpret_cast<uint8_t*>(imisc + 8);
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         if (lane == 0) {
             if (a.status) a.status[b] = (imisc[1] != 0) ? kStatusContactBound : 1;
             if (a.iters) a.iters[b] = a.iters_base;
-            ws[S::o_misc + 1] = 1.0;
+            if constexpr (!FUSED) ws[S::o_misc + 1] = 1.0;
         }
         __syncthreads();
         rollout_and_store<N, S, 64>(a, b, sm, xs0, xs0 + n);
@@ -376,9 +380,16 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         }
     }
 
-    // ================= I: K^-1 = W'W, stored as it is produced; then the persistent strip =================
-    for (int i = lane; i < S::o_R; i += 64) ws[i] = sm[i];
-    double* kinv = ws + W::o_kinv;
+    // ================= I: K^-1 = W'W tile by tile; split: stored as produced, fused: one row per lane =================
+    double kin[W::KS];
+    if constexpr (!FUSED) {
+        for (int i = lane; i < S::o_R; i += 64) ws[i] = sm[i];
+    } else {
+#pragma unroll
+        for (int c = 0; c < W::KS; ++c) kin[c] = 0.0;
+    }
+    double* kinv = FUSED ? nullptr : ws + W::o_kinv;
+    const int grp = lane >> 4;                               // tile row of this lane's K^-1 row
 #pragma unroll
     for (int aa = 0; aa < NT; ++aa) {
 #pragma unroll
@@ -391,14 +402,40 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o = mfma_f64(wka[r], wkb[r], o);
             }
-            const int col = 16 * bb + mcol;
+            if constexpr (!FUSED) {
+                const int col = 16 * bb + mcol;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = 16 * aa + kq + 4 * q;
-                if (row < n_eff && col < W::KS) kinv[row * W::KS + col] = (col < n_eff) ? o[q] : 0.0;
-                if (aa != bb && col < n_eff && row < W::KS) kinv[col * W::KS + row] = (row < n_eff) ? o[q] : 0.0;
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 16 * aa + kq + 4 * q;
+                    if (row < n_eff && col < W::KS) kinv[row * W::KS + col] = (col < n_eff) ? o[q] : 0.0;
+                    if (aa != bb && col < n_eff && row < W::KS) kinv[col * W::KS + row] = (row < n_eff) ? o[q] : 0.0;
+                }
+            } else {
+                // tile -> rows: lanes of tile row aa take row (lane & 15), lanes of tile row bb take column (lane & 15)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) scr[(kq + 4 * q) * 16 + mcol] = o[q];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    if (16 * bb + jj < W::KS) {
+                        const double v = scr[mcol * 16 + jj];
+                        kin[16 * bb + jj] = (grp == aa) ? v : kin[16 * bb + jj];
+                    }
+                    if (aa != bb && 16 * aa + jj < W::KS) {
+                        const double v = scr[jj * 16 + mcol];
+                        kin[16 * aa + jj] = (grp == bb) ? v : kin[16 * aa + jj];
+                    }
+                }
+                asm volatile("" ::: "memory");
             }
         }
+    }
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int c = 0; c < W::KS; ++c) kin[c] = (lane < n_eff && c < n_eff) ? kin[c] : 0.0;
+        __syncthreads();
+        admm_wave_body<N, MAXS>(a, b, rho_b, sm, kin);
     }
 }
 

@@ -26,22 +26,15 @@ struct SplitSmem {
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
 };
 
+// ADMM iterations + roll-out of one QP on one wave.  sm: the persistent strip at [0, S::o_R) and SplitSmem's vectors behind
+// it; kin: the K^-1 row of this lane (zeros for lanes >= n_eff).
 template <int N, int MAXS>
-__global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+__device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS]) {
     using S = CompactSmem<N, MAXS>;
     using W = SplitWs<N, MAXS>;
     using L = SplitSmem<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m, KS = W::KS;
-    static_assert(W::supported, "one K^-1 row per lane of one wave");
-    if ((int)blockIdx.x >= a.B) return;
-    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) return;   // restart pass: nothing listed for this workgroup
-    const int b = SRBDQP_QP_INDEX(a);
-    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
     const int lane = threadIdx.x;
-    const double* ws = a.ws + (size_t)b * W::doubles;
-    if (ws[S::o_misc + 1] != 0.0) return;                  // finished by the set-up kernel (no stance contact / bound)
-    for (int i = lane; i < S::o_R; i += 64) sm[i] = ws[i];
     double* rb = sm + L::o_rhs;
     double* xs_full = sm + L::o_xs;
     for (int i = lane; i < n; i += 64) xs_full[i] = 0.0;
@@ -66,18 +59,6 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
     const double loB = rowB ? -kInf : 0.0, hiB = 0.0;
     const double mucA = (ax < 2) ? mu : 0.0;
     const int irowA = 5 * gc + ((ax < 2) ? 2 * ax : 4), irowB = 5 * gc + 2 * ax + 1;
-
-    // K^-1 row of this lane
-    double kin[KS];
-    {
-        const double2* src = reinterpret_cast<const double2*>(ws + W::o_kinv + (size_t)(lane < n_eff ? lane : 0) * KS);
-#pragma unroll
-        for (int c = 0; c < KS / 2; ++c) {
-            const double2 v = src[c];
-            kin[2 * c] = (lane < n_eff) ? v.x : 0.0;
-            kin[2 * c + 1] = (lane < n_eff) ? v.y : 0.0;
-        }
-    }
 
     // A'(wA, wB) for the variable of this lane; (A v)_slot for the two slots
     auto At = [&](double wA, double wB) -> double {
@@ -191,6 +172,38 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
         if (a.iters) a.iters[b] = iters + a.iters_base;
     }
     rollout_and_store<N, S, 64>(a, b, sm, xs_full, sm + L::o_scr);
+}
+
+template <int N, int MAXS>
+__global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    using S = CompactSmem<N, MAXS>;
+    using W = SplitWs<N, MAXS>;
+    constexpr int KS = W::KS;
+    static_assert(W::supported, "one K^-1 row per lane of one wave");
+    if ((int)blockIdx.x >= a.B) return;
+    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) return;   // restart pass: nothing listed for this workgroup
+    const int b = SRBDQP_QP_INDEX(a);
+    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+    const int lane = threadIdx.x;
+    const double* ws = a.ws + (size_t)b * W::doubles;
+    if (ws[S::o_misc + 1] != 0.0) return;                  // finished by the set-up kernel (no stance contact / bound)
+    for (int i = lane; i < S::o_R; i += 64) sm[i] = ws[i];
+    __syncthreads();
+    const int n_eff = 3 * (reinterpret_cast<const int*>(sm + S::o_int) + 2 * N)[0];
+    // K^-1 row of this lane
+    double kin[KS];
+    {
+        const double2* src = reinterpret_cast<const double2*>(ws + W::o_kinv + (size_t)(lane < n_eff ? lane : 0) * KS);
+#pragma unroll
+        for (int c = 0; c < KS / 2; ++c) {
+            const double2 v = src[c];
+            kin[2 * c] = (lane < n_eff) ? v.x : 0.0;
+            kin[2 * c + 1] = (lane < n_eff) ? v.y : 0.0;
+        }
+    }
+
+    admm_wave_body<N, MAXS>(a, b, rho_b, sm, kin);
 }
 
 }  // namespace srbdqp

@@ -57,9 +57,10 @@ extern "C" {
 #define SRBDQP_KERNEL_GJ    1     /* v0: VALU assembly + in-LDS Gauss-Jordan inverse */
 #define SRBDQP_KERNEL_MFMA  2     /* v1: fp64-MFMA contraction + tiled Cholesky inverse, all 12N variables */
 #define SRBDQP_KERNEL_COMPACT 3   /* v2: v1's pipeline on the presolved QP (swing-contact variables eliminated) */
-#define SRBDQP_KERNEL_SPLIT 4     /* v2 as two kernels: set-up (4 waves per QP) then ADMM + roll-out (1 wave per QP), K^-1
-                                     handed over through HBM; AUTO picks it for batches >= 512 of the instantiations
-                                     with <= 64 presolved variables, otherwise falls back to COMPACT */
+#define SRBDQP_KERNEL_SPLIT 4     /* two kernels, one wave per QP each: set-up, then ADMM + roll-out, K^-1 handed over through
+                                     HBM (<= 64 presolved variables, otherwise falls back to COMPACT); kept for A/B */
+#define SRBDQP_KERNEL_WAVE 5      /* the whole solve on one wave per QP, K tiles register-resident, no barrier, no hand-over;
+                                     AUTO picks it for batches >= 512 of the instantiations with <= 64 presolved variables */
 
 /* Everything `MPC.__init__(dt)` / `MPC.init_matrices()` hold (run_simulation.py:169-170).  Values the
  * reference keeps inside the absent module are this build's documented choices. */

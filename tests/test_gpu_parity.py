@@ -49,19 +49,21 @@ def test_assembly_matches_oracle(torch_first, built_lib, N, schedule):
 
 # kernel variants: gj / mfma keep all 12N variables (swing contacts clamped by their rows); compact (= auto) solves the
 # presolved QP.  The oracle twin runs the matching algorithm (SrbdParams.eliminate_swing).
-@pytest.mark.parametrize("kernel", ["gj", "mfma", "auto", "split"])
+@pytest.mark.parametrize("kernel", ["gj", "mfma", "auto", "split", "wave"])
 @pytest.mark.parametrize("N,schedule,B", [(10, "single", 24), (10, "double", 8), (10, "mixed", 16), (8, "mixed", 8), (4, "single", 6)])
 def test_solve_matches_oracle_and_exact_optimum(torch_first, built_lib, kernel, N, schedule, B):
     from g1_locomotion_amd import _lib
-    kid = {"gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "auto": _lib.KERNEL_AUTO, "split": _lib.KERNEL_SPLIT}[kernel]
-    presolved = kernel in ("auto", "split")
+    kid = {"gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "auto": _lib.KERNEL_AUTO, "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE}[kernel]
+    presolved = kernel in ("auto", "split", "wave")
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=200 + N, schedule=schedule)
     with _engine(N, kernel=kid) as eng:
         out = eng.solve(x0, xr, ft, ct, want_y=True)
-        # split = two kernels (set-up, then one wave per QP); it exists for <= 64 presolved variables, else falls back to compact
-        assert eng.kernel_name().startswith({"gj": ("gj_",), "mfma": ("mfma_",), "auto": ("compact_",), "split": ("split_", "compact_")}[kernel]), eng.kernel_name()
-        if kernel == "split" and schedule == "single":
-            assert eng.kernel_name().startswith("split_")
+        # wave = the whole solve on one wave per QP, split = the same as two kernels with a hand-over through HBM; both
+        # exist for <= 64 presolved variables, else fall back to compact
+        assert eng.kernel_name().startswith({"gj": ("gj_",), "mfma": ("mfma_",), "auto": ("compact_",), "split": ("split_", "compact_"),
+                                             "wave": ("wave_", "compact_")}[kernel]), eng.kernel_name()
+        if kernel in ("split", "wave") and schedule == "single":
+            assert eng.kernel_name().startswith(kernel + "_")
     p = orc.SrbdParams(eliminate_swing=presolved)
     for b in range(B):
         ref = orc.update(p, x0[b], xr[b], ft[b], ct[b])
@@ -210,7 +212,7 @@ def test_large_batch_against_c_oracle(torch_first, built_lib, N, pattern, B):
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     with _engine(N) as eng:
         out = eng.solve(x0, xr, ft, ct)
-        assert eng.kernel_name().startswith(("compact_", "split_"))
+        assert eng.kernel_name().startswith(("compact_", "split_", "wave_"))
     np.testing.assert_array_equal(out["status"], ref["status"])
     assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
     same = out["iters"] == ref["iters"]
@@ -269,7 +271,8 @@ def test_two_streams_pipeline_distinct_batches_through_one_handle(torch_first, b
     N, B = 10, 1024
     dev = torch.device("cuda", 0)
     batches = [[torch.from_numpy(v).to(dev) for v in orc.synthetic_batch(B, N, seed=700 + i, schedule="single")] for i in range(4)]
-    with BatchMPC(horizon=N, max_contacts_per_step=2) as eng:
+    from g1_locomotion_amd import _lib
+    with BatchMPC(horizon=N, max_contacts_per_step=2, kernel=_lib.KERNEL_SPLIT) as eng:
         def solve(d, stream=0, hint=None):
             u = torch.zeros((B, N, 12), dtype=torch.float64, device=dev)
             it = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -298,7 +301,7 @@ def test_two_streams_pipeline_distinct_batches_through_one_handle(torch_first, b
         assert torch.equal(u, alone[i][0]) and torch.equal(it, alone[i][1]) and torch.equal(st, alone[i][2]), i
 
 
-@pytest.mark.parametrize("kernel", ["compact", "split"])
+@pytest.mark.parametrize("kernel", ["compact", "split", "wave"])
 def test_rho_restart_matches_the_oracle(torch_first, built_lib, kernel):
     """rho_restart_iter = 100: QPs that reach the cap of the first pass are re-factored with the re-balanced rho and
     continue from their own (x, y).  Same rule in the oracle (solve_with_restart / srbd_oracle.c), so statuses and
@@ -310,7 +313,7 @@ def test_rho_restart_matches_the_oracle(torch_first, built_lib, kernel):
     p = orc.SrbdParams(rho_restart_iter=100)
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     assert (ref["iters"] > 100).sum() >= 20 and (ref["status"] == orc.STATUS_SOLVED).mean() > 0.998
-    kid = {"compact": _lib.KERNEL_COMPACT, "split": _lib.KERNEL_SPLIT}[kernel]
+    kid = {"compact": _lib.KERNEL_COMPACT, "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE}[kernel]
     with _engine(N, kernel=kid, rho_restart_iter=100) as eng:
         out = eng.solve(x0, xr, ft, ct)
         assert eng.kernel_name().startswith(kernel + "_")
