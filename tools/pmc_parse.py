@@ -20,5 +20,5 @@ def parse(d, keys):
 
 
 if __name__ == "__main__":
-    keys = sys.argv[2:] or ["srbdqp_compact_kernel", "srbdqp_admm_kernel"]
+    keys = sys.argv[2:] or ["srbdqp_setup1_kernel", "srbdqp_compact_kernel", "srbdqp_admm_kernel"]
     print(json.dumps(parse(sys.argv[1], keys), indent=1))

@@ -8,7 +8,7 @@ import subprocess
 def main():
     pmc_dir, stats_dir, out = sys.argv[1:4]
     from pmc_parse import parse
-    per = parse(pmc_dir, ["srbdqp_compact_kernel", "srbdqp_admm_kernel"])
+    per = parse(pmc_dir, ["srbdqp_setup1_kernel", "srbdqp_compact_kernel", "srbdqp_admm_kernel"])
     stats = {}
     for f in glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -37,7 +37,11 @@ def main():
             tot_us += stats[key]["avg_us"]
         tot_fetch += fetch * 2048; tot_write += write * 1024
         kernels[key] = k
-    d = {"round": 1, "bench_kernel_name": "split_f64_n10_s2" if len(per) > 1 else "compact_f64_n10_s2", "pipeline": "split_f64_n10_s2 = srbdqp_compact_kernel<10,2,true> (set-up) + srbdqp_admm_kernel<10,2> (ADMM + roll-out)" if len(per) > 1 else "compact_f64_n10_s2",
+    name = ("split_f64_n10_s2" if len(per) > 1 else "wave_f64_n10_s2" if "srbdqp_setup1_kernel" in per else "compact_f64_n10_s2")
+    d = {"round": 1, "bench_kernel_name": name,
+         "pipeline": {"split_f64_n10_s2": "set-up kernel + srbdqp_admm_kernel<10,2> (ADMM + roll-out), K^-1 handed over through HBM",
+                      "wave_f64_n10_s2": "srbdqp_setup1_kernel<10,2,true>: the whole solve on one wave per QP",
+                      "compact_f64_n10_s2": "srbdqp_compact_kernel<10,2>: the whole solve on 4 waves per QP"}[name],
          "batch_per_launch": B,
          "workload": "bench.py --streams 1 (configs[1]: B=4096, N=10, 2-contact, fp64; longest-first hint on); one launch at a time",
          "command": "tools/pmc_collect.sh (one rocprofv3 --pmc <group> --kernel-trace pass per counter group) + rocprofv3 --kernel-trace --stats on the same bench command",
@@ -46,7 +50,7 @@ def main():
                  "algorithmic_bytes_per_launch": alg,
                  "handover_bytes_per_launch_expected": None,
                  "note": "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled per MI355X_MICROARCH.md (HBM section); WRITE_SIZE taken as is. "
-                         "In the split pipeline the traffic above the algorithmic bytes is the hand-over of K^-1 and the persistent strip between the two kernels (written once, read once)."},
+                         "In the split pipeline the traffic above the algorithmic bytes is the hand-over of K^-1 and the persistent strip between the two kernels (written once, read once); the wave and compact kernels have no hand-over."},
          "kernels": kernels,
          "notes": "SQ_* are summed over the chip; SQ_ACTIVE_INST_*/SQ_WAVE_CYCLES/SQ_WAIT_* are in 4-cycle quads; GRBM_GUI_ACTIVE is summed over the 8 XCDs."}
     json.dump(d, open(out, "w"), indent=1)
