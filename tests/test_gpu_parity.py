@@ -198,7 +198,7 @@ def test_schedule_hint_only_reorders_work(torch_first, built_lib):
         np.testing.assert_array_equal(st, outs[0][2])
 
 
-@pytest.mark.parametrize("N,pattern,B", [(10, "single", 2048), (10, "mixed", 1024), (10, "random", 1024), (8, "random", 512), (16, "single", 256)])
+@pytest.mark.parametrize("N,pattern,B", [(10, "single", 2048), (10, "mixed", 1024), (10, "random", 1024), (8, "random", 512), (8, "single", 1024), (4, "random", 1024), (16, "single", 256)])
 def test_large_batch_against_c_oracle(torch_first, built_lib, N, pattern, B):
     """Statistical parity at scale against the compiled oracle: every QP of a large seeded batch, including arbitrary
     per-point contact patterns (steps with 0, 1 or 3 stance points, whole-horizon flight)."""
