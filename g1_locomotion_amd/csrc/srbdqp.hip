@@ -362,7 +362,7 @@ int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int m
     a2.rho_qp = slot->rho;
     a2.warm_u = a1.u_out;                                   // newtons, as a caller's warm start would be
     a2.warm_y = a1.y_out;
-    a2.max_iter = h->cfg.max_iter;
+    a2.max_iter = h->cfg.max_iter - a1.max_iter;            // the cap is on the total
     a2.iters_base = a1.max_iter;
     a2.resid_out = nullptr;
     a2.qp_span = B;

@@ -77,8 +77,8 @@ typedef struct srbdqp_config {
                                     * <= 2 selects the smaller, higher-occupancy kernel instantiation. */
     int32_t rho_restart_iter;     /* one OSQP-style re-balancing of rho: a QP that has not converged after this many
                                    * iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual))
-                                   * (clipped to [rho/10, 10 rho]) and continues from its own (x, y) for up to max_iter
-                                   * more iterations; iters[] counts both passes.  0 (default) or >= max_iter = off.  Compact and
+                                   * (clipped to [rho/10, 10 rho]) and continues from its own (x, y) until max_iter
+                                   * iterations in total; iters[] counts both passes.  0 (default) or >= max_iter = off.  Compact and
                                    * split kernels only.  Per device-API launch at most max(64, B/4) QPs are restarted. */
     int32_t reserved0;
     double dt;                    /* run_simulation.py:169 */

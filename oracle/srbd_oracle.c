@@ -186,7 +186,7 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
     int status = 2, iters = 0, vote_ok = 1, iters_base = 0;
     const int restart = (p->eliminate_swing && p->rho_restart_iter > 0 && p->rho_restart_iter < p->max_iter) ? p->rho_restart_iter : 0;
     for (int pass = 0; pass < 2; ++pass) {
-    const int cap = (pass == 0 && restart) ? restart : p->max_iter;
+    const int cap = (pass == 0 && restart) ? restart : p->max_iter - iters_base;   /* the cap is on the total */
     for (int i = 0; i < nr; ++i) for (int j = 0; j < nr; ++j) K[(size_t)i * nr + j] = P[(size_t)VIDX(i) * n + VIDX(j)];
     for (int e_ = 0; e_ < nc; ++e_) {
         const int r0 = 5 * e_, c0 = 3 * e_;

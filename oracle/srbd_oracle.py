@@ -77,7 +77,7 @@ class SrbdParams:
     check_every: int = 5
     # one OSQP-style re-balancing of rho (presolved path only): a QP that has not converged after rho_restart_iter
     # iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual)), clipped to [rho/10, 10 rho] (wider clips stop further from the optimum on the same residual test), and
-    # continues from its own (x, y) for up to max_iter more iterations.  0 (or >= max_iter) = off = the default (100 solves
+    # continues from its own (x, y) until max_iter iterations in total.  0 (or >= max_iter) = off = the default (100 solves
     # 99.9 % instead of 99.4 % of the config-2 QPs; on the GPU the second pass costs ~20 % of the batch throughput).
     rho_restart_iter: int = 0
     # presolve: variables of swing contacts (force clamped to 0) are eliminated before the ADMM (kernel v2);
@@ -386,7 +386,8 @@ def solve_with_restart(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, d
         return x, z, y, it, st
     s = dtype(p.force_scale)
     xw = (x * s) / s          # the second pass re-reads the first pass's forces in newtons
-    x, z, y, it2, st = admm_solve(replace(p, rho=restart_rho(p, info)), P, q, A, l, u, xw, y, dtype=dtype)
+    x, z, y, it2, st = admm_solve(replace(p, rho=restart_rho(p, info), max_iter=p.max_iter - p.rho_restart_iter), P, q, A, l, u, xw, y,
+                                  dtype=dtype)          # the cap is on the total
     return x, z, y, p.rho_restart_iter + it2, st
 
 
