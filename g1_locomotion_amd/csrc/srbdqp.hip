@@ -184,6 +184,7 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     }
     if ((h->cfg.flags & SRBDQP_FLAG_TIMING) && !a.count_ptr) { HIP_TRY(h, hipEventRecord(h->ev_mid, st)); h->ev_mid_valid = true; }
     hipLaunchKernelGGL((srbdqp::srbdqp_admm_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), ldsB, st, a);
+    HIP_TRY(h, hipGetLastError());
     return SRBDQP_OK;
 }
 
@@ -195,6 +196,7 @@ int launch_wave(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     static const std::string nm = "wave_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
     hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
+    HIP_TRY(h, hipGetLastError());
     return SRBDQP_OK;
 }
 
@@ -356,6 +358,7 @@ int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int m
     const int grid2 = (B <= 64) ? B : ((B / 4 > 64) ? B / 4 : 64);
     hipLaunchKernelGGL(srbdqp_restart_select_kernel, dim3(1), dim3(1024), 0, st, a1.status, slot->resid, B, h->cfg.rho,
                        slot->list, slot->count, slot->rho, grid2);
+    HIP_TRY(h, hipGetLastError());
     KArgs a2 = a1;
     a2.perm = slot->list;
     a2.count_ptr = slot->count;
