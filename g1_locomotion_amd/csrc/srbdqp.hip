@@ -204,7 +204,7 @@ template <int N, int MAXS>
 int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     if constexpr (srbdqp::Setup1Smem<N, MAXS>::supported) {
         const bool want = h->cfg.kernel == SRBDQP_KERNEL_WAVE || (h->cfg.kernel == SRBDQP_KERNEL_AUTO && a.B >= kSplitMinBatch);
-        if (want && a.mode == 0 && !a.stamps && !a.done_flag) return launch_wave<N, MAXS>(h, a, st);
+        if (want && a.mode == 0 && (!a.stamps || h->cfg.kernel == SRBDQP_KERNEL_WAVE) && !a.done_flag) return launch_wave<N, MAXS>(h, a, st);
     }
     if constexpr (srbdqp::SplitWs<N, MAXS>::supported) {
         if (h->cfg.kernel == SRBDQP_KERNEL_SPLIT && a.mode == 0 && !a.stamps && !a.done_flag) return launch_split<N, MAXS>(h, a, st);

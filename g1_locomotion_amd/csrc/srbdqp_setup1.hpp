@@ -18,6 +18,16 @@
 
 namespace srbdqp {
 
+// phase stamps of the wave kernel only in diagnostic builds (tools/build_variant.sh -DSRBDQP_WAVE_STAMPS): the stamp
+// code costs registers even when the stamp buffer is null
+#ifdef SRBDQP_WAVE_STAMPS
+#define WSTAMP(a, b, idx) SRBDQP_STAMP(a, b, idx)
+#define WSTAMP_RT(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WSTAMP(a, b, idx) do { } while (0)
+#define WSTAMP_RT(a, b, idx) do { } while (0)
+#endif
+
 // LDS of one wave: [0, S::o_R) the persistent strip with the offsets of CompactSmem (the ADMM kernel reads it back from
 // the workspace), then the phase-A arrays with their lifetimes shared: inputs -> error vector / warm-start vectors ->
 // the transpose tile of the factorisation.
@@ -76,6 +86,8 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     const double* CP = sm + L1::o_cp;
 
     // ================= load + linearise (a5) =================
+    WSTAMP(a, b, 0);
+    WSTAMP_RT(a, b, 12);
     {
         const double* gx0 = a.x0 + (size_t)b * 13;
         const double* gxr = a.xref + (size_t)b * N * 13;
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         return;
     }
 
+    WSTAMP(a, b, 1);
     // ================= closed-form tables, gradient, warm-start P x^0 (see srbdqp_compact.hpp, phase A) =================
     const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = dt2 * a.inv_mass;
     double* T1 = sm + L1::o_t1;
@@ -225,6 +238,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         MT[idx] = v;
     }
     __syncthreads();
+    WSTAMP(a, b, 2);
     for (int c = lane; c < n_eff; c += 64) sm[S::o_q + c] = gt_eval(c);
     if (a.warm_u) {
         double* TF = sm + L1::o_tf;
@@ -277,6 +291,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         for (int c = lane; c < n_eff; c += 64) sm[S::o_px0 + c] = 0.0;
     }
 
+    WSTAMP(a, b, 3);
     // ================= K = G'G + R s^2 + sigma + A' rho A: every entry of the upper tiles straight into registers =========
     v4d Kt[NT][NT];
     {
@@ -312,6 +327,8 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         }
     }
     __syncthreads();   // the phase-A arrays are dead; the scratch tile is used from here on
+    WSTAMP(a, b, 4);
+    WSTAMP(a, b, 5);
 
     // A-operand form of a C-layout tile X (operand[r] at lane (i, k') = X[i][4r + k']): through the wave-private tile
     double* scr = sm + L1::o_scr;
@@ -358,6 +375,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         }
     }
     if (!all_ok && lane == 0) sm[S::o_misc] = 1.0;
+    WSTAMP(a, b, 6);
 
     // ================= W = L^-1, block row by block row, W_ij (i > j) into the slot of U_ji =================
 #pragma unroll
@@ -380,6 +398,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         }
     }
 
+    WSTAMP(a, b, 7);
     // ================= I: K^-1 = W'W tile by tile; split: stored as produced, fused: one row per lane =================
     double kin[W::KS];
     if constexpr (!FUSED) {
@@ -435,7 +454,12 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
 #pragma unroll
         for (int c = 0; c < W::KS; ++c) kin[c] = (lane < n_eff && c < n_eff) ? kin[c] : 0.0;
         __syncthreads();
+        WSTAMP(a, b, 8);
+        WSTAMP(a, b, 9);
         admm_wave_body<N, MAXS>(a, b, rho_b, sm, kin);
+        WSTAMP(a, b, 10);
+        WSTAMP(a, b, 11);
+        WSTAMP_RT(a, b, 13);
     }
 }
 
