@@ -52,7 +52,8 @@ struct Setup1Smem {
     static constexpr int o_gx = o_foot;
     static constexpr int o_scr = o_xref;
     static constexpr int endIn = o_pcom + up2(N * 3);
-    static constexpr int o_end = (endIn > o_scr + 256) ? endIn : o_scr + 256;
+    static constexpr int endIn2 = (endIn > o_scr + 256) ? endIn : o_scr + 256;
+    static constexpr int o_end = (endIn2 > o_cp + S::NT * 256) ? endIn2 : o_cp + S::NT * 256;   // K^-1 block-column staging (wave kernel)
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr bool supported = SplitWs<N, MAXS>::supported && S::NT <= 4;
     static_assert(n + 6 * N <= o_end - o_eh || true, "");
@@ -296,33 +297,47 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     v4d Kt[NT][NT];
     {
         const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
+        // per-axis diagonal weights of the p and v rows, and the data of this lane's NT columns (contact step, J column)
+        const double wp0 = SQ[3] * SQ[3] * dt4m2, wp1 = SQ[4] * SQ[4] * dt4m2, wp2 = SQ[5] * SQ[5] * dt4m2;
+        const double wv0 = SQ[9] * SQ[9] * dt2m2, wv1 = SQ[10] * SQ[10] * dt2m2, wv2 = SQ[11] * SQ[11] * dt2m2;
+        int cstep[NT], cax[NT];
+        double cJ[NT][3];
 #pragma unroll
         for (int tb = 0; tb < NT; ++tb) {
-            const int c = 16 * tb + mcol;
+            const int c = 16 * tb + mcol, cc = (c < n_eff) ? c : 0;
+            const int e = cc / 3, ax = cc - 3 * e, g = act[e];
+            const double* J = sm + S::o_J + (g >> 2) * 36 + 3 * (g & 3) + ax;
+            cstep[tb] = g >> 2; cax[tb] = ax;
+            cJ[tb][0] = J[0]; cJ[tb][1] = J[12]; cJ[tb][2] = J[24];
+        }
 #pragma unroll
-            for (int ta = 0; ta <= tb; ++ta) {
+        for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = 16 * ta + kq + 4 * q;
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * ta + kq + 4 * q, rr = (r < n_eff) ? r : 0;
+                const int er = rr / 3, axr = rr - 3 * er, gr = act[er], jr = gr >> 2;
+                const double* Jr = sm + S::o_J + jr * 36 + 3 * (gr & 3) + axr;
+                const double r0 = Jr[0], r1 = Jr[12], r2 = Jr[24];
+#pragma unroll
+                for (int tb = ta; tb < NT; ++tb) {
+                    const int c = 16 * tb + mcol;
                     const bool in = (r < n_eff) && (c < n_eff);
-                    const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;
-                    const int e1 = lo / 3, a1 = lo - 3 * e1, e2 = hi / 3, a2 = hi - 3 * e2;
-                    const int g1 = act[e1], g2 = act[e2], j = g1 >> 2, mm = g2 >> 2;
-                    const double* J1 = sm + S::o_J + j * 36 + 3 * (g1 & 3) + a1;
-                    const double* J2 = sm + S::o_J + mm * 36 + 3 * (g2 & 3) + a2;
-                    const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
-                    const double x0 = J2[0], x1 = J2[12], x2 = J2[24];
-                    double v = J1[0] * (M[0] * x0 + M[1] * x1 + M[2] * x2) + J1[12] * (M[3] * x0 + M[4] * x1 + M[5] * x2) +
-                               J1[24] * (M[6] * x0 + M[7] * x1 + M[8] * x2);
-                    const int Ls = N - mm, d = mm - j;
+                    const bool rlo = (r <= c) || !in;                    // the row variable is the earlier contact
+                    const int jlo = rlo ? jr : cstep[tb], mhi = rlo ? cstep[tb] : jr;
+                    const double l0 = rlo ? r0 : cJ[tb][0], l1 = rlo ? r1 : cJ[tb][1], l2 = rlo ? r2 : cJ[tb][2];
+                    const double h0 = rlo ? cJ[tb][0] : r0, h1 = rlo ? cJ[tb][1] : r1, h2 = rlo ? cJ[tb][2] : r2;
+                    const double* M = MT + 9 * (mhi * (mhi + 1) / 2 + jlo);
+                    double v = l0 * (M[0] * h0 + M[1] * h1 + M[2] * h2) + l1 * (M[3] * h0 + M[4] * h1 + M[5] * h2) +
+                               l2 * (M[6] * h0 + M[7] * h1 + M[8] * h2);
+                    const int Ls = N - mhi, d = mhi - jlo;
                     const int sp = ((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2);
-                    const double same = (a1 == a2) ? 1.0 : 0.0;
-                    v = fma(same, SQ[3 + a1] * SQ[3 + a1] * dt4m2 * (double)sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * (double)Ls, v);
+                    const double wp = (axr == 0) ? wp0 : (axr == 1) ? wp1 : wp2, wv = (axr == 0) ? wv0 : (axr == 1) ? wv1 : wv2;
+                    v = fma((axr == cax[tb]) ? 1.0 : 0.0, wp * (double)sp + wv * (double)Ls, v);
                     double val = s2 * v;
-                    val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b) : 0.0;
+                    val += (r == c) ? a.rs2 + a.sigma + ((axr < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b) : 0.0;
                     Kt[ta][tb][q] = in ? val : ((r == c) ? 1.0 : 0.0);     // padding -> identity
-                    if (q & 1) asm volatile("" ::: "memory");              // bounds the LDS reads in flight (register budget)
                 }
+                asm volatile("" ::: "memory");                              // bounds the LDS reads in flight (register budget)
             }
         }
     }
@@ -403,25 +418,19 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     double kin[W::KS];
     if constexpr (!FUSED) {
         for (int i = lane; i < S::o_R; i += 64) ws[i] = sm[i];
-    } else {
+        double* kinv = ws + W::o_kinv;
 #pragma unroll
-        for (int c = 0; c < W::KS; ++c) kin[c] = 0.0;
-    }
-    double* kinv = FUSED ? nullptr : ws + W::o_kinv;
-    const int grp = lane >> 4;                               // tile row of this lane's K^-1 row
+        for (int aa = 0; aa < NT; ++aa) {
 #pragma unroll
-    for (int aa = 0; aa < NT; ++aa) {
+            for (int bb = aa; bb < NT; ++bb) {
+                v4d o = zero4;                               // sum_{k >= b} W_ka' W_kb
 #pragma unroll
-        for (int bb = aa; bb < NT; ++bb) {
-            v4d o = zero4;                                   // sum_{k >= b} W_ka' W_kb
+                for (int k = bb; k < NT; ++k) {
+                    const v4d& wka = (k == aa) ? Kt[aa][aa] : Kt[aa][k];
+                    const v4d& wkb = (k == bb) ? Kt[bb][bb] : Kt[bb][k];
 #pragma unroll
-            for (int k = bb; k < NT; ++k) {
-                const v4d& wka = (k == aa) ? Kt[aa][aa] : Kt[aa][k];
-                const v4d& wkb = (k == bb) ? Kt[bb][bb] : Kt[bb][k];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o = mfma_f64(wka[r], wkb[r], o);
-            }
-            if constexpr (!FUSED) {
+                    for (int r = 0; r < 4; ++r) o = mfma_f64(wka[r], wkb[r], o);
+                }
                 const int col = 16 * bb + mcol;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -429,25 +438,42 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
                     if (row < n_eff && col < W::KS) kinv[row * W::KS + col] = (col < n_eff) ? o[q] : 0.0;
                     if (aa != bb && col < n_eff && row < W::KS) kinv[col * W::KS + row] = (row < n_eff) ? o[q] : 0.0;
                 }
-            } else {
-                // tile -> rows: lanes of tile row aa take row (lane & 15), lanes of tile row bb take column (lane & 15)
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int q = 0; q < 4; ++q) scr[(kq + 4 * q) * 16 + mcol] = o[q];
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    if (16 * bb + jj < W::KS) {
-                        const double v = scr[mcol * 16 + jj];
-                        kin[16 * bb + jj] = (grp == aa) ? v : kin[16 * bb + jj];
-                    }
-                    if (aa != bb && 16 * aa + jj < W::KS) {
-                        const double v = scr[jj * 16 + mcol];
-                        kin[16 * aa + jj] = (grp == bb) ? v : kin[16 * aa + jj];
-                    }
-                }
-                asm volatile("" ::: "memory");
             }
+        }
+    } else {
+        // one K^-1 row per lane: for every block column cb all NT blocks (g, cb) are produced directly in C layout
+        // ((g, cb) with g > cb is the same product with the operands swapped -- no transposes), staged as NT row-major
+        // tiles in the dead phase-A arrays, and lane (g, i) pulls row i of tile g with 16-byte reads
+        double* stg = sm + L1::o_cp;
+        static_assert(L1::o_end - L1::o_cp >= NT * 256, "staging of one block column of K^-1");
+        const int grp = lane >> 4;
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < NT; ++g) {
+                v4d o = zero4;                               // sum_{k >= max(g, cb)} W_kg' W_k,cb
+#pragma unroll
+                for (int k = (g > cb ? g : cb); k < NT; ++k) {
+                    const v4d& wkg = (k == g) ? Kt[g][g] : Kt[g][k];
+                    const v4d& wkc = (k == cb) ? Kt[cb][cb] : Kt[cb][k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o = mfma_f64(wkg[r], wkc[r], o);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) stg[g * 256 + (kq + 4 * q) * 16 + mcol] = o[q];
+            }
+            asm volatile("" ::: "memory");
+            const double2* rowp = reinterpret_cast<const double2*>(stg + grp * 256 + mcol * 16);
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                if (16 * cb + 2 * h + 1 < W::KS + 1) {
+                    const double2 v = rowp[h];
+                    if (16 * cb + 2 * h < W::KS) kin[16 * cb + 2 * h] = v.x;
+                    if (16 * cb + 2 * h + 1 < W::KS) kin[16 * cb + 2 * h + 1] = v.y;
+                }
+            }
+            asm volatile("" ::: "memory");
         }
     }
     if constexpr (FUSED) {
