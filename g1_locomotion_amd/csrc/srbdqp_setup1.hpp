@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
                 for (int tb = ta; tb < NT; ++tb) {
                     const int c = 16 * tb + mcol;
                     const bool in = (r < n_eff) && (c < n_eff);
-                    const bool rlo = (r <= c) || !in;                    // the row variable is the earlier contact
+                    const bool rlo = (tb > ta) || (r <= c) || !in;       // the row variable is the earlier contact (always, off the diagonal tiles)
                     const int jlo = rlo ? jr : cstep[tb], mhi = rlo ? cstep[tb] : jr;
                     const double l0 = rlo ? r0 : cJ[tb][0], l1 = rlo ? r1 : cJ[tb][1], l2 = rlo ? r2 : cJ[tb][2];
                     const double h0 = rlo ? cJ[tb][0] : r0, h1 = rlo ? cJ[tb][1] : r1, h2 = rlo ? cJ[tb][2] : r2;
