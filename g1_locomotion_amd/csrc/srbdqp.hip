@@ -148,9 +148,12 @@ int set_lds_once(srbdqp_handle* h, K kernel, size_t lds, bool& done) {
     return SRBDQP_OK;
 }
 
-// Large batches of the small instantiations run as two kernels (srbdqp_split.hpp): set-up at 4 workgroups per CU,
-// then the ADMM iterations with one wave per QP.  Small batches (latency), diagnostics and the staged path stay fused.
+// Batches of at least this many QPs of the small instantiations (<= 64 presolved variables) run with one wave per QP
+// (launch_wave); smaller ones, the staged path and the big instantiations use the 4-wave kernel.  Measured cross-over of
+// the per-call time (tools/threshold_probe.py): 512.
 constexpr int kSplitMinBatch = 512;
+
+// KERNEL_SPLIT (A/B): the one-wave set-up and the one-wave ADMM as two kernels with the hand-over through HBM.
 
 template <int N, int MAXS>
 int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
