@@ -347,3 +347,30 @@ def test_rho_restart_on_the_staged_batch1_path(torch_first, built_lib):
         assert MPC.status == refs[b]["status"] and abs(MPC.iters - refs[b]["iters"]) <= p.check_every, (b, MPC.iters, refs[b]["iters"])
         assert np.abs(MPC.u_opt - refs[b]["u"]).max() <= 2 * TOL_TWIN_N
     MPC.close()
+
+
+def test_wave_kernel_with_ragged_contact_counts(torch_first, built_lib):
+    """The one-wave kernel with fewer stance contacts than its template bound: single-support schedules with contacts
+    dropped at random (0, 1 or 2 stance points per step, so n_eff varies from QP to QP and the tiles are padded)."""
+    import c_oracle
+    from g1_locomotion_amd import _lib
+    N, B = 10, 1024
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=4300, schedule="single")
+    rng = np.random.default_rng(23)
+    ct = (ct.astype(bool) & (rng.random(ct.shape) < 0.8)).astype(np.uint8)
+    ct[0] = 0                                                       # flight
+    ct[1, 1:] = 0                                                   # contact only in the first step
+    p = orc.SrbdParams()
+    ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
+    for kid, name in ((_lib.KERNEL_WAVE, "wave_"), (_lib.KERNEL_SPLIT, "split_")):
+        with _engine(N, kernel=kid, max_contacts_per_step=2) as eng:
+            out = eng.solve(x0, xr, ft, ct)
+            assert eng.kernel_name().startswith(name)
+        np.testing.assert_array_equal(out["status"], ref["status"])
+        assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
+        same = out["iters"] == ref["iters"]
+        assert same.mean() > 0.97
+        err = np.abs(out["u"] - ref["u"]).reshape(B, -1).max(1)
+        assert err[same].max() <= 1e-4 and err.max() <= TOL_TWIN_N, (err[same].max(), err.max())
+        assert np.abs(out["x"] - ref["x"]).max() <= 1e-5
+        assert np.all(out["u"].reshape(B, N, 4, 3)[ct == 0] == 0.0)
