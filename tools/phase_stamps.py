@@ -10,7 +10,7 @@ import srbd_oracle as orc
 
 names = ["linearise", "tables", "gradient", "K assembly", "barrier", "F(chol)", "W", "I", "frag", "ADMM", "rollout"]
 for B in (1, 4096):
-    x0, xr, ft, ct = orc.synthetic_batch(B, 10, 2000, "single")
+    x0, xr, ft, ct = orc.synthetic_batch(B, 10, 2000, os.environ.get("SCHED", "single"))
     dev = torch.device("cuda", 0)
     d = [torch.from_numpy(v).to(dev) for v in (x0, xr, ft, ct)]
     u = torch.empty((B, 10, 12), dtype=torch.float64, device=dev)
