@@ -48,8 +48,8 @@ def algorithmic_bytes(N: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="QPs per GPU per step (default: configs[1])")
     ap.add_argument("--kernel", choices=["auto", "gj", "mfma", "compact", "split", "wave"], default="auto",
                     help="auto = wave (one wave per QP) for this batch size; split = the same as two kernels; compact = the 4-wave fused kernel")
