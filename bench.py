@@ -283,7 +283,28 @@ def cpu_baseline(orc, x0, xr, ft, ct):
     for _ in range(reps):
         c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=cores)
     tall = (time.perf_counter() - t) / reps
+    # the NumPy oracle (the "Python path" stand-in of SURVEY 8d) on a handful of QPs, and OSQP itself if this box has it
+    t = time.perf_counter()
+    for b in range(16):
+        orc.update(p, x0[b], xr[b], ft[b], ct[b])
+    t_np = (time.perf_counter() - t) / 16
+    osqp_rate = None
+    try:
+        import osqp                                           # not installed in the build image; probed, never assumed
+        import scipy.sparse as sp
+        ts = []
+        for b in range(16):
+            qp = orc.build_qp(p, x0[b], xr[b], ft[b], ct[b])
+            red, _, _ = orc.presolve(qp, ct[b])
+            m = osqp.OSQP()
+            m.setup(P=sp.csc_matrix(np.triu(red["P"])), q=red["q"], A=sp.csc_matrix(red["A"]), l=red["l"], u=red["u"], verbose=False,
+                    eps_abs=p.eps_abs, eps_rel=p.eps_rel, max_iter=4000, polish=False)
+            t = time.perf_counter(); m.solve(); ts.append(time.perf_counter() - t)
+        osqp_rate = 1.0 / float(np.median(ts))
+    except Exception:
+        osqp_rate = None
     return {"value": Sall / tall, "unit": "QP/s", "cores": cores, "kind": "port",
+            "numpy_oracle_qp_per_s": 1.0 / t_np, "osqp_qp_per_s": osqp_rate,
             "sample": f"the {Sall} QPs of the rank-0 batch x {reps} repetitions on {cores} threads = this box's CPU quota (cgroup cpu.max; the affinity mask shows {len(os.sched_getaffinity(0))}) (plain-C port oracle/srbd_oracle.c of the same algorithm incl. presolve, gcc -O3 -mavx2)",
             "single_thread_value": S1 / t1, "single_thread_sample": f"first {S1} QPs, 1 thread",
             "single_thread_p50_us": 1e6 * t1 / S1}
