@@ -362,10 +362,17 @@ def test_wave_kernel_with_ragged_contact_counts(torch_first, built_lib):
     ct[1, 1:] = 0                                                   # contact only in the first step
     p = orc.SrbdParams()
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
+    ct_bad = ct.copy()
+    ct_bad[2] = 1                                                   # double support under a promise of <= 2 contacts per step
     for kid, name in ((_lib.KERNEL_WAVE, "wave_"), (_lib.KERNEL_SPLIT, "split_")):
         with _engine(N, kernel=kid, max_contacts_per_step=2) as eng:
             out = eng.solve(x0, xr, ft, ct)
             assert eng.kernel_name().startswith(name)
+            bad = eng.solve(x0, xr, ft, ct_bad)
+        assert bad["status"][2] == _lib.CONTACT_BOUND and np.all(bad["u"][2] == 0.0) and bad["iters"][2] == 0
+        keep = np.arange(B) != 2
+        np.testing.assert_array_equal(bad["status"][keep], out["status"][keep])
+        np.testing.assert_array_equal(bad["u"][keep], out["u"][keep])
         np.testing.assert_array_equal(out["status"], ref["status"])
         assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
         same = out["iters"] == ref["iters"]
