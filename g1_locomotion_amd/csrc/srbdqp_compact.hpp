@@ -282,6 +282,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
 #ifdef SRBDQP_PROFILE_ADMM
     if (a.stamps && t == 0) { long long* st = a.stamps + (size_t)b * 16; st[12] = seg0; st[13] = seg1; st[14] = seg2; st[15] = seg3; st[1] = seg4; }
 #endif
+    if (status < 0) { x = 0.0; y = 0.0; }                               // a numerical failure returns zero forces, never NaN
     if (active && hp == 0) xs_full[3 * gc + ax] = x;
     if (a.y_out && has_row) a.y_out[(size_t)b * m + irow] = y;
     if (a.resid_out && status == 2 && t == 0) {

@@ -145,7 +145,7 @@ __device__ __forceinline__ void diag16_block(v4d& s, v4d& rr, v4d& w, double& pm
     const double r23 = fma(-r12, r13, fma(-r02, r03, d23)) * x22;
     const double p3 = fma(-r23, r23, fma(-r13, r13, fma(-r03, r03, d33)));
     const double x33 = fast_rsqrt(p3);
-    pmin = fmin(pmin, fmin(fmin(d00, p1), fmin(p2, p3)));
+    pmin = (d00 > 0.0 && p1 > 0.0 && p2 > 0.0 && p3 > 0.0) ? pmin : -1.0;   // (a NaN pivot fails the comparison too)
     const double x01 = -x00 * r01 * x11;
     const double x12 = -x11 * r12 * x22;
     const double x23 = -x22 * r23 * x33;

@@ -155,6 +155,7 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
             float* ro = a.resid_out + (size_t)b * 4;
             ro[0] = lastv0; ro[1] = lastv1; ro[2] = lastv2; ro[3] = lastv3;
         }
+        if (status < 0) { x = 0.0; yA = 0.0; yB = 0.0; }                    // a numerical failure returns zero forces, never NaN
         if (active) xs_full[3 * gc + ax] = x;
         if (a.y_out) {
             if (rowA) a.y_out[(size_t)b * m + irowA] = yA;

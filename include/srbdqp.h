@@ -43,8 +43,8 @@ extern "C" {
 /* per-QP status[] values */
 #define SRBDQP_SOLVED    1        /* primal and dual residual below tolerance */
 #define SRBDQP_MAX_ITER  2        /* iteration cap reached; best iterate returned */
-#define SRBDQP_NUMERICAL (-1)     /* non-finite residual / non-positive pivot */
-#define SRBDQP_CONTACT_BOUND (-2) /* more stance contacts in a step than srbdqp_config.max_contacts_per_step allows */
+#define SRBDQP_NUMERICAL (-1)     /* non-finite residual / non-positive pivot (e.g. NaN inputs); forces returned as 0 */
+#define SRBDQP_CONTACT_BOUND (-2) /* more stance contacts in a step than srbdqp_config.max_contacts_per_step allows; forces 0 */
 
 /* srbdqp_config.flags */
 #define SRBDQP_FLAG_TIMING 1      /* bracket every kernel launch with HIP events (srbdqp_last_kernel_ms) */

@@ -381,3 +381,22 @@ def test_wave_kernel_with_ragged_contact_counts(torch_first, built_lib):
         assert err[same].max() <= 1e-4 and err.max() <= TOL_TWIN_N, (err[same].max(), err.max())
         assert np.abs(out["x"] - ref["x"]).max() <= 1e-5
         assert np.all(out["u"].reshape(B, N, 4, 3)[ct == 0] == 0.0)
+
+
+def test_non_finite_input_is_reported_not_propagated(torch_first, built_lib):
+    """A NaN in one QP's inputs (here a foot position) must come back as SRBDQP_NUMERICAL for that QP only -- on the
+    one-wave batch kernel and on the 4-wave kernel."""
+    from g1_locomotion_amd import _lib
+    N, B = 10, 600
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=4400, schedule="single")
+    ft_bad = ft.copy()
+    ft_bad[7, 3, 3 * int(np.argmax(ct[7, 3])) + 1] = np.nan              # a STANCE contact's position (swing ones are not used)
+    for kid in (_lib.KERNEL_AUTO, _lib.KERNEL_COMPACT):
+        with _engine(N, kernel=kid, max_contacts_per_step=2) as eng:
+            good = eng.solve(x0, xr, ft, ct)
+            bad = eng.solve(x0, xr, ft_bad, ct)
+        assert bad["status"][7] == _lib.NUMERICAL, bad["status"][7]
+        keep = np.arange(B) != 7
+        np.testing.assert_array_equal(bad["status"][keep], good["status"][keep])
+        np.testing.assert_array_equal(bad["u"][keep], good["u"][keep])
+        assert np.all(np.isfinite(bad["u"][keep])) and np.all(bad["u"][7] == 0.0)
