@@ -400,3 +400,23 @@ def test_non_finite_input_is_reported_not_propagated(torch_first, built_lib):
         np.testing.assert_array_equal(bad["status"][keep], good["status"][keep])
         np.testing.assert_array_equal(bad["u"][keep], good["u"][keep])
         assert np.all(np.isfinite(bad["u"][keep])) and np.all(bad["u"][7] == 0.0)
+
+
+def test_explicit_com_horizon_on_the_batch_kernel(torch_first, built_lib):
+    """p_com_horizon given explicitly (run_simulation.py:103) instead of taken from x_ref: the lever arms change, on the
+    one-wave kernel and on the 4-wave kernel alike."""
+    import c_oracle
+    from g1_locomotion_amd import _lib
+    N, B = 10, 600
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=4500, schedule="single")
+    pc = xr[:, :, 3:6] + np.random.default_rng(31).uniform(-0.03, 0.03, (B, N, 3))
+    p = orc.SrbdParams()
+    ref = c_oracle.solve_batch(p, x0, xr, ft, ct, pcom=pc, nthreads=8)
+    ref0 = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
+    assert np.abs(ref["u"] - ref0["u"]).max() > 1.0                 # the explicit CoM horizon matters
+    for kid in (_lib.KERNEL_AUTO, _lib.KERNEL_COMPACT):
+        with _engine(N, kernel=kid, max_contacts_per_step=2) as eng:
+            out = eng.solve(x0, xr, ft, ct, pcom=pc)
+        np.testing.assert_array_equal(out["status"], ref["status"])
+        assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
+        assert np.abs(out["u"] - ref["u"]).max() <= TOL_TWIN_N and np.abs(out["x"] - ref["x"]).max() <= 1e-5
