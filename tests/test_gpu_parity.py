@@ -420,3 +420,27 @@ def test_explicit_com_horizon_on_the_batch_kernel(torch_first, built_lib):
         np.testing.assert_array_equal(out["status"], ref["status"])
         assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
         assert np.abs(out["u"] - ref["u"]).max() <= TOL_TWIN_N and np.abs(out["x"] - ref["x"]).max() <= 1e-5
+
+
+def test_non_default_constants_reach_every_kernel(torch_first, built_lib):
+    """No constant of the problem is baked into a kernel: a different dt, mass, inertia, friction, force bounds, weights,
+    scaling and ADMM parameters -- against the oracle with the same values, on the one-wave and the 4-wave kernel."""
+    import c_oracle
+    from g1_locomotion_amd import _lib
+    N, B = 10, 600
+    kw = dict(dt=0.03, mass=41.0, inertia=(0.11, 0.09, 0.006), mu=0.55, fz_min=5.0, fz_max=420.0,
+              q_diag=(250.0, 320.0, 120.0, 380.0, 410.0, 700.0, 2.0, 1.5, 1.0, 15.0, 25.0, 30.0, 0.0), r_diag=3.0e-4,
+              force_scale=60.0, rho=0.8, alpha=1.5, sigma=2.0e-6, eps_abs=2.0e-6, eps_rel=2.0e-6, max_iter=180, check_every=4)
+    p = orc.SrbdParams(**kw)
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=4600, schedule="single", dt=kw["dt"])
+    ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
+    for kid in (_lib.KERNEL_AUTO, _lib.KERNEL_COMPACT):
+        with _engine(N, kernel=kid, max_contacts_per_step=2, **kw) as eng:
+            out = eng.solve(x0, xr, ft, ct)
+        np.testing.assert_array_equal(out["status"], ref["status"])
+        assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
+        same = out["iters"] == ref["iters"]
+        assert same.mean() > 0.95
+        err = np.abs(out["u"] - ref["u"]).reshape(B, -1).max(1)
+        assert err[same].max() <= 1e-3 and err.max() <= 5 * TOL_TWIN_N, (err[same].max(), err.max())
+        assert np.abs(out["x"] - ref["x"]).max() <= 1e-4
