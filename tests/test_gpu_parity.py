@@ -444,3 +444,28 @@ def test_non_default_constants_reach_every_kernel(torch_first, built_lib):
         err = np.abs(out["u"] - ref["u"]).reshape(B, -1).max(1)
         assert err[same].max() <= 1e-3 and err.max() <= 5 * TOL_TWIN_N, (err[same].max(), err.max())
         assert np.abs(out["x"] - ref["x"]).max() <= 1e-4
+
+
+def test_empty_batch_and_null_optional_outputs(torch_first, built_lib):
+    """B = 0 is a no-op; status / iters / x / y are optional on the device API (null pointers), also with the rho
+    restart, which needs statuses internally."""
+    torch = torch_first
+    N = 10
+    with _engine(N) as eng:
+        out = eng.solve(np.zeros((0, 13)), np.zeros((0, N, 13)), np.zeros((0, N, 12)), np.zeros((0, N, 4), np.uint8))
+        assert out["u"].shape == (0, N, 12) and out["status"].shape == (0,)
+    B = 700
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=4700, schedule="single")
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(v).to(dev) for v in (x0, xr, ft, ct)]
+    us = []
+    for kw in ({}, {"rho_restart_iter": 100}):
+        with _engine(N, max_contacts_per_step=2, **kw) as eng:
+            u = torch.full((B, N, 12), float("nan"), dtype=torch.float64, device=dev)
+            eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr())   # u only
+            eng.synchronize()
+            full = eng.solve(x0, xr, ft, ct)
+        assert torch.isfinite(u).all()
+        np.testing.assert_array_equal(u.cpu().numpy(), full["u"])
+        us.append(full)
+    assert (us[1]["status"] == orc.STATUS_SOLVED).sum() >= (us[0]["status"] == orc.STATUS_SOLVED).sum()
