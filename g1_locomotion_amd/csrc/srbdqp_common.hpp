@@ -75,7 +75,8 @@ __device__ __forceinline__ void signal_done(const KArgs& a) {
             last = (atomicAdd(a.done_count, 1) == a.B - 1);
             if (last) *a.done_count = 0;
         }
-        if (last) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // relaxed: every thread's outputs were made visible by its own system-scope fence before the barrier
+        if (last) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -130,15 +131,28 @@ __device__ void load_and_linearise(const KArgs& a, int b, double* sm) {
     const double* gft = a.foot + (size_t)b * N * 12;
     const uint8_t* gct = a.contact + (size_t)b * N * 4;
     uint8_t* sct = reinterpret_cast<uint8_t*>(sm + S::o_ct);
-    if (t < 13) sm[S::o_x0 + t] = gx0[t];
+    // Every global load is issued before the first LDS store, branch-free (clamped indices), so that they travel as
+    // ONE batch: on the staged batch-1 path the inputs sit in GPU-mapped host memory and each dependent round is a PCIe
+    // round trip of 1.2 us (tools/pcie_probe.hip) -- five conditional load -> store blocks cost five of them.
+    constexpr int RX = (N * 13 + kThreads - 1) / kThreads, RF = (N * 12 + kThreads - 1) / kThreads;
+    static_assert(N * 4 <= kThreads, "one thread per contact flag");
+    const double* gpc = a.pcom ? a.pcom + (size_t)b * N * 3 : gx0;          // !pcom: a valid address, value unused
+    const double v_x0 = gx0[t < 13 ? t : 0];
+    const uint8_t v_ct = gct[t < N * 4 ? t : 0];
+    const double v_pc = gpc[(a.pcom && t < N * 3) ? t : 0];
+    double v_xr[RX], v_ft[RF];
+#pragma unroll
+    for (int r = 0; r < RX; ++r) { const int i = t + r * kThreads; v_xr[r] = gxr[i < N * 13 ? i : 0]; }
+#pragma unroll
+    for (int r = 0; r < RF; ++r) { const int i = t + r * kThreads; v_ft[r] = gft[i < N * 12 ? i : 0]; }
+    if (t < 13) sm[S::o_x0 + t] = v_x0;
     if (t >= 32 && t < 44) sm[S::o_sq + t - 32] = a.sqrtq[t - 32];
-    for (int i = t; i < N * 13; i += kThreads) sm[S::o_xref + i] = gxr[i];
-    for (int i = t; i < N * 12; i += kThreads) sm[S::o_foot + i] = gft[i];
-    if (t < N * 4) sct[t] = gct[t] ? 1 : 0;
-    if (a.pcom) {
-        const double* gpc = a.pcom + (size_t)b * N * 3;
-        if (t < N * 3) sm[S::o_pcom + t] = gpc[t];
-    }
+#pragma unroll
+    for (int r = 0; r < RX; ++r) { const int i = t + r * kThreads; if (i < N * 13) sm[S::o_xref + i] = v_xr[r]; }
+#pragma unroll
+    for (int r = 0; r < RF; ++r) { const int i = t + r * kThreads; if (i < N * 12) sm[S::o_foot + i] = v_ft[r]; }
+    if (t < N * 4) sct[t] = v_ct ? 1 : 0;
+    if (a.pcom && t < N * 3) sm[S::o_pcom + t] = v_pc;
     __syncthreads();
     if (!a.pcom && t < N * 3) sm[S::o_pcom + t] = sm[S::o_xref + (t / 3) * 13 + 3 + (t % 3)];
     if (t < N) {   // Rz(yaw_k)'

@@ -306,9 +306,12 @@ struct SplitWs {
     static constexpr int doubles = o_kinv + S::nmax * KS;
 };
 
+// One QP (index b) on one 256-thread workgroup; sm = the workgroup's dynamic LDS (CompactSmem<N, MAXS>::bytes).  Called
+// by srbdqp_compact_kernel (one launch per batch) and by the resident kernel (srbdqp_resident.hpp: one workgroup that
+// stays on the device and solves request after request).  Every exit is workgroup-uniform and leaves no state in LDS
+// that the next call relies on.
 template <int N, int MAXS, bool SPLIT = false>
-__global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) void srbdqp_compact_kernel(KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+__device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* sm) {
     using S = CompactSmem<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m;
     constexpr int TS = S::TS, CHMAX = S::CHMAX;
@@ -316,12 +319,6 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     static_assert(2 * S::nmax <= kThreads, "two threads per compact column / row");
     static_assert(4 * N <= 128, "the presolve compacts the 4N contact flags with at most two wave-wide ballots");
     static_assert((S::o_R % 2) == 0 && (S::o_rhs % 2) == 0, "16-byte alignment");
-    if ((int)blockIdx.x >= a.B) return;
-    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) {   // restart pass: nothing listed for this workgroup
-        signal_done(a);
-        return;
-    }
-    const int b = SRBDQP_QP_INDEX(a);
     const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -855,6 +852,17 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
     if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     }   // !SPLIT
+}
+
+template <int N, int MAXS, bool SPLIT = false>
+__global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) void srbdqp_compact_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x >= a.B) return;
+    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) {   // restart pass: nothing listed for this workgroup
+        signal_done(a);
+        return;
+    }
+    compact_qp<N, MAXS, SPLIT>(a, SRBDQP_QP_INDEX(a), sm);
 }
 
 template <int N, int MAXS>

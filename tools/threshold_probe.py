@@ -6,7 +6,7 @@ import numpy as np, torch
 import srbd_oracle as orc
 from g1_locomotion_amd import BatchMPC, _lib
 dev = torch.device("cuda", 0)
-for B in (128, 256, 512, 1024, 1536, 2048, 3072, 4096):
+for B in (1, 8, 32, 128, 256, 512, 1024, 1536, 2048, 3072, 4096):
     x0, xr, ft, ct = orc.synthetic_batch(B, 10, seed=5, schedule="single")
     d = [torch.from_numpy(v).to(dev) for v in (x0, xr, ft, ct)]
     u = torch.empty((B, 10, 12), dtype=torch.float64, device=dev)
