@@ -244,7 +244,22 @@ def latency_batch1(orc, calls=2000):
         ts = np.array(ts[50:]) * 1e6
         out["warm" if warm else "cold"] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
         mpc.close()
-    out["note"] = "warm: x/y warm-started from the previous call of a different QP (shifted plan), cold: from zero"
+    # the C-ABI call alone (inputs already in the staging arrays), at the default tolerance and at OSQP's default 1e-3
+    from g1_locomotion_amd import BatchMPC
+    for name, kw in (("c_abi", {}), ("c_abi_eps1e-3", {"eps_abs": 1e-3, "eps_rel": 1e-3})):
+        with BatchMPC(horizon=HORIZON, **kw) as eng:
+            st = eng.stage()
+            ts = []
+            for i in range(calls + 50):
+                b = i % 64
+                st["x0"][0] = x0[b]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]
+                t = time.perf_counter()
+                eng.solve_staged(1, want_x=True)
+                ts.append(time.perf_counter() - t)
+            ts = np.array(ts[50:]) * 1e6
+            out[name] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
+    out["note"] = ("cold / warm: MPC.update() from zero / from the previous call's shifted plan and duals; c_abi: "
+                   "srbdqp_solve_staged_f64(B=1) alone; eps1e-3: OSQP's default tolerance instead of 1e-6")
     return out
 
 

@@ -125,7 +125,7 @@ def test_mpc_update_drop_in_path(torch_first, built_lib):
     from g1_locomotion_amd import mpc
     N = 10
     x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=55, schedule="double"))
-    MPC = mpc.MPC(dt=0.04)
+    MPC = mpc.MPC(dt=0.04, warm_start=True)
     MPC.init_matrices()
     MPC.x0[:] = x0.reshape(13, 1)
     MPC.x_ref_hor[:] = xr
