@@ -20,13 +20,12 @@ SOLVED, MAX_ITER, NUMERICAL, CONTACT_BOUND = 1, 2, -1, -2
 FLAG_TIMING = 1
 FLAG_NO_SPIN = 2
 FLAG_SETUP4 = 4
-FLAG_RESIDENT = 8
 KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT, KERNEL_SPLIT, KERNEL_WAVE = 0, 1, 2, 3, 4, 5
 
 EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",
     "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_assemble_f64",
-    "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_resident_stop", "srbdqp_resident_running", "srbdqp_resident_last_timing", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
+    "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
 )
@@ -40,7 +39,7 @@ class Config(C.Structure):
     """struct srbdqp_config (include/srbdqp.h)."""
     _fields_ = [
         ("struct_size", C.c_int32), ("horizon", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
-        ("kernel", C.c_int32), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("max_contacts_per_step", C.c_int32), ("rho_restart_iter", C.c_int32), ("resident_idle_ms", C.c_int32),
+        ("kernel", C.c_int32), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("max_contacts_per_step", C.c_int32), ("rho_restart_iter", C.c_int32), ("reserved0", C.c_int32),
         ("dt", C.c_double), ("mass", C.c_double), ("inertia", C.c_double * 3), ("mu", C.c_double),
         ("fz_min", C.c_double), ("fz_max", C.c_double), ("q_diag", C.c_double * NX), ("r_diag", C.c_double),
         ("force_scale", C.c_double), ("rho", C.c_double), ("rho_eq_scale", C.c_double), ("sigma", C.c_double),
@@ -116,12 +115,6 @@ def load():
     lib.srbdqp_stage_ptrs.restype = C.c_int
     lib.srbdqp_solve_staged_f64.argtypes = [H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.srbdqp_solve_staged_f64.restype = C.c_int
-    lib.srbdqp_resident_stop.argtypes = [H]
-    lib.srbdqp_resident_stop.restype = C.c_int
-    lib.srbdqp_resident_running.argtypes = [H]
-    lib.srbdqp_resident_running.restype = C.c_int
-    lib.srbdqp_resident_last_timing.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    lib.srbdqp_resident_last_timing.restype = C.c_int
     lib.srbdqp_set_stamp_buffer.argtypes = [H, C.c_void_p]
     lib.srbdqp_set_stamp_buffer.restype = C.c_int
     lib.srbdqp_synchronize.argtypes = [H]

@@ -17,7 +17,6 @@
 #include "srbdqp_compact.hpp"
 #include "srbdqp_split.hpp"
 #include "srbdqp_setup1.hpp"
-#include "srbdqp_resident.hpp"
 #include "srbdqp_cascade.hpp"
 #include "srbdqp_cascade.h"
 
@@ -63,15 +62,6 @@ struct srbdqp_handle {
     bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
     bool lazy_restart = false;     // staged path: run only the first pass; the host starts the second one if a status asks for it
     KArgs last_args;               // arguments of that first pass (for the lazily started second pass)
-    // resident batch-1 solver (SRBDQP_FLAG_RESIDENT, srbdqp_resident.hpp): its own stream, the command block in the slab
-    hipStream_t rstream = nullptr;
-    srbdqp::ResidentCmd* cmd_host = nullptr;
-    srbdqp::ResidentCmd* cmd_dev = nullptr;
-    bool res_running = false;      // a resident kernel has been launched and not been joined yet
-    int32_t res_seq = 0, res_last_word = 0;
-    KArgs res_args;                // the running kernel's arguments with every optional pointer set
-    KArgs res_table[16];           // ... and per combination of request flags (host copy of res_table_dev)
-    KArgs* res_table_dev = nullptr;
 };
 
 // slot of a launch stream (at most kMaxSlots distinct streams per handle; null when exhausted)
@@ -149,14 +139,6 @@ void fill_args(const srbdqp_config& c, KArgs& a) {
     a.eps_rel = c.eps_rel;
 }
 
-// Ask a running resident kernel to leave and join it.  Cheap when none runs.
-void resident_stop(srbdqp_handle* h) {
-    if (!h->res_running) return;
-    __atomic_store_n(&h->cmd_host->doorbell, srbdqp::kResidentQuit, __ATOMIC_SEQ_CST);
-    (void)hipStreamSynchronize(h->rstream);
-    h->res_running = false;
-}
-
 template <typename K>
 int set_lds_once(srbdqp_handle* h, K kernel, size_t lds, bool& done) {
     if (!done) {
@@ -181,7 +163,6 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     if (!slot) return SRBDQP_E_INVALID;
     if (need > slot->ws_doubles) {
         HIP_TRY(h, hipStreamSynchronize(st));               // a previous launch on this stream may still use the old buffer
-        if (slot->ws) resident_stop(h);                     // hipFree joins the whole device
         if (slot->ws) { HIP_TRY(h, hipFree(slot->ws)); slot->ws = nullptr; slot->ws_doubles = 0; }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&slot->ws), need * sizeof(double));
         if (e != hipSuccess) { h->err = std::string("hipMalloc split workspace: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
@@ -306,7 +287,6 @@ int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4, int p
 
 int ensure_ws(srbdqp_handle* h, size_t bytes) {
     if (bytes <= h->ws_bytes) return SRBDQP_OK;
-    if (h->ws) resident_stop(h);                            // hipFree joins the whole device
     if (h->ws) { HIP_TRY(h, hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
     size_t want = bytes + bytes / 4;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->ws), want);
@@ -357,7 +337,6 @@ inline int restart_iter_of(const srbdqp_config& c) {
 int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, size_t m) {
     if (slot->rs && slot->rs_items >= B && slot->rs_rows >= m) return SRBDQP_OK;
     HIP_TRY(h, hipStreamSynchronize(st));
-    if (slot->rs) resident_stop(h);                         // hipFree joins the whole device, and the kernel holds slot->resid
     if (slot->rs) { HIP_TRY(h, hipFree(slot->rs)); slot->rs = nullptr; }
     auto carve = [&](Carver& c) {
         slot->resid = c.take<float>(B * 4); slot->list = c.take<int32_t>(B); slot->count = c.take<int32_t>(16);
@@ -399,114 +378,6 @@ int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int m
     return launch(h, a2, st, maxs, 2);
 }
 
-// ---- resident batch-1 solver (srbdqp_resident.hpp) ------------------------------------------------------------------
-template <int N, int MAXS>
-int launch_resident_n(srbdqp_handle* h, int32_t last_word, long long idle_ticks) {
-    constexpr size_t lds = srbdqp::CompactTraits<N, MAXS>::lds_bytes;
-    static bool attr_set = false;
-    int rc = set_lds_once(h, &srbdqp::srbdqp_resident_kernel<N, MAXS>, lds, attr_set);
-    if (rc != SRBDQP_OK) return rc;
-    static const std::string nm = "resident_compact_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
-    h->kname = nm.c_str();
-    hipLaunchKernelGGL((srbdqp::srbdqp_resident_kernel<N, MAXS>), dim3(1), dim3(srbdqp::kThreads), lds, h->rstream, h->res_table_dev, h->cmd_dev, last_word, idle_ticks);
-    HIP_TRY(h, hipGetLastError());
-    return SRBDQP_OK;
-}
-
-// doorbell: the value the kernel finds when it starts -- res_last_word (nothing pending) or a request that is waiting
-int resident_start(srbdqp_handle* h, int32_t doorbell, bool maxs4) {
-    // its own stream, created on first use: streams share a handful of hardware queues, and one more stream per handle
-    // at create time was measured to push the two launch streams of a pipelined caller onto the same queue (bench.py:
-    // 24 -> 18.7 M QP/s at 4096 QPs per step)
-    if (!h->rstream) HIP_TRY(h, hipStreamCreateWithFlags(&h->rstream, hipStreamNonBlocking));
-    const srbdqp_stage& d = h->stage_d;
-    KArgs a;
-    std::memset(&a, 0, sizeof(a));
-    fill_args(h->cfg, a);
-    a.x0 = d.x0; a.xref = d.x_ref; a.foot = d.foot; a.contact = d.contact; a.pcom = d.pcom;
-    a.warm_u = d.warm_u; a.warm_y = d.warm_y;
-    a.u_out = d.u; a.x_out = d.x; a.y_out = d.y; a.status = d.status; a.iters = d.iters;
-    a.B = 1; a.mode = 0;
-    const int restart = restart_iter_of(h->cfg);
-    if (restart) {   // first pass capped; the host starts the second one when status[] asks for it (as the staged path does)
-        auto* slot = stream_slot(h, h->stream);
-        if (!slot) return SRBDQP_E_INVALID;
-        int rc = ensure_restart_buffers(h, slot, h->stream, (size_t)h->stage_h.capacity, 20 * (size_t)h->cfg.horizon);
-        if (rc != SRBDQP_OK) return rc;
-        a.max_iter = restart;
-        a.resid_out = slot->resid;
-    }
-    h->res_args = a;
-    for (int f = 0; f < 16; ++f) {
-        KArgs& q = h->res_table[f];
-        q = a;
-        if (!(f & srbdqp::kResPcom)) q.pcom = nullptr;
-        if (!(f & srbdqp::kResWarm)) { q.warm_u = nullptr; q.warm_y = nullptr; }
-        if (!(f & srbdqp::kResWantX)) q.x_out = nullptr;
-        if (!(f & srbdqp::kResWantY) && !a.resid_out) q.y_out = nullptr;   // a rho restart continues from y
-    }
-    HIP_TRY(h, hipMemcpyAsync(h->res_table_dev, h->res_table, sizeof(h->res_table), hipMemcpyHostToDevice, h->rstream));
-    h->cmd_host->state = 1;
-    __atomic_store_n(&h->cmd_host->doorbell, doorbell, __ATOMIC_SEQ_CST);   // (also clears a stale quit)
-    const int idle_ms = h->cfg.resident_idle_ms > 0 ? h->cfg.resident_idle_ms : 100;
-    const long long ticks = (long long)idle_ms * 100000ll;   // s_memrealtime: 100 MHz
-    int rc;
-    switch (h->cfg.horizon) {
-        case 4: rc = maxs4 ? launch_resident_n<4, 4>(h, h->res_last_word, ticks) : launch_resident_n<4, 2>(h, h->res_last_word, ticks); break;
-        case 8: rc = maxs4 ? launch_resident_n<8, 4>(h, h->res_last_word, ticks) : launch_resident_n<8, 2>(h, h->res_last_word, ticks); break;
-        case 10: rc = maxs4 ? launch_resident_n<10, 4>(h, h->res_last_word, ticks) : launch_resident_n<10, 2>(h, h->res_last_word, ticks); break;
-        case 12: rc = launch_resident_n<12, 2>(h, h->res_last_word, ticks); break;
-        case 16: rc = launch_resident_n<16, 2>(h, h->res_last_word, ticks); break;
-        case 20: rc = launch_resident_n<20, 2>(h, h->res_last_word, ticks); break;
-        default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
-    }
-    if (rc == SRBDQP_OK) h->res_running = true;
-    return rc;
-}
-
-// One staged batch-1 solve through the resident kernel: ring the doorbell, spin on the completion word.
-int resident_solve(srbdqp_handle* h, int maxs, bool use_pcom, bool use_warm, bool want_x, bool want_y) {
-    using namespace srbdqp;
-    const bool maxs4 = maxs > 2 && h->cfg.horizon <= 10;    // the long horizons exist for <= 2 stance contacts per step only
-    h->res_seq = (h->res_seq >= (1 << 24)) ? 1 : h->res_seq + 1;
-    const int32_t word = (h->res_seq << 6) | (use_pcom ? kResPcom : 0) | (use_warm ? kResWarm : 0) | (want_x ? kResWantX : 0) |
-                         (want_y ? kResWantY : 0) | (maxs4 ? kResMaxs4 : 0);
-    if (!h->res_running) {
-        int rc = resident_start(h, h->res_last_word, maxs4);
-        if (rc != SRBDQP_OK) return rc;
-    }
-    h->ev_valid = false;
-    __atomic_store_n(&h->cmd_host->doorbell, word, __ATOMIC_SEQ_CST);   // full fence: the state word is read after this store
-    auto t0 = std::chrono::steady_clock::now();
-    unsigned polls = 0;
-    while (__atomic_load_n(&h->cmd_host->done, __ATOMIC_ACQUIRE) != word) {
-        if ((++polls & 255u) != 0) continue;
-        if (__atomic_load_n(&h->cmd_host->state, __ATOMIC_ACQUIRE) == 2) {
-            // idle time-out (it may still be serving this very request): join it, start a new one if it did not
-            HIP_TRY(h, hipStreamSynchronize(h->rstream));
-            h->res_running = false;
-            if (__atomic_load_n(&h->cmd_host->done, __ATOMIC_ACQUIRE) == word) break;
-            int rc = resident_start(h, word, maxs4);
-            if (rc != SRBDQP_OK) return rc;
-            t0 = std::chrono::steady_clock::now();
-        } else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            h->err = "the resident kernel does not answer";
-            return SRBDQP_E_HIP;
-        }
-    }
-    h->res_last_word = word;
-    if (restart_iter_of(h->cfg) && h->stage_h.status[0] == SRBDQP_MAX_ITER) {
-        KArgs a1 = h->res_args;
-        if (!use_pcom) a1.pcom = nullptr;
-        if (!use_warm) { a1.warm_u = nullptr; a1.warm_y = nullptr; }
-        if (!want_x) a1.x_out = nullptr;
-        int rc = srbdqp_restart_pass(h, a1, h->stream, maxs, false);
-        if (rc != SRBDQP_OK) return rc;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-    }
-    return SRBDQP_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -534,7 +405,7 @@ int srbdqp_default_config(srbdqp_config* c) {
     c->force_scale = 100.0;
     c->rho = 1.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
     c->eps_abs = 1.0e-6; c->eps_rel = 1.0e-6;
-    c->rho_restart_iter = 0; c->resident_idle_ms = 0;
+    c->rho_restart_iter = 0; c->reserved0 = 0;
     return SRBDQP_OK;
 }
 
@@ -545,7 +416,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10}; {12, 16, 20} with max_contacts_per_step <= 2)"; return SRBDQP_E_INVALID; }
     if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons 12, 16 and 20 exist only for the compact kernel"; return SRBDQP_E_INVALID; }
     if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) ||
-        cfg->max_iter < 1 || cfg->check_every < 1 || cfg->rho_restart_iter < 0 || cfg->resident_idle_ms < 0 || cfg->resident_idle_ms > 10000 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
+        cfg->max_iter < 1 || cfg->check_every < 1 || cfg->rho_restart_iter < 0 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -563,10 +434,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
         if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
         if (h->stream) (void)hipStreamDestroy(h->stream);
-        if (h->rstream) (void)hipStreamDestroy(h->rstream);
         if (h->stage_host) (void)hipHostFree(h->stage_host);
         if (h->done_count) (void)hipFree(h->done_count);
-        if (h->res_table_dev) (void)hipFree(h->res_table_dev);
         delete h;
         return SRBDQP_E_HIP;
     };
@@ -589,7 +458,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
         };
         srbdqp_stage tmp{};
         const size_t body = (carve(reinterpret_cast<char*>(4096), tmp) + 255) & ~size_t(255);   // dry run for the size
-        const size_t bytes = body + 512;                     // + completion word + resident command block
+        const size_t bytes = body + 256;
         if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->stage_host), bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return fail("hipHostMalloc(staging)", e);
         if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->stage_dev), h->stage_host, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
         std::memset(h->stage_host, 0, bytes);
@@ -597,11 +466,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
         carve(h->stage_dev, h->stage_d);
         h->done_host = reinterpret_cast<volatile int32_t*>(h->stage_host + body);
         h->done_dev = reinterpret_cast<int32_t*>(h->stage_dev + body);
-        h->cmd_host = reinterpret_cast<srbdqp::ResidentCmd*>(h->stage_host + body + 256);
-        h->cmd_dev = reinterpret_cast<srbdqp::ResidentCmd*>(h->stage_dev + body + 256);
         if ((e = hipMalloc(reinterpret_cast<void**>(&h->done_count), 64)) != hipSuccess) return fail("hipMalloc(done counter)", e);
         if ((e = hipMemset(h->done_count, 0, 64)) != hipSuccess) return fail("hipMemset(done counter)", e);
-        if ((e = hipMalloc(reinterpret_cast<void**>(&h->res_table_dev), sizeof(h->res_table))) != hipSuccess) return fail("hipMalloc(resident arguments)", e);
     }
     *out = h;
     return SRBDQP_OK;
@@ -610,39 +476,17 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
 int srbdqp_destroy(srbdqp_handle* h) {
     if (!h) return SRBDQP_OK;
     (void)hipSetDevice(h->cfg.device);
-    resident_stop(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
     for (auto& sl : h->slots) { if (sl.perm) (void)hipFree(sl.perm); if (sl.ws) (void)hipFree(sl.ws); if (sl.rs) (void)hipFree(sl.rs); }
     if (h->done_count) (void)hipFree(h->done_count);
-    if (h->res_table_dev) (void)hipFree(h->res_table_dev);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->stream) (void)hipStreamDestroy(h->stream);
-    if (h->rstream) (void)hipStreamDestroy(h->rstream);
     delete h;
     return SRBDQP_OK;
-}
-
-int srbdqp_resident_stop(srbdqp_handle* h) {
-    if (!h) return SRBDQP_E_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    resident_stop(h);
-    return SRBDQP_OK;
-}
-
-int srbdqp_resident_last_timing(const srbdqp_handle* h, double* service_us, double* shader_ghz) {
-    if (!h || !h->cmd_host || h->res_last_word == 0) return SRBDQP_E_INVALID;
-    const double us = (double)(h->cmd_host->t_done - h->cmd_host->t_seen) * 0.01;
-    if (service_us) *service_us = us;
-    if (shader_ghz) *shader_ghz = us > 0.0 ? (double)(h->cmd_host->c_done - h->cmd_host->c_seen) / us * 1.0e-3 : 0.0;
-    return SRBDQP_OK;
-}
-
-int srbdqp_resident_running(const srbdqp_handle* h) {
-    return (h && h->res_running && h->cmd_host && __atomic_load_n(&h->cmd_host->state, __ATOMIC_ACQUIRE) == 1) ? 1 : 0;
 }
 
 const char* srbdqp_last_error(const srbdqp_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -672,12 +516,6 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     // completion: the compact kernel publishes a sequence number in host memory after its outputs (signal_done());
     // spinning on it skips the stream's completion interrupt (~15 us).  Other kernel variants: stream synchronise.
     const bool spin = resolve_kernel(h->cfg) == SRBDQP_KERNEL_COMPACT && !(h->cfg.flags & SRBDQP_FLAG_NO_SPIN);
-    if (B == 1 && (h->cfg.flags & SRBDQP_FLAG_RESIDENT) && resolve_kernel(h->cfg) == SRBDQP_KERNEL_COMPACT && !h->stamps) {
-        const int maxs1 = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
-        h->maxs_override = 0;
-        HIP_TRY(h, hipSetDevice(h->cfg.device));
-        return resident_solve(h, maxs1, use_pcom != 0, use_warm != 0, want_x != 0, want_y != 0);
-    }
     auto wait_done = [&]() -> int {
         if (spin) {
             const auto t0 = std::chrono::steady_clock::now();
@@ -778,7 +616,6 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
         if (!slot) return SRBDQP_E_INVALID;
         if ((size_t)B > slot->perm_cap) {
             HIP_TRY(h, hipStreamSynchronize(lst));          // a previous launch on this stream may still read the old order
-            if (slot->perm) resident_stop(h);
             if (slot->perm) HIP_TRY(h, hipFree(slot->perm));
             slot->perm = nullptr; slot->perm_cap = 0;
             HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&slot->perm), sizeof(int32_t) * (size_t)B));

@@ -391,29 +391,37 @@ __device__ __forceinline__ void block_max(double (&v)[NV], double* red) {
 // xs (LDS, n doubles) holds the scaled solution u_hat.
 // ---------------------------------------------------------------------------------------------------------
 template <int N, class L, int BT = kThreads>
-__device__ void rollout_and_store(const KArgs& a, int b, double* sm, const double* uh, double* scratch /* >= 6N */) {
+__device__ void rollout_and_store(const KArgs& a, int b, double* sm, const double* uh, double* scratch /* >= 12N */) {
     using S = L;
     constexpr int n = Dims<N>::n;
     const int t = threadIdx.x;
     for (int c = t; c < n; c += BT) a.u_out[(size_t)b * n + c] = a.s * uh[c];
     if (!a.x_out) return;
     const double* x0 = sm + S::o_x0;
-    // phase A: omega_k, v_k for k = 1..N  (scratch[(k-1)*6 + comp])
+    // phase A1: per-step angular / linear acceleration sums  s_j = J_j u_j (3), sum_contacts u_j / m (3)  -- one step
+    // per thread (60 threads x 12 products; a thread per (k, comp) summing all steps j < k itself took 10 x as long, 4 us
+    // of a batch-1 solve)
+    double* sj = scratch + 6 * N;
+    for (int idx = t; idx < 6 * N; idx += BT) {
+        const int j = idx / 6, comp = idx % 6;
+        const double* u = uh + 12 * j;
+        double s;
+        if (comp < 3) {
+            const double* J = sm + S::o_J + j * 36 + comp * 12;
+            s = 0.0;
+            for (int c = 0; c < 12; ++c) s += J[c] * u[c];
+        } else {
+            const int ax = comp - 3;
+            s = (u[ax] + u[3 + ax] + u[6 + ax] + u[9 + ax]) * a.inv_mass;
+        }
+        sj[idx] = s;
+    }
+    __syncthreads();
+    // phase A2: omega_k, v_k for k = 1..N  (scratch[(k-1)*6 + comp]); same summation order as before
     for (int idx = t; idx < 6 * N; idx += BT) {
         const int k = idx / 6 + 1, comp = idx % 6;
         double acc = 0.0;
-        for (int j = 0; j < k; ++j) {
-            const double* u = uh + 12 * j;
-            if (comp < 3) {
-                const double* J = sm + S::o_J + j * 36 + comp * 12;
-                double sj = 0.0;
-                for (int c = 0; c < 12; ++c) sj += J[c] * u[c];
-                acc += sj;
-            } else {
-                const int ax = comp - 3;
-                acc += (u[ax] + u[3 + ax] + u[6 + ax] + u[9 + ax]) * a.inv_mass;
-            }
-        }
+        for (int j = 0; j < k; ++j) acc += sj[6 * j + comp];
         double v = x0[6 + comp] + a.dt * a.s * acc;
         if (comp == 5) v += (double)k * a.dt * x0[12];
         scratch[idx] = v;

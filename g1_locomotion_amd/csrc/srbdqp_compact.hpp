@@ -306,10 +306,8 @@ struct SplitWs {
     static constexpr int doubles = o_kinv + S::nmax * KS;
 };
 
-// One QP (index b) on one 256-thread workgroup; sm = the workgroup's dynamic LDS (CompactSmem<N, MAXS>::bytes).  Called
-// by srbdqp_compact_kernel (one launch per batch) and by the resident kernel (srbdqp_resident.hpp: one workgroup that
-// stays on the device and solves request after request).  Every exit is workgroup-uniform and leaves no state in LDS
-// that the next call relies on.
+// One QP (index b) on one 256-thread workgroup; sm = the workgroup's dynamic LDS (CompactSmem<N, MAXS>::bytes).
+// Every exit is workgroup-uniform and leaves no state in LDS that a later call would rely on.
 template <int N, int MAXS, bool SPLIT = false>
 __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* sm) {
     using S = CompactSmem<N, MAXS>;

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     }
     const int na = imisc[0];
     const int n_eff = 3 * na;
-    double* xs0 = sm + L1::o_mt;                             // scratch vectors of the early exit (n + 6N doubles; M is not built)
+    double* xs0 = sm + L1::o_mt;                             // scratch vectors of the early exit (n + 12N doubles; M is not built)
+    static_assert(L1::o_end - L1::o_mt >= n + 12 * N, "early-exit scratch");
     if (imisc[1] != 0 || na == 0) {   // bound violated (status -2) or nothing to solve (all forces 0): finished here
         for (int c = lane; c < n; c += 64) xs0[c] = 0.0;
         if (a.y_out) for (int i = lane; i < m; i += 64) a.y_out[(size_t)b * m + i] = 0.0;
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         __syncthreads();
         WSTAMP(a, b, 8);
         WSTAMP(a, b, 9);
+        static_assert(L1::o_end >= SplitSmem<N, MAXS>::o_end, "the ADMM body's vectors live in this kernel's LDS");
         admm_wave_body<N, MAXS>(a, b, rho_b, sm, kin);
         WSTAMP(a, b, 10);
         WSTAMP(a, b, 11);

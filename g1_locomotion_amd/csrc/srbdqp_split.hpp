@@ -21,8 +21,8 @@ struct SplitSmem {
     using S = CompactSmem<N, MAXS>;
     static constexpr int o_rhs = (S::o_R + 1) & ~1;        // 64 (+ padding to the row stride)
     static constexpr int o_xs = o_rhs + 72;                // n: full variable vector for the roll-out
-    static constexpr int o_scr = o_xs + Dims<N>::n;        // 6N roll-out scratch
-    static constexpr int o_end = o_scr + 6 * N + 2;
+    static constexpr int o_scr = o_xs + Dims<N>::n;        // 12N roll-out scratch
+    static constexpr int o_end = o_scr + 12 * N + 2;
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
 };
 

@@ -47,17 +47,14 @@ class BatchMPC:
     """B independent SRBD convex-MPC QPs per call.  One instance <-> one HIP stream <-> one thread."""
 
     def __init__(self, horizon: int = 10, dt: float = 0.04, device: int = 0, kernel: int = _lib.KERNEL_AUTO,
-                 timing: bool = False, resident: bool = False, **overrides):
-        """resident=True: batch-1 ``solve_staged`` calls are served by a kernel that stays on the device (no launch per
-        solve, ~15 us less per call; include/srbdqp.h SRBDQP_FLAG_RESIDENT).  It leaves on ``close()``,
-        ``resident_stop()`` and after ``resident_idle_ms`` (default 100) without a request."""
+                 timing: bool = False, **overrides):
         lib = _lib.load()
         cfg = _lib.default_config()
         cfg.horizon = int(horizon)
         cfg.dt = float(dt)
         cfg.device = int(device)
         cfg.kernel = int(kernel)
-        cfg.flags = (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_RESIDENT if resident else 0)
+        cfg.flags = _lib.FLAG_TIMING if timing else 0
         for k, v in overrides.items():
             if not hasattr(cfg, k):
                 raise TypeError(f"unknown srbdqp_config field {k!r}")
@@ -99,19 +96,6 @@ class BatchMPC:
 
     def __exit__(self, *exc):
         self.close()
-
-    def resident_stop(self):
-        """Make the resident kernel (``resident=True``) leave now, e.g. before a ``torch.cuda.synchronize()``."""
-        _lib.check(self._lib.srbdqp_resident_stop(self._h), self._h)
-
-    def resident_running(self) -> bool:
-        return bool(self._lib.srbdqp_resident_running(self._h))
-
-    def resident_last_timing(self):
-        """(service_us, shader_ghz) of the last resident request: doorbell seen -> outputs stored on the device clock."""
-        us, ghz = C.c_double(), C.c_double()
-        _lib.check(self._lib.srbdqp_resident_last_timing(self._h, C.byref(us), C.byref(ghz)), self._h)
-        return us.value, ghz.value
 
     # -- host-buffer API -------------------------------------------------------------------------------
     def solve(self, x0, x_ref, foot, contact, pcom=None, warm_u=None, warm_y=None, want_x=True, want_y=False):

@@ -51,13 +51,6 @@ extern "C" {
 #define SRBDQP_FLAG_SETUP4 4      /* split pipeline: set-up kernel with 4 waves per QP instead of one wave per QP (A/B) */
 #define SRBDQP_FLAG_NO_SPIN 2     /* srbdqp_solve_staged_f64: wait with hipStreamSynchronize instead of spinning on the
                                      completion word the kernel writes to host memory */
-#define SRBDQP_FLAG_RESIDENT 8    /* srbdqp_solve_staged_f64 with B = 1: no kernel launch per solve.  One workgroup of the
-                                     4-wave kernel stays on the device, polls a doorbell word in the staging slab and
-                                     solves request after request (same source as the launched kernel, results equal to
-                                     rounding; ~15 us less per call).  It leaves when the handle is destroyed, on srbdqp_resident_stop(), and by
-                                     itself after resident_idle_ms without a request (the next solve starts it again).
-                                     While it runs, hipDeviceSynchronize() / hipFree() in the same process wait for that
-                                     time-out: call srbdqp_resident_stop() first.  Other streams are not held up. */
 
 /* srbdqp_config.kernel: which implementation of the hot path runs */
 #define SRBDQP_KERNEL_AUTO  0     /* the fastest parity-green kernel */
@@ -87,8 +80,7 @@ typedef struct srbdqp_config {
                                    * (clipped to [rho/10, 10 rho]) and continues from its own (x, y) until max_iter
                                    * iterations in total; iters[] counts both passes.  0 (default) or >= max_iter = off.  Compact and
                                    * split kernels only.  Per device-API launch at most max(64, B/4) QPs are restarted. */
-    int32_t resident_idle_ms;     /* SRBDQP_FLAG_RESIDENT: the resident kernel exits after this long without a request
-                                   * (0 = default 100 ms, i.e. more than two 25 Hz control periods; at most 10000) */
+    int32_t reserved0;
     double dt;                    /* run_simulation.py:169 */
     double mass;                  /* wbid.py:291 model.getMass() */
     double inertia[3];            /* wbid.py:261-266 torso inertia diagonal */
@@ -171,15 +163,6 @@ typedef struct srbdqp_stage {
 } srbdqp_stage;
 int srbdqp_stage_ptrs(srbdqp_handle* h, srbdqp_stage* out);
 int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32_t use_warm, int32_t want_x, int32_t want_y);
-
-/* SRBDQP_FLAG_RESIDENT: make the resident kernel leave now and wait until it has (no-op when none runs);
- * srbdqp_resident_running: 1 while a resident kernel is on the device and has not timed out. */
-int srbdqp_resident_stop(srbdqp_handle* h);
-int srbdqp_resident_running(const srbdqp_handle* h);
-/* Device-side timing of the last request the resident kernel served: service_us = from the moment the workgroup saw
- * the doorbell to the moment its outputs were stored (the device's 100 MHz clock), shader_ghz = the shader clock over
- * that interval.  Either pointer may be null.  SRBDQP_E_INVALID if no request has been served. */
-int srbdqp_resident_last_timing(const srbdqp_handle* h, double* service_us, double* shader_ghz);
 
 /* Diagnostic: device buffer [B][16] of int64 that subsequent solves fill with per-QP s_memtime stamps of the kernel's
  * phase boundaries (100 MHz constant clock); NULL switches stamping off.  Not part of the drop-in surface. */

@@ -30,8 +30,7 @@ def main():
     from g1_locomotion_amd import BatchMPC, MPC, _lib
     x0, xr, ft, ct = orc.synthetic_batch(64, 10, seed=99, schedule="single")
     out = {}
-    for name, kw in (("spin", {}), ("stream_sync", {"flags": _lib.FLAG_NO_SPIN}), ("spin_eps1e-3", {"eps_abs": 1e-3, "eps_rel": 1e-3}),
-                     ("resident", {"resident": True}), ("resident_eps1e-3", {"resident": True, "eps_abs": 1e-3, "eps_rel": 1e-3})):
+    for name, kw in (("spin", {}), ("stream_sync", {"flags": _lib.FLAG_NO_SPIN}), ("spin_eps1e-3", {"eps_abs": 1e-3, "eps_rel": 1e-3})):
         eng = BatchMPC(horizon=10, **kw)
         st = eng.stage()
         ts, its = [], []
@@ -65,8 +64,8 @@ def main():
         ks.append(eng.last_kernel_ms() * 1e-3)
     out["kernel_events"] = pct(ks[50:])
     eng.close()
-    for warm, resident in ((False, False), (True, False), (False, True)):
-        mpc = MPC(dt=0.04, horizon=10, warm_start=warm, resident=resident)
+    for warm in (False, True):
+        mpc = MPC(dt=0.04, horizon=10, warm_start=warm)
         mpc.init_matrices()
         ts = []
         for i in range(calls + 100):
@@ -75,16 +74,16 @@ def main():
             t = time.perf_counter()
             mpc.update(list(ct[b]), list(ft[b]), xr[b][:, 3:6], x_current=x0[b].reshape(13, 1), one_rollout=True)
             ts.append(time.perf_counter() - t)
-        out["mpc_update_" + ("warm" if warm else "cold") + ("_resident" if resident else "")] = pct(ts[100:])
+        out["mpc_update_" + ("warm" if warm else "cold")] = pct(ts[100:])
         mpc.close()
     # closed loop: consecutive QPs of one robot (standing with a push, then stepping in place)
     from srbd_plant import SrbdPlant
     from g1_locomotion_amd import msgs
     FEET = np.array([[0.0, 0.0645, 0.0], [0.17, 0.0645, 0.0], [0.0, -0.0645, 0.0], [0.17, -0.0645, 0.0]])
     COM = np.array([0.085, 0.0, 0.598])
-    for warm, resident in ((False, False), (True, False), (False, True)):
+    for warm in (False, True):
         for standing in (True, False):
-            mpc = MPC(dt=0.04, horizon=10, warm_start=warm, resident=resident)
+            mpc = MPC(dt=0.04, horizon=10, warm_start=warm)
             mpc.init_matrices()
             real_update = mpc.update
             ts, its = [], []
@@ -106,7 +105,7 @@ def main():
                 for _ in range(10):
                     x = plant.step(x, FEET, u0, 0.004)
                 t_sim += 0.04
-            out[f"closed_loop_{'standing' if standing else 'stepping'}_{'warm' if warm else 'cold'}{'_resident' if resident else ''}"] = dict(pct(ts[5:]), mean_iters=float(np.mean(its[5:])))
+            out[f"closed_loop_{'standing' if standing else 'stepping'}_{'warm' if warm else 'cold'}"] = dict(pct(ts[5:]), mean_iters=float(np.mean(its[5:])))
             mpc.close()
     print(json.dumps(out, indent=1))
 
