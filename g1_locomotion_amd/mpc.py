@@ -297,8 +297,14 @@ class MPC:
         st = eng.stage()
         st["x0"][0] = np.asarray(x_current, dtype=np.float64).reshape(NX)
         st["x_ref"][0] = np.asarray(x_ref_hor, dtype=np.float64).reshape(N, NX)
-        st["foot"][0] = np.asarray(c_horizon, dtype=np.float64).reshape(N, NU)
-        st["contact"][0] = np.asarray(contact_horizon).reshape(N, NC) != 0
+        # the reference passes per-step lists (run_simulation.py:94-101): concatenating straight into the staging
+        # arrays is ~1 us cheaper than np.asarray(list) + copy; anything irregular takes the general path
+        try:
+            np.concatenate(c_horizon, out=st["foot"][0].reshape(-1))
+            np.concatenate(contact_horizon, out=st["contact"][0].reshape(-1), casting="unsafe")   # 0 / non-zero flags
+        except (ValueError, TypeError):
+            st["foot"][0] = np.asarray(c_horizon, dtype=np.float64).reshape(N, NU)
+            st["contact"][0] = np.asarray(contact_horizon).reshape(N, NC) != 0
         use_pcom = p_com_horizon is not None
         if use_pcom:
             st["pcom"][0] = np.asarray(p_com_horizon, dtype=np.float64).reshape(N, 3)
