@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--no-sched-hint", action="store_true",
                     help="do not feed the previous step's iteration counts back as the longest-first dispatch hint")
     ap.add_argument("--max-iter", type=int, default=0, help="override srbdqp_config.max_iter (0 = library default)")
+    ap.add_argument("--rho-restart", type=int, default=0, help="override srbdqp_config.rho_restart_iter (0 = library default: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -101,7 +102,8 @@ def main():
            "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE}[args.kernel]
     # configs[1] is the 2-contact (single support) workload: at most 2 stance contact points per horizon step
     eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=2,
-                   **({"max_iter": args.max_iter} if args.max_iter > 0 else {}))
+                   **({"max_iter": args.max_iter} if args.max_iter > 0 else {}),
+                   **({"rho_restart_iter": args.rho_restart} if args.rho_restart > 0 else {}))
     # non-default streams: the C-ABI treats a NULL stream as "the handle's own", and the HIP events that time a kernel
     # must sit on the stream the kernel is launched on
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
@@ -196,7 +198,7 @@ def main():
                                    f"support friction cone, fp64; u_opt0 all-gather over RCCL when n_gpus>1",
                        "horizon": N, "batch_per_gpu": B, "kernel": eng.kernel_name(), "streams": S, "longest_first_hint": not args.no_sched_hint,
                        "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
-                       "eps_abs": eng.cfg.eps_abs, "eps_rel": eng.cfg.eps_rel},
+                       "eps_abs": eng.cfg.eps_abs, "eps_rel": eng.cfg.eps_rel, "rho_restart_iter": int(eng.cfg.rho_restart_iter)},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*_pmc_summary.json)",
