@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <string>
+#include <unordered_set>
 
 #include "srbdqp.h"
 #include "srbdqp_common.hpp"
@@ -62,6 +63,9 @@ struct srbdqp_handle {
     bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
     bool lazy_restart = false;     // staged path: run only the first pass; the host starts the second one if a status asks for it
     KArgs last_args;               // arguments of that first pass (for the lazily started second pass)
+    // kernels whose dynamic-LDS limit has been raised on this handle's device (function attributes are per device, and a
+    // process may hold handles on several)
+    std::unordered_set<const void*> lds_attr_done;
 };
 
 // slot of a launch stream (at most kMaxSlots distinct streams per handle; null when exhausted)
@@ -140,10 +144,11 @@ void fill_args(const srbdqp_config& c, KArgs& a) {
 }
 
 template <typename K>
-int set_lds_once(srbdqp_handle* h, K kernel, size_t lds, bool& done) {
-    if (!done) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        done = true;
+int set_lds_once(srbdqp_handle* h, K kernel, size_t lds) {
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    if (!h->lds_attr_done.count(fn)) {
+        HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        h->lds_attr_done.insert(fn);
     }
     return SRBDQP_OK;
 }
@@ -170,8 +175,7 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     }
     a.ws = slot->ws;
     constexpr size_t ldsA = srbdqp::CompactTraits<N, MAXS>::lds_bytes, ldsB = srbdqp::SplitSmem<N, MAXS>::bytes;
-    static bool attr_set = false;
-    int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, true>, ldsA, attr_set);
+    int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, true>, ldsA);
     if (rc != SRBDQP_OK) return rc;
     static const std::string nm = "split_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
@@ -213,8 +217,7 @@ int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
         if (h->cfg.kernel == SRBDQP_KERNEL_SPLIT && a.mode == 0 && !a.stamps && !a.done_flag) return launch_split<N, MAXS>(h, a, st);
     }
     constexpr size_t lds = srbdqp::CompactTraits<N, MAXS>::lds_bytes;
-    static bool attr_set = false;
-    int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS>, lds, attr_set);
+    int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS>, lds);
     if (rc != SRBDQP_OK) return rc;
     static const std::string nm = "compact_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
@@ -231,15 +234,13 @@ int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int variant, int 
         if (rc != SRBDQP_OK) return rc;
     } else if (variant == SRBDQP_KERNEL_MFMA && srbdqp::MfmaTraits<N>::supported) {
         constexpr size_t lds = srbdqp::MfmaTraits<N>::lds_bytes;
-        static bool attr_set = false;
-        rc = set_lds_once(h, &srbdqp::srbdqp_mfma_kernel<N>, lds, attr_set);
+        rc = set_lds_once(h, &srbdqp::srbdqp_mfma_kernel<N>, lds);
         if (rc != SRBDQP_OK) return rc;
         h->kname = srbdqp::MfmaTraits<N>::name;
         hipLaunchKernelGGL(srbdqp::srbdqp_mfma_kernel<N>, grid, block, lds, st, a);
     } else {
         constexpr size_t lds = srbdqp::GjSmem<N>::bytes;
-        static bool attr_set = false;
-        rc = set_lds_once(h, &srbdqp::srbdqp_gj_kernel<N>, lds, attr_set);
+        rc = set_lds_once(h, &srbdqp::srbdqp_gj_kernel<N>, lds);
         if (rc != SRBDQP_OK) return rc;
         static const std::string nm = "gj_f64_n" + std::to_string(N);
         h->kname = nm.c_str();
@@ -431,7 +432,6 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
         g_create_err = std::string(what) + ": " + hipGetErrorString(er);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
         if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         if (h->stage_host) (void)hipHostFree(h->stage_host);
