@@ -14,6 +14,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -98,6 +99,16 @@ int main() {
             fg[0] = 42.0; fg[1] = 1.0;                       // CPU store through the BAR
             CK(hipMemcpy(hsrc, fg, 16, hipMemcpyDeviceToHost));
             printf("  CPU store visible to the device: %g %g\n", hsrc[0], hsrc[1]);
+            // what the CPU pays for writing one QP's inputs (2.3 KB) there, and for reading 40 bytes back
+            std::vector<double> src(288, 1.0);
+            auto t0 = std::chrono::steady_clock::now();
+            for (int rep = 0; rep < 2000; ++rep) { memcpy(fg + (rep & 7) * 288, src.data(), 2304); __builtin_ia32_sfence(); }
+            auto t1 = std::chrono::steady_clock::now();
+            volatile double sink = 0.0;
+            for (int rep = 0; rep < 200; ++rep) for (int i = 0; i < 5; ++i) sink += ((volatile double*)fg)[i + 8 * (rep & 7)];
+            auto t2 = std::chrono::steady_clock::now();
+            printf("  CPU memcpy of 2304 B into it + sfence: %.3f us; CPU read of 40 B from it: %.3f us\n",
+                   std::chrono::duration<double, std::micro>(t1 - t0).count() / 2000, std::chrono::duration<double, std::micro>(t2 - t1).count() / 200);
         }
     }
     return 0;
