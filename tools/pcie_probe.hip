@@ -63,6 +63,10 @@ __global__ void probe(const double* src, double* dst, long long* out, double* si
     sink[t] = acc;
 }
 
+__global__ void readback(const double* src, double* dst) {
+    for (int i = threadIdx.x; i < 288; i += 256) dst[i] = src[i];
+}
+
 int main() {
     const size_t nd = 4096;
     double *hsrc, *hdst, *dsrc, *ddst, *sink; long long* out;
@@ -95,10 +99,33 @@ int main() {
         e = hipPointerGetAttributes(&at, fg);
         printf("  attributes: %s type %d host %p device %p\n", hipGetErrorString(e), (int)at.type, at.hostPointer, at.devicePointer);
         fflush(stdout);
+        {   // the same kernel probe with fine-grained device memory as the source (what a BAR-fed input stage would read)
+            CK(hipMemset(fg, 0, nd * 8));
+            std::vector<long long> samples[7];
+            for (int rep = 0; rep < 60; ++rep) {
+                hipLaunchKernelGGL(probe, dim3(1), dim3(256), 0, 0, fg, ddst, out, sink);
+                CK(hipDeviceSynchronize());
+                if (rep >= 10) for (int i = 0; i < 7; ++i) samples[i].push_back(out[i]);
+            }
+            printf("fine-grained device memory (reads):");
+            for (int i = 0; i < 4; ++i) { std::sort(samples[i].begin(), samples[i].end()); printf("  %s %.2f us", names[i], samples[i][samples[i].size() / 2] * 0.01); }
+            printf("\n");
+        }
         if (getenv("PCIE_PROBE_TOUCH")) {
             fg[0] = 42.0; fg[1] = 1.0;                       // CPU store through the BAR
             CK(hipMemcpy(hsrc, fg, 16, hipMemcpyDeviceToHost));
             printf("  CPU store visible to the device: %g %g\n", hsrc[0], hsrc[1]);
+            {   // does a later kernel see what the CPU wrote over the same addresses (no stale cache line)?
+                int stale = 0;
+                for (int rep = 0; rep < 200; ++rep) {
+                    for (int i = 0; i < 288; ++i) fg[512 + i] = (double)(rep * 1000 + i);
+                    __builtin_ia32_sfence();
+                    hipLaunchKernelGGL(readback, dim3(1), dim3(256), 0, 0, fg + 512, hdst);
+                    CK(hipDeviceSynchronize());
+                    for (int i = 0; i < 288; ++i) stale += (hdst[i] != (double)(rep * 1000 + i));
+                }
+                printf("  200 x (CPU overwrites 288 doubles through the BAR, kernel reads them): %d stale values\n", stale);
+            }
             // what the CPU pays for writing one QP's inputs (2.3 KB) there, and for reading 40 bytes back
             std::vector<double> src(288, 1.0);
             auto t0 = std::chrono::steady_clock::now();
