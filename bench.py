@@ -111,7 +111,7 @@ def main():
     def step(i):
         st = streams[i % S]
         if not args.no_sched_hint:   # receding-horizon deployment: the iteration counts this stream's previous step produced
-            eng.set_schedule_hint(d_it[i % S].data_ptr() if i >= S else 0)
+            eng.set_schedule_hint(d_it[i % S].data_ptr() if i >= S else 0, B)
         eng.solve_device(B, d_x0.data_ptr(), d_xr.data_ptr(), d_ft.data_ptr(), d_ct.data_ptr(), d_u[i % S].data_ptr(),
                          x_out=d_x[i % S].data_ptr(), status=d_st[i % S].data_ptr(), iters=d_it[i % S].data_ptr(),
                          stream=st.cuda_stream)
@@ -142,7 +142,7 @@ def main():
                       **({"max_iter": args.max_iter} if args.max_iter > 0 else {})) as teng:
             acc = []
             for i in range(6):
-                teng.set_schedule_hint(0 if args.no_sched_hint else d_it[0].data_ptr())
+                teng.set_schedule_hint(0 if args.no_sched_hint else d_it[0].data_ptr(), B)
                 teng.solve_device(B, d_x0.data_ptr(), d_xr.data_ptr(), d_ft.data_ptr(), d_ct.data_ptr(), d_u[0].data_ptr(),
                                   x_out=d_x[0].data_ptr(), status=d_st[0].data_ptr(), iters=d_it[0].data_ptr(), stream=streams[0].cuda_stream)
                 torch.cuda.synchronize(dev)

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrbdqp.so")
+# SRBDQP_LIB: a diagnostic build of the same library (tools/build_variant.sh), never a different implementation
+LIB_PATH = os.environ.get("SRBDQP_LIB") or os.path.join(_HERE, "libsrbdqp.so")
 
 NX, NU, NC = 13, 12, 4
 ROWS_PER_STEP = 20
@@ -20,11 +21,12 @@ SOLVED, MAX_ITER, NUMERICAL, CONTACT_BOUND = 1, 2, -1, -2
 FLAG_TIMING = 1
 FLAG_NO_SPIN = 2
 FLAG_SETUP4 = 4
-KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT, KERNEL_SPLIT, KERNEL_WAVE = 0, 1, 2, 3, 4, 5
+KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT, KERNEL_SPLIT, KERNEL_WAVE, KERNEL_WRENCH = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",
-    "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_assemble_f64",
+    "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_solve_batch_f32", "srbdqp_solve_batch_device_f32",
+    "srbdqp_assemble_f64", "srbdqp_assemble_wrench_f64",
     "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
@@ -107,9 +109,15 @@ def load():
     lib.srbdqp_solve_batch_f64.restype = C.c_int
     lib.srbdqp_solve_batch_device_f64.argtypes = [H, C.c_int32, dp, dp, dp, u8p, dp, dp, dp, dp, dp, dp, i32p, i32p, C.c_void_p]
     lib.srbdqp_solve_batch_device_f64.restype = C.c_int
+    lib.srbdqp_solve_batch_f32.argtypes = [H, C.c_int32, dp, dp, dp, u8p, dp, dp, dp, dp, dp, dp, i32p, i32p]
+    lib.srbdqp_solve_batch_f32.restype = C.c_int
+    lib.srbdqp_solve_batch_device_f32.argtypes = [H, C.c_int32, dp, dp, dp, u8p, dp, dp, dp, dp, dp, dp, i32p, i32p, C.c_void_p]
+    lib.srbdqp_solve_batch_device_f32.restype = C.c_int
     lib.srbdqp_assemble_f64.argtypes = [H, C.c_int32, dp, dp, dp, u8p, dp, dp, dp, dp, dp]
     lib.srbdqp_assemble_f64.restype = C.c_int
-    lib.srbdqp_set_schedule_hint.argtypes = [H, C.c_void_p]
+    lib.srbdqp_assemble_wrench_f64.argtypes = [H, C.c_int32, dp, dp, dp, u8p, dp, dp, dp, dp, dp]
+    lib.srbdqp_assemble_wrench_f64.restype = C.c_int
+    lib.srbdqp_set_schedule_hint.argtypes = [H, C.c_void_p, C.c_int32]
     lib.srbdqp_set_schedule_hint.restype = C.c_int
     lib.srbdqp_stage_ptrs.argtypes = [H, C.POINTER(Stage)]
     lib.srbdqp_stage_ptrs.restype = C.c_int

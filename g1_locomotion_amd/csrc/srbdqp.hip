@@ -18,6 +18,7 @@
 #include "srbdqp_compact.hpp"
 #include "srbdqp_split.hpp"
 #include "srbdqp_setup1.hpp"
+#include "srbdqp_wrench.hpp"
 #include "srbdqp_cascade.hpp"
 #include "srbdqp_cascade.h"
 
@@ -26,6 +27,7 @@ using srbdqp::KArgs;
 struct srbdqp_handle {
     srbdqp_config cfg;
     int maxs_override = 0;         // set by the host-buffer API after scanning the contact flags
+    bool io_f32 = false;           // set around a launch by the _f32 entry points: the caller's buffers are float
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;   // ev_mid: between the two kernels of the split pipeline
     bool ev_valid = false, ev_mid_valid = false;
@@ -36,6 +38,7 @@ struct srbdqp_handle {
     const char* kname = "none";
     long long* stamps = nullptr;   // diagnostic stamp buffer (device), see srbdqp_set_stamp_buffer
     const int32_t* sched_hint = nullptr;   // device: previous step's iters[] (srbdqp_set_schedule_hint)
+    size_t sched_hint_len = 0;             // its length: batches larger than that are dispatched in natural order
     // per-launch-stream device scratch (a caller may pipeline solves of one handle over several streams: each stream
     // needs its own dispatch order and its own split-pipeline hand-over workspace)
     struct StreamSlot {
@@ -115,9 +118,10 @@ std::string g_create_err;
 
 // fp64 instantiations: N in {4, 8, 10} with up to 4 stance contacts per step; N in {12, 16} with at most 2 (the dense
 // 12N x 12N inverse of the larger cases does not fit on chip)
-bool horizon_supported(int N) { return N == 4 || N == 8 || N == 10 || N == 12 || N == 16 || N == 20; }
+bool horizon_supported(int N) { return N == 4 || N == 8 || N == 10 || N == 12 || N == 16 || N == 20 || N == 24; }
 
 int resolve_kernel(const srbdqp_config& c) {
+    if (c.kernel == SRBDQP_KERNEL_WRENCH) return SRBDQP_KERNEL_WRENCH;
     if (c.kernel == SRBDQP_KERNEL_GJ) return SRBDQP_KERNEL_GJ;
     if (c.kernel == SRBDQP_KERNEL_MFMA) return SRBDQP_KERNEL_MFMA;
     return SRBDQP_KERNEL_COMPACT;
@@ -250,12 +254,50 @@ int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int variant, int 
     return SRBDQP_OK;
 }
 
+// The general kernel (srbdqp_wrench.hpp): any contact pattern, fp64 or fp32 iterations / buffers.
+template <int N, typename R>
+struct WrenchTraits {
+    using S = srbdqp::WrenchSmem<N>;
+    static constexpr int by_lds = (S::lds_wgs * S::NW) / 4 > 0 ? (S::lds_wgs * S::NW) / 4 : 1;   // waves per SIMD LDS admits
+    static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 36 ? 2 : 1);                  // register budget
+    static constexpr int wps = by_lds < want ? by_lds : want;
+};
+
+template <int N, typename R, typename TIO>
+int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
+    using S = srbdqp::WrenchSmem<N>;
+    constexpr int WPS = WrenchTraits<N, R>::wps;
+    constexpr size_t lds = S::bytes;
+    static_assert(lds <= 163840, "one QP must fit the LDS of a CU");
+    static const std::string nm = std::string("wrench_") + (sizeof(R) == 4 ? "f32" : "f64") + "_n" + std::to_string(N);
+    if (a.mode == 1) {
+        if constexpr (sizeof(R) == 8) {
+            int rc = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel<N, double, double, 1, WPS>, lds);
+            if (rc != SRBDQP_OK) return rc;
+            h->kname = nm.c_str();
+            hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, double, double, 1, WPS>), dim3((unsigned)a.B), dim3(S::BT), lds, st, a);
+        } else { h->err = "the assembly dump is fp64 only"; return SRBDQP_E_INVALID; }
+    } else {
+        int rc = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>, lds);
+        if (rc != SRBDQP_OK) return rc;
+        h->kname = nm.c_str();
+        hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>), dim3((unsigned)a.B), dim3(S::BT), lds, st, a);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SRBDQP_OK;
+}
+
+template <int N>
+int launch_wrench(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
+    if (h->io_f32) return launch_wrench_t<N, float, float>(h, a, st);
+    return launch_wrench_t<N, double, double>(h, a, st);
+}
+
 template <int N>
 int launch_long(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
-    if (a.mode == 1) { h->err = "srbdqp_assemble_f64 is limited to horizons <= 10"; return SRBDQP_E_INVALID; }
-    // only the <= 2-contacts-per-step instantiation exists: a QP with more stance contacts in a step comes back with
-    // status SRBDQP_CONTACT_BOUND
-    (void)maxs;
+    // the compact kernel exists only with <= 2 stance contacts per step at these horizons; anything else (and every
+    // fp32 call) goes to the general kernel
+    if (maxs > 2 || h->io_f32 || a.mode == 1 || h->cfg.kernel == SRBDQP_KERNEL_WRENCH) return launch_wrench<N>(h, a, st);
     int rc = launch_compact<N, 2>(h, a, st);
     if (rc != SRBDQP_OK) return rc;
     HIP_TRY(h, hipGetLastError());
@@ -265,17 +307,19 @@ int launch_long(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
 // pass: 0 = the only launch of a solve, 1 = first of two (restart follows), 2 = second of two
 int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4, int pass = 0) {
     if (a.B <= 0) return SRBDQP_OK;
+    const bool force_wrench = h->cfg.kernel == SRBDQP_KERNEL_WRENCH || h->io_f32;
     const int variant = (a.mode == 1) ? SRBDQP_KERNEL_GJ : resolve_kernel(h->cfg);
     const bool timing = (h->cfg.flags & SRBDQP_FLAG_TIMING) != 0;
     if (timing && pass != 2) { HIP_TRY(h, hipEventRecord(h->ev0, st)); h->ev_mid_valid = false; }
     int rc;
     switch (h->cfg.horizon) {
-        case 4: rc = launch_n<4>(h, a, st, variant, maxs); break;
-        case 8: rc = launch_n<8>(h, a, st, variant, maxs); break;
-        case 10: rc = launch_n<10>(h, a, st, variant, maxs); break;
+        case 4: rc = force_wrench ? launch_wrench<4>(h, a, st) : launch_n<4>(h, a, st, variant, maxs); break;
+        case 8: rc = force_wrench ? launch_wrench<8>(h, a, st) : launch_n<8>(h, a, st, variant, maxs); break;
+        case 10: rc = force_wrench ? launch_wrench<10>(h, a, st) : launch_n<10>(h, a, st, variant, maxs); break;
         case 12: rc = launch_long<12>(h, a, st, maxs); break;
         case 16: rc = launch_long<16>(h, a, st, maxs); break;
         case 20: rc = launch_long<20>(h, a, st, maxs); break;
+        case 24: rc = launch_wrench<24>(h, a, st); break;
         default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
     }
     if (rc != SRBDQP_OK) return rc;
@@ -414,8 +458,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if (!cfg || !out) { g_create_err = "null argument"; return SRBDQP_E_INVALID; }
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(srbdqp_config)) { g_create_err = "srbdqp_config.struct_size mismatch"; return SRBDQP_E_INVALID; }
-    if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (fp64 kernels: N in {4, 8, 10}; {12, 16, 20} with max_contacts_per_step <= 2)"; return SRBDQP_E_INVALID; }
-    if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons 12, 16 and 20 exist only for the compact kernel"; return SRBDQP_E_INVALID; }
+    if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (N in {4, 8, 10, 12, 16, 20, 24})"; return SRBDQP_E_INVALID; }
+    if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons above 10 exist only for the compact and the general kernel"; return SRBDQP_E_INVALID; }
     if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) ||
         cfg->max_iter < 1 || cfg->check_every < 1 || cfg->rho_restart_iter < 0 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }
@@ -515,7 +559,8 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     }
     // completion: the compact kernel publishes a sequence number in host memory after its outputs (signal_done());
     // spinning on it skips the stream's completion interrupt (~15 us).  Other kernel variants: stream synchronise.
-    const bool spin = resolve_kernel(h->cfg) == SRBDQP_KERNEL_COMPACT && !(h->cfg.flags & SRBDQP_FLAG_NO_SPIN);
+    const int rk = resolve_kernel(h->cfg);
+    const bool spin = (rk == SRBDQP_KERNEL_COMPACT || rk == SRBDQP_KERNEL_WRENCH) && !(h->cfg.flags & SRBDQP_FLAG_NO_SPIN);
     auto wait_done = [&]() -> int {
         if (spin) {
             const auto t0 = std::chrono::steady_clock::now();
@@ -536,9 +581,12 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     if (spin) { h->done_seq = (h->done_seq == INT32_MAX) ? 1 : h->done_seq + 1; h->signal_next = true; }
     const int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
     h->lazy_restart = true;                                 // the rho restart costs two more launches: only when needed
+    const int32_t* hint_keep = h->sched_hint;               // the dispatch hint belongs to the device-buffer API
+    h->sched_hint = nullptr;
     int rc = srbdqp_solve_batch_device_f64(h, B, d.x0, d.x_ref, d.foot, d.contact, use_pcom ? d.pcom : nullptr,
                                            use_warm ? d.warm_u : nullptr, use_warm ? d.warm_y : nullptr, d.u,
                                            want_x ? d.x : nullptr, want_y ? d.y : nullptr, d.status, d.iters, h->stream);
+    h->sched_hint = hint_keep;
     h->lazy_restart = false;
     h->maxs_override = 0;
     h->signal_next = false;
@@ -558,9 +606,11 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     return rc;
 }
 
-int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev) {
+int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev, int32_t length) {
     if (!h) return SRBDQP_E_INVALID;
+    if (device_iters_prev && length < 0) { h->err = "negative hint length"; return SRBDQP_E_INVALID; }
     h->sched_hint = device_iters_prev;
+    h->sched_hint_len = device_iters_prev ? (size_t)length : 0;
     return SRBDQP_OK;
 }
 
@@ -595,23 +645,28 @@ int srbdqp_last_kernel_parts_ms(srbdqp_handle* h, double* setup_ms, double* admm
     return SRBDQP_OK;
 }
 
-int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref,
-                                  const double* foot, const uint8_t* contact, const double* pcom,
-                                  const double* warm_u, const double* warm_y, double* u_out, double* x_out,
-                                  double* y_out, int32_t* status, int32_t* iters, void* stream) {
-    if (!h) return SRBDQP_E_INVALID;
+}  // extern "C"
+
+namespace {
+
+// common body of the device-buffer entry points; the element type of the caller's buffers is h->io_f32 ? float : double
+int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x_ref, const void* foot, const uint8_t* contact,
+                      const void* pcom, const void* warm_u, const void* warm_y, void* u_out, void* x_out, void* y_out,
+                      int32_t* status, int32_t* iters, void* stream) {
     if (B < 0 || (B > 0 && (!x0 || !x_ref || !foot || !contact || !u_out))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     KArgs a;
     std::memset(&a, 0, sizeof(a));
     fill_args(h->cfg, a);
-    a.x0 = x0; a.xref = x_ref; a.foot = foot; a.contact = contact; a.pcom = pcom;
-    a.warm_u = warm_u; a.warm_y = warm_y;
-    a.u_out = u_out; a.x_out = x_out; a.y_out = y_out; a.status = status; a.iters = iters;
+    a.x0 = static_cast<const double*>(x0); a.xref = static_cast<const double*>(x_ref); a.foot = static_cast<const double*>(foot);
+    a.contact = contact; a.pcom = static_cast<const double*>(pcom);
+    a.warm_u = static_cast<const double*>(warm_u); a.warm_y = static_cast<const double*>(warm_y);
+    a.u_out = static_cast<double*>(u_out); a.x_out = static_cast<double*>(x_out); a.y_out = static_cast<double*>(y_out);
+    a.status = status; a.iters = iters;
     a.B = B; a.mode = 0; a.stamps = h->stamps;
     if (h->signal_next) { a.done_flag = h->done_dev; a.done_count = h->done_count; a.done_value = h->done_seq; }
     hipStream_t lst = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
-    if (h->sched_hint && B > 1) {
+    if (h->sched_hint && B > 1 && (size_t)B <= h->sched_hint_len) {
         auto* slot = stream_slot(h, lst);
         if (!slot) return SRBDQP_E_INVALID;
         if ((size_t)B > slot->perm_cap) {
@@ -625,7 +680,7 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
         a.perm = slot->perm;
     }
     int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
-    const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h->cfg);
+    const int restart = (h->stamps || B < 1 || h->io_f32) ? 0 : restart_iter_of(h->cfg);
     if (!restart) return launch(h, a, lst, maxs);
 
     // ---- two passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those
@@ -647,41 +702,41 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0,
     return srbdqp_restart_pass(h, a1, lst, maxs, a.done_flag != nullptr);
 }
 
-int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,
-                           const uint8_t* contact, const double* pcom, const double* warm_u, const double* warm_y,
-                           double* u_out, double* x_out, double* y_out, int32_t* status, int32_t* iters) {
-    if (!h) return SRBDQP_E_INVALID;
+// common body of the host-buffer entry points (esz = sizeof the caller's element type)
+int solve_host_impl(srbdqp_handle* h, int32_t B, size_t esz, const void* x0, const void* x_ref, const void* foot,
+                    const uint8_t* contact, const void* pcom, const void* warm_u, const void* warm_y, void* u_out,
+                    void* x_out, void* y_out, int32_t* status, int32_t* iters) {
     if (B < 0 || (B > 0 && (!x0 || !x_ref || !foot || !contact || !u_out))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
     if (B == 0) return SRBDQP_OK;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t N = (size_t)h->cfg.horizon, n = 12 * N, m = 20 * N, b = (size_t)B;
     Carver sz(nullptr);
-    auto carve = [&](Carver& c, double*& dx0, double*& dxr, double*& dft, uint8_t*& dct, double*& dpc, double*& dwu,
-                     double*& dwy, double*& du, double*& dx, double*& dy, int32_t*& dst, int32_t*& dit) {
-        dx0 = c.take<double>(b * 13); dxr = c.take<double>(b * N * 13); dft = c.take<double>(b * N * 12);
+    auto carve = [&](Carver& c, char*& dx0, char*& dxr, char*& dft, uint8_t*& dct, char*& dpc, char*& dwu,
+                     char*& dwy, char*& du, char*& dx, char*& dy, int32_t*& dst, int32_t*& dit) {
+        dx0 = c.take<char>(b * 13 * esz); dxr = c.take<char>(b * N * 13 * esz); dft = c.take<char>(b * N * 12 * esz);
         dct = c.take<uint8_t>(b * N * 4);
-        dpc = pcom ? c.take<double>(b * N * 3) : nullptr;
-        dwu = warm_u ? c.take<double>(b * n) : nullptr;
-        dwy = warm_y ? c.take<double>(b * m) : nullptr;
-        du = c.take<double>(b * n);
-        dx = x_out ? c.take<double>(b * (N + 1) * 13) : nullptr;
-        dy = y_out ? c.take<double>(b * m) : nullptr;
+        dpc = pcom ? c.take<char>(b * N * 3 * esz) : nullptr;
+        dwu = warm_u ? c.take<char>(b * n * esz) : nullptr;
+        dwy = warm_y ? c.take<char>(b * m * esz) : nullptr;
+        du = c.take<char>(b * n * esz);
+        dx = x_out ? c.take<char>(b * (N + 1) * 13 * esz) : nullptr;
+        dy = y_out ? c.take<char>(b * m * esz) : nullptr;
         dst = c.take<int32_t>(b); dit = c.take<int32_t>(b);
     };
-    double *dx0, *dxr, *dft, *dpc, *dwu, *dwy, *du, *dx, *dy; uint8_t* dct; int32_t *dst, *dit;
+    char *dx0, *dxr, *dft, *dpc, *dwu, *dwy, *du, *dx, *dy; uint8_t* dct; int32_t *dst, *dit;
     carve(sz, dx0, dxr, dft, dct, dpc, dwu, dwy, du, dx, dy, dst, dit);
     int rc = ensure_ws(h, sz.off);
     if (rc != SRBDQP_OK) return rc;
     Carver cv(h->ws);
     carve(cv, dx0, dxr, dft, dct, dpc, dwu, dwy, du, dx, dy, dst, dit);
     hipStream_t st = h->stream;
-    HIP_TRY(h, hipMemcpyAsync(dx0, x0, b * 13 * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(dxr, x_ref, b * N * 13 * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(dft, foot, b * N * 12 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dx0, x0, b * 13 * esz, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dxr, x_ref, b * N * 13 * esz, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dft, foot, b * N * 12 * esz, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(dct, contact, b * N * 4, hipMemcpyHostToDevice, st));
-    if (pcom) HIP_TRY(h, hipMemcpyAsync(dpc, pcom, b * N * 3 * 8, hipMemcpyHostToDevice, st));
-    if (warm_u) HIP_TRY(h, hipMemcpyAsync(dwu, warm_u, b * n * 8, hipMemcpyHostToDevice, st));
-    if (warm_y) HIP_TRY(h, hipMemcpyAsync(dwy, warm_y, b * m * 8, hipMemcpyHostToDevice, st));
+    if (pcom) HIP_TRY(h, hipMemcpyAsync(dpc, pcom, b * N * 3 * esz, hipMemcpyHostToDevice, st));
+    if (warm_u) HIP_TRY(h, hipMemcpyAsync(dwu, warm_u, b * n * esz, hipMemcpyHostToDevice, st));
+    if (warm_y) HIP_TRY(h, hipMemcpyAsync(dwy, warm_y, b * m * esz, hipMemcpyHostToDevice, st));
     if (h->cfg.max_contacts_per_step <= 0) {   // pick the kernel instantiation from the batch's own contact flags
         int worst = 0;
         for (size_t q = 0; q < b * N && worst <= 2; ++q) {
@@ -691,16 +746,61 @@ int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B, const double* x0, const 
         }
         h->maxs_override = (worst <= 2) ? 2 : 4;
     }
-    rc = srbdqp_solve_batch_device_f64(h, B, dx0, dxr, dft, dct, dpc, dwu, dwy, du, dx, dy, dst, dit, st);
+    const int32_t* hint_keep = h->sched_hint;               // the dispatch hint belongs to the device-buffer API
+    h->sched_hint = nullptr;
+    rc = solve_device_impl(h, B, dx0, dxr, dft, dct, dpc, dwu, dwy, du, dx, dy, dst, dit, st);
+    h->sched_hint = hint_keep;
     h->maxs_override = 0;
     if (rc != SRBDQP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(u_out, du, b * n * 8, hipMemcpyDeviceToHost, st));
-    if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, dx, b * (N + 1) * 13 * 8, hipMemcpyDeviceToHost, st));
-    if (y_out) HIP_TRY(h, hipMemcpyAsync(y_out, dy, b * m * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(u_out, du, b * n * esz, hipMemcpyDeviceToHost, st));
+    if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, dx, b * (N + 1) * 13 * esz, hipMemcpyDeviceToHost, st));
+    if (y_out) HIP_TRY(h, hipMemcpyAsync(y_out, dy, b * m * esz, hipMemcpyDeviceToHost, st));
     if (status) HIP_TRY(h, hipMemcpyAsync(status, dst, b * 4, hipMemcpyDeviceToHost, st));
     if (iters) HIP_TRY(h, hipMemcpyAsync(iters, dit, b * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     return SRBDQP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref,
+                                  const double* foot, const uint8_t* contact, const double* pcom,
+                                  const double* warm_u, const double* warm_y, double* u_out, double* x_out,
+                                  double* y_out, int32_t* status, int32_t* iters, void* stream) {
+    if (!h) return SRBDQP_E_INVALID;
+    h->io_f32 = false;
+    return solve_device_impl(h, B, x0, x_ref, foot, contact, pcom, warm_u, warm_y, u_out, x_out, y_out, status, iters, stream);
+}
+
+int srbdqp_solve_batch_device_f32(srbdqp_handle* h, int32_t B, const float* x0, const float* x_ref,
+                                  const float* foot, const uint8_t* contact, const float* pcom,
+                                  const float* warm_u, const float* warm_y, float* u_out, float* x_out,
+                                  float* y_out, int32_t* status, int32_t* iters, void* stream) {
+    if (!h) return SRBDQP_E_INVALID;
+    h->io_f32 = true;
+    const int rc = solve_device_impl(h, B, x0, x_ref, foot, contact, pcom, warm_u, warm_y, u_out, x_out, y_out, status, iters, stream);
+    h->io_f32 = false;
+    return rc;
+}
+
+int srbdqp_solve_batch_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,
+                           const uint8_t* contact, const double* pcom, const double* warm_u, const double* warm_y,
+                           double* u_out, double* x_out, double* y_out, int32_t* status, int32_t* iters) {
+    if (!h) return SRBDQP_E_INVALID;
+    h->io_f32 = false;
+    return solve_host_impl(h, B, sizeof(double), x0, x_ref, foot, contact, pcom, warm_u, warm_y, u_out, x_out, y_out, status, iters);
+}
+
+int srbdqp_solve_batch_f32(srbdqp_handle* h, int32_t B, const float* x0, const float* x_ref, const float* foot,
+                           const uint8_t* contact, const float* pcom, const float* warm_u, const float* warm_y,
+                           float* u_out, float* x_out, float* y_out, int32_t* status, int32_t* iters) {
+    if (!h) return SRBDQP_E_INVALID;
+    h->io_f32 = true;
+    const int rc = solve_host_impl(h, B, sizeof(float), x0, x_ref, foot, contact, pcom, warm_u, warm_y, u_out, x_out, y_out, status, iters);
+    h->io_f32 = false;
+    return rc;
 }
 
 int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,
@@ -743,6 +843,64 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const dou
     HIP_TRY(h, hipMemcpyAsync(q_out, dq, b * n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(l_out, dl, b * m * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(ub_out, du, b * m * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return SRBDQP_OK;
+}
+
+int srbdqp_assemble_wrench_f64(srbdqp_handle* h, int32_t B, const double* x0, const double* x_ref, const double* foot,
+                               const uint8_t* contact, const double* pcom, double* T_out, double* q_out, double* blocks_out,
+                               double* goff_out) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!x0 || !x_ref || !foot || !contact || !T_out || !q_out || !blocks_out || !goff_out))) { h->err = "null pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = (size_t)h->cfg.horizon, n = 12 * N, ng = 6 * N, b = (size_t)B;
+    auto carve = [&](Carver& c, double*& dx0, double*& dxr, double*& dft, uint8_t*& dct, double*& dpc, double*& dT,
+                     double*& dq, double*& dbl, double*& dgo) {
+        dx0 = c.take<double>(b * 13); dxr = c.take<double>(b * N * 13); dft = c.take<double>(b * N * 12);
+        dct = c.take<uint8_t>(b * N * 4);
+        dpc = pcom ? c.take<double>(b * N * 3) : nullptr;
+        dT = c.take<double>(b * ng * ng); dq = c.take<double>(b * n); dbl = c.take<double>(b * n * 24); dgo = c.take<double>(b * (N + 1));
+    };
+    double *dx0, *dxr, *dft, *dpc, *dT, *dq, *dbl, *dgo; uint8_t* dct;
+    Carver sz(nullptr);
+    carve(sz, dx0, dxr, dft, dct, dpc, dT, dq, dbl, dgo);
+    int rc = ensure_ws(h, sz.off);
+    if (rc != SRBDQP_OK) return rc;
+    Carver cv(h->ws);
+    carve(cv, dx0, dxr, dft, dct, dpc, dT, dq, dbl, dgo);
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(dx0, x0, b * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dxr, x_ref, b * N * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dft, foot, b * N * 12 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dct, contact, b * N * 4, hipMemcpyHostToDevice, st));
+    if (pcom) HIP_TRY(h, hipMemcpyAsync(dpc, pcom, b * N * 3 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemsetAsync(dT, 0, b * ng * ng * 8, st));
+    HIP_TRY(h, hipMemsetAsync(dq, 0, b * n * 8, st));
+    HIP_TRY(h, hipMemsetAsync(dbl, 0, b * n * 24 * 8, st));
+    HIP_TRY(h, hipMemsetAsync(dgo, 0, b * (N + 1) * 8, st));
+    KArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_args(h->cfg, a);
+    a.x0 = dx0; a.xref = dxr; a.foot = dft; a.contact = dct; a.pcom = dpc;
+    a.P_out = dT; a.q_out = dq; a.l_out = dbl; a.ub_out = dgo;
+    a.B = B; a.mode = 1;
+    h->io_f32 = false;
+    switch (h->cfg.horizon) {
+        case 4: rc = launch_wrench<4>(h, a, st); break;
+        case 8: rc = launch_wrench<8>(h, a, st); break;
+        case 10: rc = launch_wrench<10>(h, a, st); break;
+        case 12: rc = launch_wrench<12>(h, a, st); break;
+        case 16: rc = launch_wrench<16>(h, a, st); break;
+        case 20: rc = launch_wrench<20>(h, a, st); break;
+        case 24: rc = launch_wrench<24>(h, a, st); break;
+        default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
+    }
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(T_out, dT, b * ng * ng * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(q_out, dq, b * n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(blocks_out, dbl, b * n * 24 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(goff_out, dgo, b * (N + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     return SRBDQP_OK;
 }

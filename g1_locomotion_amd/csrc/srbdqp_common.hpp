@@ -176,10 +176,10 @@ __device__ void load_and_linearise(const KArgs& a, int b, double* sm) {
         const double rx = sm[S::o_foot + k * 12 + 3 * ci + 0] - sm[S::o_pcom + k * 3 + 0];
         const double ry = sm[S::o_foot + k * 12 + 3 * ci + 1] - sm[S::o_pcom + k * 3 + 1];
         const double rz = sm[S::o_foot + k * 12 + 3 * ci + 2] - sm[S::o_pcom + k * 3 + 2];
-        double s0, s1, s2;   // column ax of skew(r)
-        if (ax == 0) { s0 = 0.0; s1 = rz;  s2 = -ry; }
-        else if (ax == 1) { s0 = -rz; s1 = 0.0; s2 = rx; }
-        else { s0 = ry;  s1 = -rx; s2 = 0.0; }
+        // column ax of skew(r) as selects (a three-way if chain on this value was miscompiled in srbdqp_wrench.hpp)
+        const double s0 = (ax == 0) ? 0.0 : ((ax == 1) ? -rz : ry);
+        const double s1 = (ax == 0) ? rz : ((ax == 1) ? 0.0 : -rx);
+        const double s2 = (ax == 0) ? -ry : ((ax == 1) ? rx : 0.0);
         double* J = sm + S::o_J + k * 36;
         J[0 * 12 + cc] = w00 * s0 + w01 * s1;
         J[1 * 12 + cc] = w01 * s0 + w11 * s1;

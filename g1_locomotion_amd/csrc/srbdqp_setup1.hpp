@@ -142,10 +142,10 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
             const double rx = sm[L1::o_foot + k * 12 + 3 * ci + 0] - sm[L1::o_pcom + k * 3 + 0];
             const double ry = sm[L1::o_foot + k * 12 + 3 * ci + 1] - sm[L1::o_pcom + k * 3 + 1];
             const double rz = sm[L1::o_foot + k * 12 + 3 * ci + 2] - sm[L1::o_pcom + k * 3 + 2];
-            double s0, s1, s2;   // column ax of skew(r)
-            if (ax == 0) { s0 = 0.0; s1 = rz;  s2 = -ry; }
-            else if (ax == 1) { s0 = -rz; s1 = 0.0; s2 = rx; }
-            else { s0 = ry;  s1 = -rx; s2 = 0.0; }
+            // column ax of skew(r) as selects (a three-way if chain on this value was miscompiled in srbdqp_wrench.hpp)
+            const double s0 = (ax == 0) ? 0.0 : ((ax == 1) ? -rz : ry);
+            const double s1 = (ax == 0) ? rz : ((ax == 1) ? 0.0 : -rx);
+            const double s2 = (ax == 0) ? -ry : ((ax == 1) ? rx : 0.0);
             double* J = sm + S::o_J + k * 36;
             J[0 * 12 + cc] = w00 * s0 + w01 * s1;
             J[1 * 12 + cc] = w01 * s0 + w11 * s1;

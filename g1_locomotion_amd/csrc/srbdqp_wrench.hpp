@@ -1,0 +1,1069 @@
+// srbdqp_wrench.hpp -- the general kernel ("wrench"): any contact pattern, horizons up to 24, fp64 or fp32 iterations.
+//
+// Presolve in two steps.  (1) Swing contacts are eliminated as in srbdqp_compact.hpp.  (2) A step's 3c stance-force
+// variables act on the body only through the 6-vector wrench g = W u, W = [J_e ... ; I I ...] (angular acceleration
+// I_w^-1 sum r x f, total force), and A'A is diagonal per contact (diag(2, 2, 4 mu^2 + 1)), so the reduced-KKT matrix of
+// the ADMM is  K = D + Y' S Y  with D DIAGONAL and S the Hessian in the per-step coordinates g_j: the 6 wrench
+// coordinates when the step has >= 3 stance contacts (Y_j = W_j), the 3c force variables themselves otherwise (Y_j = I).
+// Woodbury twice:
+//     K^-1 = Bd + V' T^-1 V,   T = S + E^-1,  E = Y D^-1 Y' (6x6 per step),  V = E^-1 Y D^-1,  Bd = D^-1 - D^-1 Y' V.
+// Only T (n_g x n_g, n_g <= 6N) is assembled, factored and inverted: full double support at N = 20 (BASELINE.json
+// configs[2]) is a 120 x 120 problem instead of 240 x 240 -- 8x less factor work, 3x less work per ADMM iteration -- and
+// T is far better conditioned than K (8e4 instead of 1e8 on that config).  Bd and V are 12 x 12 and 6 x 12 per step and
+// live in the registers of the step's lanes.  oracle/srbd_oracle.py wrench_reduce() restates this in NumPy.
+//
+// Mapping: 12 lanes per horizon step, 5 steps per wave (lanes 60..63 idle), NW = ceil(N / 5) waves per QP.  Lane ul of a
+// step group is at once force variable (contact ul / 3, axis ul % 3) -- a contact = 3 lanes carrying 2 + 2 + 1 rows, as in
+// srbdqp_split.hpp -- and half h = ul % 2 of row ul / 2 of T^-1 for that step.  Per ADMM iteration the 12 right-hand
+// sides of a step are exchanged inside the wave (no barrier), v = V w crosses the workgroup through a double-buffered
+// LDS vector (ONE barrier per iteration), t = T^-1 v is a register mat-vec (a half row per lane), and
+// x~ = x_q + Bd w + V' t is again local to the step.
+//
+// Precision (template parameter R): the set-up (assembly, Cholesky, T^-1) is always fp64.  R = float keeps T^-1, V, Bd
+// and the iterates in fp32 and reads / writes fp32 buffers.  What makes fp32 iterations converge at all is the split
+// x~ = x_q + K^-1 (sigma x + A'(rho z - y)) with x_q = -K^-1 q computed ONCE in fp64: q is O(1e4) in the scaled
+// variables and would otherwise drown the O(1) iterate in the mat-vec's cancellation; and the dual residual is
+// tracked as c = P x + q (recursion c~ = sigma (x - x~) - A' nu), which never sees q either.  R = double runs the same
+// recursions (the oracle twin is admm_solve_split()).
+//
+// The reference for all of this is the absent submodule g1_mpc; conventions from
+// g1_mujoco_sim/src/run_simulation.py:73-111.
+#pragma once
+#include "srbdqp_common.hpp"
+#include "srbdqp_admm.hpp"
+#include "srbdqp_mfma.hpp"
+
+namespace srbdqp {
+
+#ifndef SRBDQP_PHASE_LOCAL
+#define SRBDQP_PHASE_LOCAL(...) asm volatile("" : __VA_ARGS__)
+#endif
+
+template <int N>
+struct WrenchSmem {
+    static constexpr int n = 12 * N, m = 20 * N;
+    static constexpr int NW = (N + 4) / 5;                // waves per QP: 5 steps of 12 lanes per wave
+    static constexpr int BT = 64 * NW;
+    static constexpr int NG = 6 * N;                      // upper bound of n_g
+    static constexpr int NT = (NG + 15) / 16;
+    static constexpr int NTT = NT * (NT + 1) / 2;
+    static constexpr int TS = (NTT + NW - 1) / NW;        // tile slots per wave
+    static constexpr int WQ = (NT + NW - 1) / NW;         // W phase: tiles of a block row per wave
+    static constexpr int CHMAX = 2 * ((NG + 3) / 4);      // columns per half row of T^-1 (even)
+    static constexpr int NPAIR = N * (N + 1) / 2;
+    static constexpr int up2(int v) { return (v + 1) & ~1; }
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    // ---- persistent strip
+    static constexpr int o_x0 = 0;                        // 13 (+1)
+    static constexpr int o_tm = o_x0 + 14;                // 9N   Rz' per step
+    static constexpr int o_J = o_tm + up2(N * 9);         // 36N  I_w^-1 [r]x per step
+    static constexpr int o_red = o_J + N * 36;            // 32   reductions / check maxima / vote flags
+    static constexpr int o_ct = o_red + 32;               // 4N bytes of contact flags
+    static constexpr int o_misc = o_ct + up2((N * 4 + 7) / 8);   // [0] numerical failure
+    static constexpr int o_sq = o_misc + 4;               // 12   sqrt(q_diag)
+    static constexpr int o_int = o_sq + 12;               // ints: gsz[N], goff[N + 1], n_g, na
+    static constexpr int o_R = o_int + up2((2 * N + 6) / 2 + 1);
+    // ---- phase A (closed-form assembly)
+    static constexpr int o_xref = o_R;                    // 13N
+    static constexpr int o_foot = o_xref + up2(N * 13);   // 12N
+    static constexpr int o_pcom = o_foot + N * 12;        // 3N
+    static constexpr int o_cp = o_pcom + up2(N * 3);      // 9N   prefix sums of Rz'
+    static constexpr int o_eh = o_cp + up2(N * 9);        // 12N  Q^1/2 (A_qp x0 - x_ref)
+    static constexpr int o_t1 = o_eh + n;                 // 9N
+    static constexpr int o_t2 = o_t1 + up2(9 * N);        // 9N
+    static constexpr int o_mt = o_t2 + up2(9 * N);        // 9 NPAIR: M(j, m)
+    static constexpr int o_gv = o_mt + up2(9 * NPAIR);    // 9N   G'v tables
+    static constexpr int o_gx = o_gv + up2(9 * N);        // 12N  G x^0 (warm start)
+    static constexpr int o_tf = o_gx + n;                 // 6N
+    static constexpr int o_x0c = o_tf + 6 * N;            // 12N  warm start in the scaled variables
+    static constexpr int o_zt = o_x0c + n;                // 6 NG: wrench-space 6-vector of every g coordinate
+    static constexpr int o_ei = o_zt + 6 * NG;            // 36N  E^-1 per step
+    static constexpr int o_gs = o_ei + 36 * N;            // NG bytes: step of every g coordinate
+    static constexpr int endA = o_gs + up2((NG + 7) / 8);
+    // ---- phase B (tiles)
+    static constexpr int o_T = o_R;
+    static constexpr int endB = o_T + NTT * 256;
+    // ---- phase C (ADMM vectors; element type R <= 8 bytes, offsets in doubles)
+    static constexpr int VB = 2 * CHMAX + 8;              // one v buffer (elements)
+    static constexpr int o_wb = o_R;                      // NW x 64   right-hand sides, wave private
+    static constexpr int o_tb = o_wb + 64 * NW;           // NW x 32   t of the wave's steps, wave private
+    static constexpr int o_vb = o_tb + 32 * NW;           // 2 x VB    v = V w, double buffered
+    static constexpr int o_xs = o_vb + 2 * VB;            // n         full solution (scaled) for the roll-out
+    static constexpr int o_scr = o_xs + n;                // 12N       roll-out scratch
+    static constexpr int endC = o_scr + n + 2;
+    static constexpr int o_end = cmax(endA, cmax(endB, endC));
+    static constexpr size_t bytes = (size_t)o_end * sizeof(double);
+    static constexpr int lds_wgs = 163840 / (int)bytes;
+};
+
+// ---- small helpers on the iteration type ----------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_swap1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float bperm(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+__device__ __forceinline__ double bperm(double v, int src_lane) { return bperm_f64(v, src_lane); }
+__device__ __forceinline__ float rmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float rmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double rmin(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double rmax(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float rabs(float a) { return fabsf(a); }
+__device__ __forceinline__ double rabs(double a) { return fabs(a); }
+
+// workgroup-wide max of one non-negative value (NW waves); two barriers
+template <int NW>
+__device__ __forceinline__ double wg_max1(double v, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double x = wave_max_nonneg(v);
+    if (lane == 63) red[wave] = x;
+    __syncthreads();
+    double r = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r = fmax(r, red[w]);
+    __syncthreads();
+    return r;
+}
+
+// x~-part of one application of K^-1 = Bd + V' T^-1 V on the step-group mapping; all exchange through LDS.
+//   wv      this lane's right-hand side (0 on inactive lanes)
+//   returns (K^-1 w) for the variable of this lane
+// Used once in fp64 for x_q and every iteration in R.  `vb` is the v buffer to publish into; a workgroup barrier sits
+// between the publication of v and its use.  hook() runs right after that barrier (the ADMM loop reads the convergence
+// decision there).
+template <typename R, int CHMAX, class Hook>
+__device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, int sg, int ul, bool active_g, int Rrow, int CH,
+                                        const R (&kin)[CHMAX], const R (&vrow)[6], const R (&vcol)[6], const R (&bdrow)[12], Hook&& hook) {
+    typedef R R4 __attribute__((ext_vector_type(4)));
+    typedef R R2 __attribute__((ext_vector_type(2)));
+    const int h = ul & 1;
+    wbw[lane] = wv;
+    asm volatile("" ::: "memory");
+    R wg[12];
+    {
+        const R* src = wbw + 12 * sg;                       // 12 sg elements: 16-byte aligned for float (48 B) and double (96 B)
+        if constexpr (sizeof(R) == 4) {
+            const R4* s4 = reinterpret_cast<const R4*>(src);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const R4 v = s4[i]; wg[4 * i] = v[0]; wg[4 * i + 1] = v[1]; wg[4 * i + 2] = v[2]; wg[4 * i + 3] = v[3]; }
+        } else {
+            const R2* s2 = reinterpret_cast<const R2*>(src);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { const R2 v = s2[i]; wg[2 * i] = v[0]; wg[2 * i + 1] = v[1]; }
+        }
+    }
+    R vp = R(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vp = fma(vrow[i], h ? wg[6 + i] : wg[i], vp);
+    const R v = vp + dpp_swap1(vp);
+    if (active_g && h == 0) vb[Rrow] = v;
+    R xb = R(0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xb = fma(bdrow[i], wg[i], xb);
+    __syncthreads();
+    hook();
+    R tp;
+    {
+        R acc0 = R(0), acc1 = R(0), acc2 = R(0), acc3 = R(0);
+        const R* src = vb + CH * h;                         // CH even; VB multiple of 8: 16-byte aligned for double, 8-byte for float
+        if constexpr (sizeof(R) == 4) {
+            const R2* s2 = reinterpret_cast<const R2*>(src);
+#pragma unroll
+            for (int c = 0; c < CHMAX / 2; ++c) {
+                const R2 vv = s2[c];                            // columns past CH: zero padding of the buffer x zero kin
+                if (c & 1) { acc2 = fma(kin[2 * c], vv[0], acc2); acc3 = fma(kin[2 * c + 1], vv[1], acc3); }
+                else { acc0 = fma(kin[2 * c], vv[0], acc0); acc1 = fma(kin[2 * c + 1], vv[1], acc1); }
+            }
+        } else {
+            const R2* s2 = reinterpret_cast<const R2*>(src);
+            constexpr int NV = CHMAX / 2, BL = (NV <= 8) ? NV : 8, NB = (NV + BL - 1) / BL;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                if (blk == 0 || blk * 2 * BL < CH) {
+                    R2 vv[BL];
+#pragma unroll
+                    for (int i = 0; i < BL; ++i) vv[i] = (blk * BL + i < NV) ? s2[blk * BL + i] : (R2){R(0), R(0)};
+#pragma unroll
+                    for (int i = 0; i < BL; ++i) {
+                        const int c0 = 2 * (blk * BL + i);
+                        if (c0 + 1 < CHMAX) {
+                            if (i & 1) { acc2 = fma(kin[c0], vv[i][0], acc2); acc3 = fma(kin[c0 + 1], vv[i][1], acc3); }
+                            else { acc0 = fma(kin[c0], vv[i][0], acc0); acc1 = fma(kin[c0 + 1], vv[i][1], acc1); }
+                        }
+                    }
+                }
+            }
+        }
+        tp = (acc0 + acc1) + (acc2 + acc3);
+    }
+    const R tv = tp + dpp_swap1(tp);
+    if (h == 0) tbw[6 * sg + (ul >> 1)] = active_g ? tv : R(0);
+    asm volatile("" ::: "memory");
+    R xt = xb;
+    {
+        const R* src = tbw + 6 * sg;                        // 6 sg elements: 8-byte aligned (float), 16-byte (double)
+        const R2* s2 = reinterpret_cast<const R2*>(src);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const R2 vv = s2[i]; xt = fma(vcol[2 * i], vv[0], xt); xt = fma(vcol[2 * i + 1], vv[1], xt); }
+    }
+    asm volatile("" ::: "memory");
+    return xt;
+}
+
+// One QP (index b) on one workgroup of NW waves.  TIO = element type of the caller's buffers, R = iteration type.
+template <int N, typename R, typename TIO, int MODE>
+__device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* sm) {
+    using S = WrenchSmem<N>;
+    constexpr int n = S::n, m = S::m, NW = S::NW, BT = S::BT, TS = S::TS, CHMAX = S::CHMAX;
+    static_assert((S::o_R % 2) == 0 && (S::o_wb % 2) == 0 && (S::o_tb % 2) == 0 && (S::o_vb % 2) == 0, "16-byte alignment");
+    static_assert(S::NT <= 2 * NW || S::WQ >= 1, "");
+    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    int mcol = lane & 15, kq = lane >> 4;
+    double* T = sm + S::o_T;
+    int* igsz = reinterpret_cast<int*>(sm + S::o_int);            // gsz[N]
+    int* igoff = igsz + N;                                        // goff[N + 1]
+    int* imisc = igoff + N + 1;                                   // [0] n_g, [1] na
+    uint8_t* sct = reinterpret_cast<uint8_t*>(sm + S::o_ct);
+    uint8_t* gstep = reinterpret_cast<uint8_t*>(sm + S::o_gs);
+    const double* SQ = sm + S::o_sq;
+    const double* CP = sm + S::o_cp;
+    const TIO* gwu = reinterpret_cast<const TIO*>(a.warm_u);
+    const TIO* gwy = reinterpret_cast<const TIO*>(a.warm_y);
+
+    // ================= load (coalesced, one batch of loads) + linearise (a5) =================
+    SRBDQP_STAMP(a, b, 0);
+    {
+        const TIO* gx0 = reinterpret_cast<const TIO*>(a.x0) + (size_t)b * 13;
+        const TIO* gxr = reinterpret_cast<const TIO*>(a.xref) + (size_t)b * N * 13;
+        const TIO* gft = reinterpret_cast<const TIO*>(a.foot) + (size_t)b * N * 12;
+        const uint8_t* gct = a.contact + (size_t)b * N * 4;
+        constexpr int RX = (N * 13 + BT - 1) / BT, RF = (N * 12 + BT - 1) / BT;
+        static_assert(N * 4 <= BT && N * 3 <= BT, "one thread per contact flag / pcom entry");
+        const TIO* gpc = a.pcom ? reinterpret_cast<const TIO*>(a.pcom) + (size_t)b * N * 3 : gx0;
+        const TIO v_x0 = gx0[t < 13 ? t : 0];
+        const uint8_t v_ct = gct[t < N * 4 ? t : 0];
+        const TIO v_pc = gpc[(a.pcom && t < N * 3) ? t : 0];
+        TIO v_xr[RX], v_ft[RF];
+#pragma unroll
+        for (int r = 0; r < RX; ++r) { const int i = t + r * BT; v_xr[r] = gxr[i < N * 13 ? i : 0]; }
+#pragma unroll
+        for (int r = 0; r < RF; ++r) { const int i = t + r * BT; v_ft[r] = gft[i < N * 12 ? i : 0]; }
+        if (t < 13) sm[S::o_x0 + t] = (double)v_x0;
+        if (t >= 32 && t < 44) sm[S::o_sq + t - 32] = a.sqrtq[t - 32];
+#pragma unroll
+        for (int r = 0; r < RX; ++r) { const int i = t + r * BT; if (i < N * 13) sm[S::o_xref + i] = (double)v_xr[r]; }
+#pragma unroll
+        for (int r = 0; r < RF; ++r) { const int i = t + r * BT; if (i < N * 12) sm[S::o_foot + i] = (double)v_ft[r]; }
+        if (t < N * 4) sct[t] = v_ct ? 1 : 0;
+        if (a.pcom && t < N * 3) sm[S::o_pcom + t] = (double)v_pc;
+        if (t == 0) { sm[S::o_misc] = 0.0; sm[S::o_misc + 1] = 0.0; }
+        __syncthreads();
+        if (!a.pcom && t < N * 3) sm[S::o_pcom + t] = sm[S::o_xref + (t / 3) * 13 + 3 + (t % 3)];
+        if (t < N) {
+            double sn, cs;
+            sincos(sm[S::o_xref + t * 13 + 2], &sn, &cs);
+            double* Tm = sm + S::o_tm + t * 9;
+            Tm[0] = cs;  Tm[1] = sn;  Tm[2] = 0.0;
+            Tm[3] = -sn; Tm[4] = cs;  Tm[5] = 0.0;
+            Tm[6] = 0.0; Tm[7] = 0.0; Tm[8] = 1.0;
+        }
+        if (t == BT - 1) {   // presolve bookkeeping: g coordinates per step (serial over <= 24 steps)
+            int off = 0, na = 0;
+            for (int k = 0; k < N; ++k) {
+                const int c = sct[4 * k] + sct[4 * k + 1] + sct[4 * k + 2] + sct[4 * k + 3];
+                const int g = (c >= 3) ? 6 : 3 * c;
+                igsz[k] = g; igoff[k] = off;
+                for (int r = 0; r < g; ++r) gstep[off + r] = (uint8_t)k;
+                off += g; na += c;
+            }
+            igoff[N] = off; imisc[0] = off; imisc[1] = na;
+        }
+        __syncthreads();
+        if (t < 9) {
+            double acc = 0.0;
+            for (int k = 0; k < N; ++k) { acc += sm[S::o_tm + k * 9 + t]; sm[S::o_cp + k * 9 + t] = acc; }
+        }
+        static_assert(N * 12 <= BT, "one thread per entry of a J row");
+        if (t < N * 12) {   // J_k[:, 3 ci + ax] = Iw^-1 skew(r)[:, ax]
+            const int i = t;
+            const int k = i / 12, cc = i - 12 * k, ci = cc / 3, ax = cc - 3 * ci;
+            const double cs = sm[S::o_tm + k * 9 + 0], sn = sm[S::o_tm + k * 9 + 1];
+            const double i0 = a.iinv[0], i1 = a.iinv[1], i2 = a.iinv[2];
+            const double w00 = cs * cs * i0 + sn * sn * i1, w01 = cs * sn * (i0 - i1), w11 = sn * sn * i0 + cs * cs * i1;
+            const double rx = sm[S::o_foot + k * 12 + 3 * ci + 0] - sm[S::o_pcom + k * 3 + 0];
+            const double ry = sm[S::o_foot + k * 12 + 3 * ci + 1] - sm[S::o_pcom + k * 3 + 1];
+            const double rz = sm[S::o_foot + k * 12 + 3 * ci + 2] - sm[S::o_pcom + k * 3 + 2];
+            // column ax of skew(r), as selects: hipcc (ROCm 7.2) lowers the three-way if / else-if / else on this 16-bit
+            // value as a switch and loses the "s1 = -rx" of the last arm for some instantiations (seen in the ISA at N = 12)
+            const double s0 = (ax == 0) ? 0.0 : ((ax == 1) ? -rz : ry);
+            const double s1 = (ax == 0) ? rz : ((ax == 1) ? 0.0 : -rx);
+            const double s2 = (ax == 0) ? -ry : ((ax == 1) ? rx : 0.0);
+            double* J = sm + S::o_J + k * 36;
+            J[0 * 12 + cc] = w00 * s0 + w01 * s1;
+            J[1 * 12 + cc] = w01 * s0 + w11 * s1;
+            J[2 * 12 + cc] = i2 * s2;
+        }
+        __syncthreads();
+    }
+    const int n_g = imisc[0];
+    const int na = imisc[1];
+
+    // ---- lane roles
+    const int sg = lane / 12, ul = lane - 12 * sg;
+    const int jstep = 5 * w + sg;
+    const bool stepok = (sg < 5) && (jstep < N);
+    const int js = stepok ? jstep : 0;
+    const int ci = ul / 3, ax = ul - 3 * ci;
+    const int rl = ul >> 1, h = ul & 1;
+    const int f0 = sct[4 * js], f1 = sct[4 * js + 1], f2 = sct[4 * js + 2], f3 = sct[4 * js + 3];
+    const int cj = f0 + f1 + f2 + f3;
+    const bool wrench = cj >= 3;
+    const bool active_u = stepok && sct[4 * js + ci] != 0;
+    const int gsj = stepok ? igsz[js] : 0;
+    const bool active_g = rl < gsj;
+    const int Rrow = igoff[js] + (active_g ? rl : 0);
+    const int uvar = 12 * js + ul;                                   // index in the full 12N vector
+    const int cbase = 12 * sg + 3 * ci;                              // first lane of this contact in the wave
+    const int irowA = 20 * js + 5 * ci + ((ax < 2) ? 2 * ax : 4), irowB = 20 * js + 5 * ci + 2 * ax + 1;
+
+    if constexpr (MODE == 1) { if (na == 0) return; }   // assembly dump of an empty problem: all zeros (the host cleared the buffers)
+    if (na == 0) {   // nothing to solve: all forces 0
+        for (int c = t; c < n; c += BT) sm[S::o_xs + c] = 0.0;
+        if (a.y_out) for (int i = t; i < m; i += BT) reinterpret_cast<TIO*>(a.y_out)[(size_t)b * m + i] = TIO(0);
+        if (t == 0) { if (a.status) a.status[b] = 1; if (a.iters) a.iters[b] = 0; }
+        __syncthreads();
+    } else {
+
+    // ================= tables of the closed-form assembly (a6 + a7; srbdqp_compact.hpp has the derivation) =================
+    const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = dt2 * a.inv_mass;
+    double* T1 = sm + S::o_t1;
+    double* T2 = sm + S::o_t2;
+    double* MT = sm + S::o_mt;
+    double* GV = sm + S::o_gv;
+    for (int k = t; k < n; k += BT) {
+        const int i = k / 12, kk = k - 12 * i;
+        sm[S::o_eh + k] = SQ[kk] * (free_response<N, S>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
+    }
+    for (int idx = t; idx < 9 * N; idx += BT) {
+        const int mm = idx / 9, pq = idx - 9 * mm, p = pq / 3, q = pq - 3 * p;
+        const double* Cm = CP + mm * 9;
+        const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2];
+        const double m0p = Cm[p], m1p = Cm[3 + p], m2p = Cm[6 + p], m0q = Cm[q], m1q = Cm[3 + q], m2q = Cm[6 + q], mpq = Cm[pq];
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+        for (int i = 0; i < N; ++i) {
+            const double* Ci = CP + i * 9;
+            const double on = (i >= mm) ? 1.0 : 0.0;
+            const double d0p = Ci[p] - m0p, d1p = Ci[3 + p] - m1p, d2p = Ci[6 + p] - m2p;
+            const double d0q = Ci[q] - m0q, d1q = Ci[3 + q] - m1q, d2q = Ci[6 + q] - m2q;
+            s1 = fma(on, Ci[pq] - mpq, s1);
+            s2 = fma(on, (w0 * d0p) * d0q + (w1 * d1p) * d1q + (w2 * d2p) * d2q, s2);
+        }
+        T1[idx] = s1;
+        T2[idx] = s2;
+    }
+    __syncthreads();
+    auto gt_tables = [&](const double* vec) {
+        for (int idx = t; idx < 9 * N; idx += BT) {
+            const int j = idx / 9, comp = idx - 9 * j;
+            const double* Cj = CP + j * 9;
+            double acc = 0.0;
+            if (comp < 3) {
+                const double c0 = Cj[comp], c1 = Cj[3 + comp], c2 = Cj[6 + comp];
+                const double q0 = SQ[0] * dt2, q1 = SQ[1] * dt2, q2 = SQ[2] * dt2, qw = SQ[6 + comp] * dt;
+#pragma unroll 4
+                for (int i = 0; i < N; ++i) {
+                    const double* Ci = CP + i * 9;
+                    const double* v = vec + 12 * i;
+                    const double on = (i >= j) ? 1.0 : 0.0;
+                    acc = fma(on, (Ci[comp] - c0) * (q0 * v[0]) + (Ci[3 + comp] - c1) * (q1 * v[1]) + (Ci[6 + comp] - c2) * (q2 * v[2]) + qw * v[6 + comp], acc);
+                }
+            } else {
+                const int kk = (comp < 6) ? comp : 3 + comp;
+#pragma unroll 4
+                for (int i = 0; i < N; ++i) {
+                    const double wgt = (i >= j) ? ((comp < 6) ? (double)(i - j) : 1.0) : 0.0;
+                    acc = fma(wgt, vec[12 * i + kk], acc);
+                }
+            }
+            GV[idx] = acc;
+        }
+    };
+    // (G'v)[u] for this lane's force variable, from the tables
+    auto gt_eval_u = [&]() -> double {
+        const double* J = sm + S::o_J + js * 36 + ul;
+        const double* g = GV + 9 * js;
+        return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
+    };
+    gt_tables(sm + S::o_eh);
+    for (int idx = t; idx < 9 * S::NPAIR; idx += BT) {   // M(j, m), j <= m, at MT[9 (m (m + 1) / 2 + j)]
+        const int pair = idx / 9, pq = idx - 9 * pair, p = pq / 3, q = pq - 3 * p;
+        int mm = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
+        mm += ((mm + 1) * (mm + 2) / 2 <= pair) ? 1 : 0;
+        mm -= (mm * (mm + 1) / 2 > pair) ? 1 : 0;
+        const int j = pair - mm * (mm + 1) / 2;
+        const double* Cm = CP + mm * 9;
+        const double* Cj = CP + j * 9;
+        const double* t1 = T1 + mm * 9;
+        double v = T2[mm * 9 + pq];
+        v += (Cm[p] - Cj[p]) * (SQ[0] * SQ[0]) * t1[q] + (Cm[3 + p] - Cj[3 + p]) * (SQ[1] * SQ[1]) * t1[3 + q] + (Cm[6 + p] - Cj[6 + p]) * (SQ[2] * SQ[2]) * t1[6 + q];
+        v *= dt2 * dt2;
+        if (p == q) v += (double)(N - mm) * dt2 * SQ[6 + p] * SQ[6 + p];
+        MT[idx] = v;
+    }
+    __syncthreads();
+    SRBDQP_STAMP(a, b, 1);
+    const double qv = active_u ? gt_eval_u() : 0.0;                  // gradient of this lane's variable
+#ifdef SRBDQP_WRENCH_DEBUG
+    if constexpr (MODE == 1) {   // raw LDS image after the tables (diagnostic builds only)
+        double* out = a.P_out + (size_t)b * (S::NG * S::NG);
+        for (int i = t; i < S::NG * S::NG && i < S::o_end; i += BT) out[i] = sm[i];
+        return;
+    }
+#endif
+    double px0 = 0.0, x_init = 0.0;
+    if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0 (u space, swing variables 0)
+        double* TF = sm + S::o_tf;
+        x_init = active_u ? (double)gwu[(size_t)b * n + uvar] / a.s : 0.0;
+        if (stepok) sm[S::o_x0c + uvar] = x_init;
+        __syncthreads();
+        for (int idx = t; idx < 6 * N; idx += BT) {   // per step: tau_j = J_j x_j (3), f_j = sum of contact forces (3)
+            const int j = idx / 6, comp = idx - 6 * j;
+            const double* x = sm + S::o_x0c + 12 * j;
+            double acc = 0.0;
+            if (comp < 3) {
+                const double* J = sm + S::o_J + j * 36 + comp * 12;
+                for (int c = 0; c < 12; ++c) acc += J[c] * x[c];
+            } else {
+                acc = x[comp - 3] + x[comp] + x[comp + 3] + x[comp + 6];
+            }
+            TF[idx] = acc;
+        }
+        __syncthreads();
+        for (int k = t; k < n; k += BT) {   // G x^0, row kk of step i
+            const int i = k / 12, kk = k - 12 * i;
+            double acc = 0.0;
+            if (kk < 3) {
+                const double* Ci = CP + i * 9 + kk * 3;
+                for (int j = 0; j <= i; ++j) {
+                    const double* Cj = CP + j * 9 + kk * 3;
+                    const double* tau = TF + 6 * j;
+                    acc += (Ci[0] - Cj[0]) * tau[0] + (Ci[1] - Cj[1]) * tau[1] + (Ci[2] - Cj[2]) * tau[2];
+                }
+                acc *= dt2;
+            } else if (kk < 6) {
+                for (int j = 0; j <= i; ++j) acc += (double)(i - j) * TF[6 * j + kk];
+                acc *= dt2m;
+            } else if (kk < 9) {
+                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
+                acc *= dt;
+            } else {
+                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
+                acc *= dtm;
+            }
+            sm[S::o_gx + k] = SQ[kk] * a.s * acc;
+        }
+        __syncthreads();
+        gt_tables(sm + S::o_gx);
+        __syncthreads();
+        px0 = active_u ? gt_eval_u() + a.rs2 * x_init : 0.0;
+    }
+
+    // ================= per-step wrench blocks: E^-1, V, Bd (registers of the step's lanes) =================
+    const double dxy = a.rs2 + a.sigma + 2.0 * rho_b, dz = a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b;
+    const double idxy = 1.0 / dxy, idz = 1.0 / dz;
+    double vrow[6], vcol[6], bdrow[12];
+    {
+        const double* Jj = sm + S::o_J + js * 36;
+        const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
+        double* ZT = sm + S::o_zt;
+        double* EI = sm + S::o_ei + 36 * js;
+        if (wrench) {
+            // E = W D^-1 W' (6 x 6, SPD): every lane of the step forms and inverts it redundantly in registers
+            double Em[6][6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Em[p][q] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int a2 = 0; a2 < 3; ++a2) {
+                    const int u2 = 3 * c + a2;
+                    const double wgt = fl[c] * ((a2 < 2) ? idxy : idz);
+                    const double j0 = Jj[u2], j1 = Jj[12 + u2], j2 = Jj[24 + u2];
+                    const double jw[3] = {j0 * wgt, j1 * wgt, j2 * wgt};
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        Em[p][0] = fma(jw[p], j0, Em[p][0]); Em[p][1] = fma(jw[p], j1, Em[p][1]); Em[p][2] = fma(jw[p], j2, Em[p][2]);
+                        Em[p][3 + a2] += jw[p];
+                    }
+                    Em[3 + a2][3 + a2] += wgt;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Em[3 + q][p] = Em[p][3 + q];
+            // Cholesky E = L L', Li = L^-1, E^-1 = Li' Li
+            double Lm[6][6], Li[6][6];
+            bool okE = true;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                double d = Em[p][p];
+#pragma unroll
+                for (int k2 = 0; k2 < p; ++k2) d = fma(-Lm[p][k2], Lm[p][k2], d);
+                okE = okE && (d > 0.0);
+                const double inv = 1.0 / sqrt(d);
+                Lm[p][p] = d * inv;
+                Li[p][p] = inv;
+#pragma unroll
+                for (int q = p + 1; q < 6; ++q) {
+                    double v = Em[q][p];
+#pragma unroll
+                    for (int k2 = 0; k2 < p; ++k2) v = fma(-Lm[q][k2], Lm[p][k2], v);
+                    Lm[q][p] = v * inv;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int r = c + 1; r < 6; ++r) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int k2 = c; k2 < r; ++k2) v = fma(Lm[r][k2], Li[k2][c], v);
+                    Li[r][c] = -v * Li[r][r];
+                }
+            double Ei[6][6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int q = p; q < 6; ++q) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int k2 = q; k2 < 6; ++k2) v = fma(Li[k2][p], Li[k2][q], v);
+                    Ei[p][q] = v; Ei[q][p] = v;
+                }
+            if (!okE && stepok && ul == 0) sm[S::o_misc] = 1.0;   // 4 collinear contact points: E singular
+            // row rl of E^-1 (select chain: no runtime-indexed register array)
+            double er[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) er[c] = (rl == 0) ? Ei[0][c] : (rl == 1) ? Ei[1][c] : (rl == 2) ? Ei[2][c] : (rl == 3) ? Ei[3][c] : (rl == 4) ? Ei[4][c] : Ei[5][c];
+            if (stepok) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    EI[6 * rl + 3 * h + i] = h ? er[3 + i] : er[i];
+                    ZT[6 * Rrow + 3 * h + i] = (3 * h + i == rl) ? 1.0 : 0.0;
+                }
+            }
+            // V[rl][6 h + i] = wgt (er[0..2] . J[:, u'] + er[3 + a'])
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int u2 = 6 * h + i;
+                const double flc = (u2 / 3 == 0) ? fl[0] : (u2 / 3 == 1) ? fl[1] : (u2 / 3 == 2) ? fl[2] : fl[3];
+                const double wgt = flc * (((i % 3) < 2) ? idxy : idz);
+                vrow[i] = wgt * (er[0] * Jj[u2] + er[1] * Jj[12 + u2] + er[2] * Jj[24 + u2] + er[3 + (i % 3)]);
+            }
+            // y = E^-1 omega_u, omega_u = [J[:, ul]; e_ax]
+            const double wu = active_u ? ((ax < 2) ? idxy : idz) : 0.0;
+            const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
+            double yv[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double ea = (ax == 0) ? Ei[r][3] : (ax == 1) ? Ei[r][4] : Ei[r][5];
+                yv[r] = Ei[r][0] * j0 + Ei[r][1] * j1 + Ei[r][2] * j2 + ea;
+                vcol[r] = wu * yv[r];
+            }
+#pragma unroll
+            for (int u2 = 0; u2 < 12; ++u2) {
+                const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
+                const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
+                bdrow[u2] = -wu * wgt2 * dotv;
+            }
+            // the diagonal term of D^-1 (static index: select chain over the unrolled loop)
+#pragma unroll
+            for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] += (u2 == ul) ? wu : 0.0;
+        } else {
+            // identity coordinates: g row r <-> the r-th stance force variable of the step
+            const int before = (ci > 0 ? f0 : 0) + (ci > 1 ? f1 : 0) + (ci > 2 ? f2 : 0);   // stance contacts before ci
+            const int rank = 3 * before + ax;                                                // g row of this lane's variable
+            // variable of g row rl: contact = the (rl / 3)-th stance contact
+            const int want = rl / 3;
+            int cc = -1, seen = 0;
+            if (f0) { if (seen == want && cc < 0) cc = 0; ++seen; }
+            if (f1) { if (seen == want && cc < 0) cc = 1; ++seen; }
+            if (f2) { if (seen == want && cc < 0) cc = 2; ++seen; }
+            if (f3) { if (seen == want && cc < 0) cc = 3; ++seen; }
+            const int ug = (cc >= 0 ? 3 * cc : 0) + (rl % 3);        // variable (0..11) of g row rl
+#pragma unroll
+            for (int i = 0; i < 6; ++i) vrow[i] = (active_g && (6 * h + i == ug)) ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) vcol[r] = (active_u && r == rank) ? 1.0 : 0.0;
+#pragma unroll
+            for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] = 0.0;
+            if (stepok && active_g) {
+                const double dd = ((rl % 3) < 2) ? dxy : dz;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    EI[6 * rl + 3 * h + i] = (3 * h + i == rl) ? dd : 0.0;
+                    ZT[6 * Rrow + 3 * h + i] = h ? (((rl % 3) == i) ? 1.0 : 0.0) : Jj[12 * i + ug];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (MODE == 1) { if (sm[S::o_misc] != 0.0) { if (t == 0) a.ub_out[(size_t)b * (N + 1) + N] = -1.0; return; } }
+    if (sm[S::o_misc] != 0.0) {   // degenerate contact geometry: report, return zero forces
+        for (int c = t; c < n; c += BT) sm[S::o_xs + c] = 0.0;
+        if (a.y_out) for (int i = t; i < m; i += BT) reinterpret_cast<TIO*>(a.y_out)[(size_t)b * m + i] = TIO(0);
+        if (t == 0) { if (a.status) a.status[b] = -1; if (a.iters) a.iters[b] = 0; }
+        __syncthreads();
+    } else {
+    SRBDQP_STAMP(a, b, 2);
+
+    // ================= phase H: T = S + E^-1 entry by entry into the C-layout register tiles =================
+    const int NT = (n_g + 15) >> 4;
+    const int NTT = (NT * (NT + 1)) >> 1;
+    int ta[TS], tb[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int id = NW * s + w;
+        int bb = 0;
+        while (((bb + 1) * (bb + 2)) / 2 <= id) ++bb;
+        tb[s] = (id < NTT) ? bb : -1;
+        ta[s] = (id < NTT) ? id - (bb * (bb + 1)) / 2 : -1;
+    }
+    v4d acc[TS];
+    {
+        const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
+        const double* ZT = sm + S::o_zt;
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (ta[s] >= 0) {
+                const int c = 16 * tb[s] + mcol;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 16 * ta[s] + kq + 4 * q;
+                    const bool in = (r < n_g) && (c < n_g);
+                    const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;
+                    const int j = gstep[lo], mm = gstep[hi];
+                    const double* z1 = ZT + 6 * lo;
+                    const double* z2 = ZT + 6 * hi;
+                    const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
+                    const double x0 = z2[0], x1 = z2[1], x2 = z2[2];
+                    double v = z1[0] * (M[0] * x0 + M[1] * x1 + M[2] * x2) + z1[1] * (M[3] * x0 + M[4] * x1 + M[5] * x2) +
+                               z1[2] * (M[6] * x0 + M[7] * x1 + M[8] * x2);
+                    const int Ls = N - mm, d = mm - j;
+                    const double sp = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2)), ls = (double)Ls;
+#pragma unroll
+                    for (int a1 = 0; a1 < 3; ++a1)
+                        v = fma(z1[3 + a1] * z2[3 + a1], SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls, v);
+                    double val = s2 * v;
+                    if (j == mm) val += sm[S::o_ei + 36 * j + 6 * (lo - igoff[j]) + (hi - igoff[j])];
+                    acc[s][q] = in ? val : ((r == c) ? 1.0 : 0.0);               // padding -> identity
+                }
+            }
+        }
+    }
+    SRBDQP_STAMP(a, b, 3);
+    __syncthreads();
+    if constexpr (MODE == 1) {   // assembly dump (tests): T dense [NG][NG], then q[12N], V rows / Bd rows per lane, goff
+        double* out = a.P_out + (size_t)b * (S::NG * S::NG);
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            if (ta[s] >= 0) {
+                const int c = 16 * tb[s] + mcol;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 16 * ta[s] + kq + 4 * q;
+                    if (r < S::NG && c < S::NG) {
+                        const double v = (r < n_g && c < n_g) ? acc[s][q] : 0.0;
+                        out[r * S::NG + c] = v;
+                        out[c * S::NG + r] = v;
+                    }
+                }
+            }
+        }
+        if (stepok) {
+            a.q_out[(size_t)b * n + uvar] = qv;
+            double* vo = a.l_out + (size_t)b * (24 * n) + 24 * uvar;   // per force variable: Bd row (12), V column (6), V half row (6)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) vo[i] = bdrow[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { vo[12 + i] = vcol[i]; vo[18 + i] = vrow[i]; }
+        }
+        if (t <= N) a.ub_out[(size_t)b * (N + 1) + t] = (double)igoff[t];
+        return;
+    } else {
+
+    // ================= phase F: tiled right-looking Cholesky T = U'U, trailing tiles in registers =================
+    SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
+    for (int j = 0; j < NT; ++j) {
+        double* Djj = T + tile_id(j, j) * 256;
+        {
+            bool mine = false;
+            v4d d = acc[0];
+#pragma unroll
+            for (int s = 0; s < TS; ++s)
+                if (ta[s] == j && tb[s] == j) { mine = true; d = acc[s]; }
+            if (mine) {
+                int lane_j = lane;
+                SRBDQP_PHASE_LOCAL("+v"(lane_j));
+                bool ok;
+                const v4d winv = diag16_invert_mfma(d, lane_j, ok);
+                store_tile<true>(Djj, winv, lane_j);
+                if (!ok && lane == 0) sm[S::o_misc] = 1.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            if (ta[s] == j && tb[s] > j) {
+                v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double av = Djj[mcol * 16 + (k ^ mcol)];
+                    av = (k <= mcol) ? av : 0.0;
+                    o = mfma_f64(av, acc[s][r], o);
+                }
+                acc[s] = o;
+                store_tile<false>(T + tile_id(j, tb[s]) * 256, o, lane);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            if (ta[s] > j) {
+                const double* Ua = T + tile_id(j, ta[s]) * 256;
+                const double* Ub = T + tile_id(j, tb[s]) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    acc[s] = mfma_f64(-Ua[k * 16 + mcol], Ub[k * 16 + mcol], acc[s]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    SRBDQP_STAMP(a, b, 4);
+
+    // ================= phase W: W = L^-1 block row by block row, in place over U =================
+    SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
+    for (int i = 1; i < NT; ++i) {
+        v4d res[S::WQ];
+        const double* Dii = T + tile_id(i, i) * 256;
+#pragma unroll
+        for (int q = 0; q < S::WQ; ++q) {
+            const int j = w + NW * q;
+            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (j < i) {
+                v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
+                {
+                    const double* Uji = T + tile_id(j, i) * 256;
+                    const double* Djj = T + tile_id(j, j) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * r + kq;
+                        double bv = Djj[k * 16 + (mcol ^ k)];
+                        bv = (mcol <= k) ? bv : 0.0;
+                        o = mfma_f64(Uji[k * 16 + mcol], bv, o);
+                    }
+                }
+                for (int k2 = j + 1; k2 < i; ++k2) {
+                    const double* Uki = T + tile_id(k2, i) * 256;
+                    const double* Wkj = T + tile_id(j, k2) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * r + kq;
+                        o = mfma_f64(Uki[k * 16 + mcol], Wkj[k * 16 + mcol], o);
+                    }
+                }
+                v4d o2 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double av = Dii[mcol * 16 + (k ^ mcol)];
+                    av = (k <= mcol) ? -av : 0.0;
+                    o2 = mfma_f64(av, o[r], o2);
+                }
+                res[q] = o2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < S::WQ; ++q) {
+            const int j = w + NW * q;
+            if (j < i) store_tile<false>(T + tile_id(j, i) * 256, res[q], lane);
+        }
+        __syncthreads();
+    }
+    SRBDQP_STAMP(a, b, 5);
+
+    // ================= phase I: T^-1 = W'W =================
+    SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (ta[s] >= 0) {
+            const int ia = ta[s], ib = tb[s];
+            const double* Dbb = T + tile_id(ib, ib) * 256;
+            {
+                const double* Wba = T + tile_id(ia, ib) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    double dv = Dbb[k * 16 + (mcol ^ k)];
+                    dv = (mcol <= k) ? dv : 0.0;
+                    const double av = (ia < ib) ? Wba[k * 16 + mcol] : dv;
+                    acc[s] = mfma_f64(av, dv, acc[s]);
+                }
+            }
+            for (int i = ib + 1; i < NT; ++i) {
+                const double* Wia = T + tile_id(ia, i) * 256;
+                const double* Wib = T + tile_id(ib, i) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * r + kq;
+                    acc[s] = mfma_f64(Wia[k * 16 + mcol], Wib[k * 16 + mcol], acc[s]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TS; ++s)
+        if (ta[s] >= 0) store_tile<true>(T + tile_id(ta[s], tb[s]) * 256, acc[s], lane);
+    __syncthreads();
+    SRBDQP_STAMP(a, b, 6);
+
+    // ================= half rows of T^-1 (fp64), then x_q = -K^-1 q in fp64 =================
+    const int CH = 2 * ((n_g + 3) / 4);
+    double kin64[CHMAX];
+    {
+        const int rr = active_g ? Rrow : 0;
+#pragma unroll
+        for (int cc = 0; cc < CHMAX; ++cc) {
+            const int c = CH * h + cc;
+            const bool ok = active_g && (cc < CH) && (c < n_g);
+            const int cs = ok ? c : 0;
+            const int lo = (rr <= cs) ? rr : cs, hi = (rr <= cs) ? cs : rr;
+            const int row = lo & 15, col = hi & 15;
+            const double v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
+            kin64[cc] = ok ? v : 0.0;
+        }
+    }
+    const bool failed = sm[S::o_misc] != 0.0;
+    __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
+    int status = -1, iters = 0;
+    R x = R(0), yA = R(0), yB = R(0);
+    if (!failed) {
+        double xq;
+        {
+            double* wbw = sm + S::o_wb + 64 * w;
+            double* tbw = sm + S::o_tb + 32 * w;
+            double* vb = sm + S::o_vb;
+            for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
+            __syncthreads();
+            xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, [] {});
+            xq = active_u ? xq : 0.0;
+            __syncthreads();
+        }
+        SRBDQP_STAMP(a, b, 7);
+
+        // ================= ADMM iterations (a9) in R =================
+        R* wbw = reinterpret_cast<R*>(sm + S::o_wb) + 64 * w;
+        R* tbw = reinterpret_cast<R*>(sm + S::o_tb) + 32 * w;
+        R* vbuf = reinterpret_cast<R*>(sm + S::o_vb);
+        float* redf = reinterpret_cast<float*>(sm + S::o_red);          // [2][4 NW] check maxima
+        int* vflag = reinterpret_cast<int*>(redf + 8 * NW);             // [NW] pre-test votes
+        for (int i = t; i < 2 * S::VB; i += BT) vbuf[i] = R(0);
+        if (t < NW) vflag[t] = 0;
+        R kin[CHMAX], vr[6], vc[6], bd[12];
+#pragma unroll
+        for (int cc = 0; cc < CHMAX; ++cc) kin[cc] = (R)kin64[cc];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { vr[i] = (R)vrow[i]; vc[i] = (R)vcol[i]; }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) bd[i] = (R)bdrow[i];
+        const R xqr = (R)xq;
+        const bool rowA = active_u, rowB = active_u && ax < 2;
+        const R sigma = (R)a.sigma, alpha = (R)a.alpha, oma = (R)(1.0 - a.alpha), mu = (R)a.mu, irho = (R)(1.0 / rho_b);
+        const R rhoA = rowA ? (R)rho_b : R(0), rhoB = rowB ? (R)rho_b : R(0);
+        const R loA = !rowA ? R(0) : (ax < 2 ? (R)-kInf : (R)a.fzmin_s), hiA = !rowA ? R(0) : (ax < 2 ? R(0) : (R)a.fzmax_s);
+        const R loB = rowB ? (R)-kInf : R(0), hiB = R(0);
+        const R mucA = (ax < 2) ? mu : R(0);
+        auto At = [&](R wA, R wB) -> R {
+            const R ssum = wA + wB;
+            const R s01 = bperm(ssum, cbase), s23 = bperm(ssum, cbase + 1);
+            return (ax < 2) ? wA - wB : fma(-mu, s01 + s23, wA);
+        };
+        x = (R)x_init;
+        R cpx = (R)(px0 + qv), spxA = R(0), spxB = R(0);             // c = P x + q = cpx - A' spx
+        yA = (rowA && a.warm_y) ? (R)gwy[(size_t)b * m + irowA] : R(0);
+        yB = (rowB && a.warm_y) ? (R)gwy[(size_t)b * m + irowB] : R(0);
+        const R fz0 = bperm(x, cbase + 2);
+        R axA = rowA ? fma(-mucA, fz0, x) : R(0), axB = rowB ? fma(-mu, fz0, -x) : R(0);
+        R zA = rmin(rmax(axA, loA), hiA), zB = rmin(rmax(axB, loB), hiB);
+        const float qnf = (float)wg_max1<NW>(fabs(qv), sm + S::o_red + 24);
+        R wv = fma(sigma, x, At(fma(rhoA, zA, -yA), fma(rhoB, zB, -yB)));
+        __syncthreads();
+        status = 2; iters = a.max_iter;
+        int nchk = 0, ph = 0;
+        bool pending = false, vote_ok = true, done = false;
+        double e_prim_last = kInf * 1.0e10;
+        for (int k = 1; k <= a.max_iter + 1 && !done; ++k) {
+            R* vb = vbuf + (k & 1) * S::VB;
+            const R kw = apply_kinv<R, CHMAX>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, [&] {
+                if (pending) {   // decision of the check made at iteration k - 1 (its maxima were published by this barrier)
+                    const float* buf = redf + ((nchk - 1) & 1) * 4 * NW;
+                    float v0 = buf[0], v1 = buf[1], v2 = buf[2], v3 = buf[3];
+#pragma unroll
+                    for (int q = 1; q < NW; ++q) { v0 = fmaxf(v0, buf[4 * q]); v1 = fmaxf(v1, buf[4 * q + 1]); v2 = fmaxf(v2, buf[4 * q + 2]); v3 = fmaxf(v3, buf[4 * q + 3]); }
+                    const double e_prim = a.eps_abs + a.eps_rel * (double)v1;
+                    const double e_dual = a.eps_abs + a.eps_rel * fmax((double)v3, (double)qnf);
+                    e_prim_last = e_prim;
+                    if (!((double)v0 <= kInf) || !((double)v2 <= kInf)) { status = -1; iters = k - 1; done = true; }
+                    else if ((double)v0 <= e_prim && (double)v2 <= e_dual) { status = 1; iters = k - 1; done = true; }
+                    pending = false;
+                }
+                if (++ph == a.check_every) ph = 0;
+                if (ph == 0) {
+                    int vsum = 0;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) vsum |= vflag[q];
+                    vote_ok = (vsum == 0);
+                }
+            });
+            if (done || k > a.max_iter) break;
+            const bool check = ((ph == 0) && vote_ok) || (k == a.max_iter);
+            const bool pretest = (ph == a.check_every - 1);
+            const R xt = active_u ? xqr + kw : R(0);
+            const R fzt = bperm(xt, cbase + 2);
+            const R ztA = fma(-mucA, fzt, xt), ztB = fma(-mu, fzt, -xt);
+            const R nuA = fma(rhoA, ztA - zA, yA), nuB = fma(rhoB, ztB - zB, yB);
+            const R zhA = fma(alpha, ztA, oma * zA), zhB = fma(alpha, ztB, oma * zB);
+            const R znA = rmin(rmax(fma(yA, irho, zhA), loA), hiA), znB = rmin(rmax(fma(yB, irho, zhB), loB), hiB);
+            yA = fma(rhoA, zhA - znA, yA); yB = fma(rhoB, zhB - znB, yB);
+            zA = znA; zB = znB;
+            axA = fma(alpha, ztA, oma * axA); axB = fma(alpha, ztB, oma * axB);
+            spxA = fma(alpha, nuA, oma * spxA); spxB = fma(alpha, nuB, oma * spxB);
+            const R atw = At(fma(rhoA, zA, -yA), fma(rhoB, zB, -yB));
+            cpx = fma(alpha, sigma * (x - xt), oma * cpx);
+            x = fma(alpha, xt, oma * x);
+            wv = fma(sigma, x, atw);
+            if (pretest) {
+                const bool bad = (rowA && !((double)rabs(axA - zA) <= e_prim_last)) || (rowB && !((double)rabs(axB - zB) <= e_prim_last));
+                const unsigned long long bal = __ballot(bad);
+                if (lane == 0) vflag[w] = (bal != 0ull) ? 1 : 0;
+            }
+            if (check) {
+                const R aty = At(yA, yB), cc = cpx - At(spxA, spxB);      // cc = P x + q
+                R rd = rabs(cc + aty);
+                R rp = rmax(rowA ? rabs(axA - zA) : R(0), rowB ? rabs(axB - zB) : R(0));
+                rd = (rd == rd) ? rd : (R)(kInf * 10.0);
+                rp = (rp == rp) ? rp : (R)(kInf * 10.0);
+                const R nr = rmax(rowA ? rmax(rabs(axA), rabs(zA)) : R(0), rowB ? rmax(rabs(axB), rabs(zB)) : R(0));
+                const float v0 = (float)rp, v1 = (float)nr;
+                const float v2 = active_u ? (float)rd : 0.0f, v3 = active_u ? (float)rmax(rabs(cc - (R)qv), rabs(aty)) : 0.0f;
+                const float m0 = wave_maxf_nonneg(v0), m1 = wave_maxf_nonneg(v1), m2 = wave_maxf_nonneg(v2), m3 = wave_maxf_nonneg(v3);
+                if (lane == 63) {
+                    float* buf = redf + (nchk & 1) * 4 * NW + 4 * w;
+                    buf[0] = m0; buf[1] = m1; buf[2] = m2; buf[3] = m3;
+                }
+                ++nchk; pending = true;
+            }
+        }
+        if (status < 0) { x = R(0); yA = R(0); yB = R(0); }
+    }
+    SRBDQP_STAMP(a, b, 8);
+    __syncthreads();
+    if (stepok) sm[S::o_xs + uvar] = (double)x;
+    if (a.y_out) {
+        TIO* yo = reinterpret_cast<TIO*>(a.y_out) + (size_t)b * m;
+        if (stepok) {
+            const bool on = active_u;
+            yo[irowA] = on ? (TIO)yA : TIO(0);
+            if (ax < 2) yo[irowB] = on ? (TIO)yB : TIO(0);
+        }
+    }
+    if (t == 0) {
+        if (a.status) a.status[b] = status;
+        if (a.iters) a.iters[b] = iters + a.iters_base;
+    }
+    __syncthreads();
+    }   // MODE
+    }   // !degenerate
+    }   // na > 0
+
+    // ================= roll-out (a10) and stores =================
+    {
+        const double* uh = sm + S::o_xs;
+        double* scratch = sm + S::o_scr;
+        TIO* uo = reinterpret_cast<TIO*>(a.u_out) + (size_t)b * n;
+        for (int c = t; c < n; c += BT) uo[c] = (TIO)(a.s * uh[c]);
+        if (a.x_out) {
+            const double* x0 = sm + S::o_x0;
+            double* sj = scratch + 6 * N;
+            for (int idx = t; idx < 6 * N; idx += BT) {
+                const int j = idx / 6, comp = idx % 6;
+                const double* u = uh + 12 * j;
+                double s;
+                if (comp < 3) {
+                    const double* J = sm + S::o_J + j * 36 + comp * 12;
+                    s = 0.0;
+                    for (int c = 0; c < 12; ++c) s += J[c] * u[c];
+                } else {
+                    const int ax2 = comp - 3;
+                    s = (u[ax2] + u[3 + ax2] + u[6 + ax2] + u[9 + ax2]) * a.inv_mass;
+                }
+                sj[idx] = s;
+            }
+            __syncthreads();
+            for (int idx = t; idx < 6 * N; idx += BT) {
+                const int k = idx / 6 + 1, comp = idx % 6;
+                double acc2 = 0.0;
+                for (int j = 0; j < k; ++j) acc2 += sj[6 * j + comp];
+                double v = x0[6 + comp] + a.dt * a.s * acc2;
+                if (comp == 5) v += (double)k * a.dt * x0[12];
+                scratch[idx] = v;
+            }
+            __syncthreads();
+            TIO* xo = reinterpret_cast<TIO*>(a.x_out) + (size_t)b * (N + 1) * 13;
+            for (int idx = t; idx < 13 * (N + 1); idx += BT) {
+                const int k = idx / 13, comp = idx % 13;
+                double v;
+                if (k == 0) v = x0[comp];
+                else if (comp == 12) v = x0[12];
+                else if (comp >= 6) v = scratch[(k - 1) * 6 + comp - 6];
+                else if (comp >= 3) {
+                    double acc2 = x0[6 + comp];
+                    for (int l = 1; l < k; ++l) acc2 += scratch[(l - 1) * 6 + comp];
+                    v = x0[comp] + a.dt * acc2;
+                } else {
+                    double acc2 = 0.0;
+                    for (int l = 0; l < k; ++l) {
+                        const double* Tm = sm + S::o_tm + l * 9 + comp * 3;
+                        const double* wv2 = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
+                        acc2 += Tm[0] * wv2[0] + Tm[1] * wv2[1] + Tm[2] * wv2[2];
+                    }
+                    v = x0[comp] + a.dt * acc2;
+                }
+                xo[idx] = (TIO)v;
+            }
+        }
+    }
+    signal_done(a);
+    SRBDQP_STAMP(a, b, 9);
+}
+
+template <int N, typename R, typename TIO, int MODE, int WPS>
+__global__ __launch_bounds__(WrenchSmem<N>::BT, WPS) void srbdqp_wrench_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x >= a.B) return;
+    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) { signal_done(a); return; }
+    wrench_qp<N, R, TIO, MODE>(a, SRBDQP_QP_INDEX(a), sm);
+}
+
+}  // namespace srbdqp

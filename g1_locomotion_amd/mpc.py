@@ -98,26 +98,31 @@ class BatchMPC:
         self.close()
 
     # -- host-buffer API -------------------------------------------------------------------------------
-    def solve(self, x0, x_ref, foot, contact, pcom=None, warm_u=None, warm_y=None, want_x=True, want_y=False):
-        """Solve B QPs.  Returns dict(u (B,N,12) [N], x (B,N+1,13), y (B,20N), status (B,), iters (B,))."""
+    def solve(self, x0, x_ref, foot, contact, pcom=None, warm_u=None, warm_y=None, want_x=True, want_y=False,
+              dtype=np.float64):
+        """Solve B QPs.  Returns dict(u (B,N,12) [N], x (B,N+1,13), y (B,20N), status (B,), iters (B,)).
+        dtype=np.float32 goes through srbdqp_solve_batch_f32: fp32 buffers and fp32 ADMM iterations (fp64 set-up)."""
         N, n, m = self.N, self.n, self.m
-        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        dt = np.dtype(dtype)
+        if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise TypeError("dtype must be float64 or float32")
+        x0 = np.ascontiguousarray(x0, dtype=dt)
         B = x0.size // NX
-        x0 = _as(x0, np.float64, (B, NX), "x0")
-        x_ref = _as(x_ref, np.float64, (B, N, NX), "x_ref")
-        foot = _as(foot, np.float64, (B, N, NU), "foot")
+        x0 = _as(x0, dt, (B, NX), "x0")
+        x_ref = _as(x_ref, dt, (B, N, NX), "x_ref")
+        foot = _as(foot, dt, (B, N, NU), "foot")
         contact = _as(np.asarray(contact) != 0, np.uint8, (B, N, NC), "contact")
-        pcom = None if pcom is None else _as(pcom, np.float64, (B, N, 3), "pcom")
-        warm_u = None if warm_u is None else _as(warm_u, np.float64, (B, n), "warm_u")
-        warm_y = None if warm_y is None else _as(warm_y, np.float64, (B, m), "warm_y")
-        u = np.empty((B, N, NU))
-        x = np.empty((B, N + 1, NX)) if want_x else None
-        y = np.empty((B, m)) if want_y else None
+        pcom = None if pcom is None else _as(pcom, dt, (B, N, 3), "pcom")
+        warm_u = None if warm_u is None else _as(warm_u, dt, (B, n), "warm_u")
+        warm_y = None if warm_y is None else _as(warm_y, dt, (B, m), "warm_y")
+        u = np.empty((B, N, NU), dt)
+        x = np.empty((B, N + 1, NX), dt) if want_x else None
+        y = np.empty((B, m), dt) if want_y else None
         status = np.empty(B, np.int32)
         iters = np.empty(B, np.int32)
-        rc = self._lib.srbdqp_solve_batch_f64(self._h, B, _ptr(x0), _ptr(x_ref), _ptr(foot), _ptr(contact), _ptr(pcom),
-                                              _ptr(warm_u), _ptr(warm_y), _ptr(u), _ptr(x), _ptr(y), _ptr(status),
-                                              _ptr(iters))
+        fn = self._lib.srbdqp_solve_batch_f64 if dt == np.dtype(np.float64) else self._lib.srbdqp_solve_batch_f32
+        rc = fn(self._h, B, _ptr(x0), _ptr(x_ref), _ptr(foot), _ptr(contact), _ptr(pcom), _ptr(warm_u), _ptr(warm_y),
+                _ptr(u), _ptr(x), _ptr(y), _ptr(status), _ptr(iters))
         _lib.check(rc, self._h)
         return dict(u=u, x=x, y=y, status=status, iters=iters)
 
@@ -137,21 +142,40 @@ class BatchMPC:
         _lib.check(rc, self._h)
         return dict(P=P, q=q, l=lo, u=hi)
 
+    def assemble_wrench(self, x0, x_ref, foot, contact, pcom=None):
+        """What the general kernel builds before its factorisation (srbdqp_assemble_wrench_f64): dict(T (B,6N,6N), q (B,12N),
+        Bd (B,12N,12), Vcol (B,12N,6), Vrow (B,12N,6), goff (B,N+1) int)."""
+        N, n = self.N, self.n
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B = x0.size // NX
+        x0 = _as(x0, np.float64, (B, NX), "x0")
+        x_ref = _as(x_ref, np.float64, (B, N, NX), "x_ref")
+        foot = _as(foot, np.float64, (B, N, NU), "foot")
+        contact = _as(np.asarray(contact) != 0, np.uint8, (B, N, NC), "contact")
+        pcom = None if pcom is None else _as(pcom, np.float64, (B, N, 3), "pcom")
+        T = np.empty((B, 6 * N, 6 * N)); q = np.empty((B, n)); bl = np.empty((B, n, 24)); go = np.empty((B, N + 1))
+        rc = self._lib.srbdqp_assemble_wrench_f64(self._h, B, _ptr(x0), _ptr(x_ref), _ptr(foot), _ptr(contact), _ptr(pcom),
+                                                  _ptr(T), _ptr(q), _ptr(bl), _ptr(go))
+        _lib.check(rc, self._h)
+        return dict(T=T, q=q, Bd=bl[:, :, 0:12].copy(), Vcol=bl[:, :, 12:18].copy(), Vrow=bl[:, :, 18:24].copy(), goff=go.astype(int))
+
     # -- device-buffer API -----------------------------------------------------------------------------
     def solve_device(self, B, x0, x_ref, foot, contact, u_out, x_out=0, y_out=0, status=0, iters=0, pcom=0,
-                     warm_u=0, warm_y=0, stream=0):
+                     warm_u=0, warm_y=0, stream=0, f32=False):
         """Enqueue a solve on HBM-resident buffers.  Every argument is a raw device address (int), e.g.
         ``tensor.data_ptr()``; 0 = absent.  ``stream`` is a hipStream_t address (0 = the handle's own stream).
-        Does not synchronise."""
+        f32=True: the buffers hold float32 (srbdqp_solve_batch_device_f32).  Does not synchronise."""
         v = lambda p: C.c_void_p(int(p)) if p else None
-        rc = self._lib.srbdqp_solve_batch_device_f64(self._h, int(B), v(x0), v(x_ref), v(foot), v(contact), v(pcom),
-                                                     v(warm_u), v(warm_y), v(u_out), v(x_out), v(y_out), v(status),
-                                                     v(iters), v(stream))
+        fn = self._lib.srbdqp_solve_batch_device_f32 if f32 else self._lib.srbdqp_solve_batch_device_f64
+        rc = fn(self._h, int(B), v(x0), v(x_ref), v(foot), v(contact), v(pcom), v(warm_u), v(warm_y), v(u_out), v(x_out),
+                v(y_out), v(status), v(iters), v(stream))
         _lib.check(rc, self._h)
 
-    def set_schedule_hint(self, iters_prev_ptr=0):
-        """Device address of the previous step's iters[] (or 0): longest-first dispatch for the next device solves."""
-        _lib.check(self._lib.srbdqp_set_schedule_hint(self._h, C.c_void_p(int(iters_prev_ptr)) if iters_prev_ptr else None), self._h)
+    def set_schedule_hint(self, iters_prev_ptr=0, length=0):
+        """Device address and length of the previous step's iters[] (or 0): longest-first dispatch for the next device
+        solves of at most `length` QPs."""
+        _lib.check(self._lib.srbdqp_set_schedule_hint(self._h, C.c_void_p(int(iters_prev_ptr)) if iters_prev_ptr else None,
+                                                      int(length) if iters_prev_ptr else 0), self._h)
 
     # -- low-latency staged API (small batches; the single-robot control loop) --------------------------
     def stage(self):

@@ -31,7 +31,7 @@ extern "C" {
 #define SRBDQP_NU 12
 #define SRBDQP_NC 4
 #define SRBDQP_ROWS_PER_STEP 20   /* 4 contacts x (4 friction-pyramid rows + 1 normal-force row) */
-#define SRBDQP_MAX_HORIZON 20     /* fp64 instantiations: N in {4, 8, 10}; {12, 16, 20} with <= 2 stance contacts per step */
+#define SRBDQP_MAX_HORIZON 24     /* instantiations: N in {4, 8, 10, 12, 16, 20, 24} */
 
 /* return codes */
 #define SRBDQP_OK 0
@@ -61,6 +61,10 @@ extern "C" {
                                      HBM (<= 64 presolved variables, otherwise falls back to COMPACT); kept for A/B */
 #define SRBDQP_KERNEL_WAVE 5      /* the whole solve on one wave per QP, K tiles register-resident, no barrier, no hand-over;
                                      AUTO picks it for batches >= 512 of the instantiations with <= 64 presolved variables */
+#define SRBDQP_KERNEL_WRENCH 6    /* the general kernel: any contact pattern at every horizon (4 ... 24), wrench-space presolve
+                                     (a step with >= 3 stance contacts contributes 6 coordinates instead of 3 per contact),
+                                     fp64 or fp32 iterations; AUTO picks it for > 2 stance contacts per step at N > 10, for
+                                     N = 24 and for every _f32 call */
 
 /* Everything `MPC.__init__(dt)` / `MPC.init_matrices()` hold (run_simulation.py:169-170).  Values the
  * reference keeps inside the absent module are this build's documented choices. */
@@ -133,6 +137,23 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B,
                                   double* u_out, double* x_out, double* y_out,
                                   int32_t* status, int32_t* iters, void* stream);
 
+/* The same two calls with fp32 buffers (BASELINE.json configs[2]: "Batch=65536, N=20, 4-contact double-support, fp32").
+ * Every array above becomes float; contact stays uint8.  The set-up (closed-form assembly, Cholesky factor, inverse) is
+ * computed in fp64 on chip; the ADMM iterations run in fp32 on the general kernel (SRBDQP_KERNEL_WRENCH), whatever
+ * srbdqp_config.kernel says.  Tolerances reachable in fp32: see DESIGN.md section 3. */
+int srbdqp_solve_batch_f32(srbdqp_handle* h, int32_t B,
+                           const float* x0, const float* x_ref, const float* foot,
+                           const uint8_t* contact, const float* pcom,
+                           const float* warm_u, const float* warm_y,
+                           float* u_out, float* x_out, float* y_out,
+                           int32_t* status, int32_t* iters);
+int srbdqp_solve_batch_device_f32(srbdqp_handle* h, int32_t B,
+                                  const float* x0, const float* x_ref, const float* foot,
+                                  const uint8_t* contact, const float* pcom,
+                                  const float* warm_u, const float* warm_y,
+                                  float* u_out, float* x_out, float* y_out,
+                                  int32_t* status, int32_t* iters, void* stream);
+
 /* ~ the QP-assembly half of MPC.update (what init_matrices() allocates: H, g, cone rows).  HOST
  * buffers, for parity tests of linearise/condense/H/g/bounds.  Scaled variables u_hat.
  *   P_out [B][12N][12N]   Hessian H = Bs' Q Bs + R s^2        q_out [B][12N]   gradient
@@ -143,13 +164,28 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B,
                         const uint8_t* contact, const double* pcom,
                         double* P_out, double* q_out, double* l_out, double* ub_out);
 
-/* Longest-first scheduling hint for the DEVICE-buffer API: `device_iters_prev` = the iters[] array (device memory,
- * length >= B) of the previous control step of the same batch, or NULL to switch the hint off.  Subsequent device
+/* The same for the general kernel (SRBDQP_KERNEL_WRENCH), whose presolve never forms H: what it does build, dumped by the
+ * shipped kernel itself right before its factorisation.  With g_j = the coordinates of step j (6 wrench coordinates when
+ * the step has >= 3 stance contacts, its 3c force variables otherwise), n_g = sum_j g_j <= 6N:
+ *   T_out      [B][6N][6N]   T = S + E^-1 (symmetric, leading n_g x n_g block, rest 0); K^-1 = Bd + V' T^-1 V
+ *   q_out      [B][12N]      gradient in the scaled force variables (0 for swing contacts)
+ *   blocks_out [B][12N][24]  per force variable u (index 12 k + 3 i + a): row u of Bd within its step (12), column u of
+ *                            V (6), and -- as lane (row r = (u % 12) / 2, half h = u % 2) of the step -- V[r][6h .. 6h+5] (6)
+ *   goff_out   [B][N+1]      offset of step j's coordinates in T (as doubles); goff[N] = n_g
+ * HOST buffers; parity tests of rows a5-a8 on the kernel that ships (tests/test_gpu_wrench.py). */
+int srbdqp_assemble_wrench_f64(srbdqp_handle* h, int32_t B,
+                               const double* x0, const double* x_ref, const double* foot,
+                               const uint8_t* contact, const double* pcom,
+                               double* T_out, double* q_out, double* blocks_out, double* goff_out);
+
+/* Longest-first scheduling hint for the DEVICE-buffer API only (the host-buffer and the staged calls ignore it):
+ * `device_iters_prev` = the iters[] array (device memory, `length` entries) of the previous control step of the same
+ * batch, or NULL to switch the hint off.  A solve of more than `length` QPs is dispatched in natural order.  Subsequent device
  * solves first build a dispatch order from it (one tiny kernel on the same stream) so that QPs that needed many ADMM
  * iterations last step start first and the straggler tail overlaps the bulk of the launch.  In a receding-horizon
  * loop consecutive steps of a robot are strongly correlated; a wrong hint costs nothing but the reordering.  The
  * pointer is read at every solve; results, status[] and iters[] stay in the caller's QP order. */
-int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev);
+int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev, int32_t length);
 
 /* Low-latency path for small batches (the single-robot control loop, B = 1): the library owns pinned, GPU-mapped host
  * staging arrays; the caller fills the inputs in place, calls srbdqp_solve_staged_f64 (one kernel launch that reads and

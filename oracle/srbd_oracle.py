@@ -250,6 +250,101 @@ def closed_form_hessian_gradient(p: SrbdParams, x0, x_ref, foot_hor, contact_hor
     return P, q, vi
 
 
+def wrench_reduce(p: SrbdParams, x_ref, foot_hor, contact_hor, pcom_hor=None, rho=None):
+    """The presolve of the general (any contact pattern) HIP kernel, restated in NumPy for the tests: the reduced-KKT
+    matrix K = P + sigma I + A' rho A of the stance-contact QP, inverted through the rank structure of the SRBD.
+
+    A step's 3c stance-force variables act on the body only through the 6-vector wrench g = W u, W = [J_e ...; I I ...]
+    (angular acceleration I_w^-1 sum r x f, total force).  So the condensed Hessian is P = Om' S_w Om + R s^2 I with
+    Om = blockdiag(W_j) and the 6N x 6N wrench-space matrix S_w(j, m) = s^2 blockdiag(M(j, m), diag(d(j, m)))
+    (closed_form_hessian_gradient()'s tables), and A'A is diagonal per contact (diag(2, 2, 4 mu^2 + 1)), hence
+    K = D + Y' S Y with D diagonal.  Per step the kernel keeps g_j = 6 wrench coordinates if the step has >= 3 stance
+    contacts (Y_j = W_j) and the 3c force variables themselves otherwise (Y_j = I), and applies
+        K^-1 = Bd + V' T^-1 V,   T = S + E^-1,  E = Y D^-1 Y' (block diagonal),  V = E^-1 Y D^-1,
+        Bd = D^-1 - D^-1 Y' V   (block diagonal; zero on the identity steps)
+    (Woodbury twice).  Only T (n_g x n_g, n_g <= 6N) is factored: double support at N = 20 is a 120 x 120 problem
+    instead of 240 x 240.  Returns dict(T, V, Bd, D, gsz, goff, n_g, vi, contacts)."""
+    x_ref = np.asarray(x_ref, dtype=np.float64)
+    N = x_ref.shape[0]
+    foot_hor = np.asarray(foot_hor, dtype=np.float64).reshape(N, NC, 3)
+    contact_hor = np.asarray(contact_hor).reshape(N, NC) != 0
+    pcom = x_ref[:, 3:6] if pcom_hor is None else np.asarray(pcom_hor, dtype=np.float64).reshape(N, 3)
+    rho = p.rho if rho is None else float(rho)
+    dt, s, inv_m = p.dt, p.force_scale, 1.0 / p.mass
+    w = np.asarray(p.q_diag, dtype=np.float64)
+    W_th, W_p, W_om, W_v = np.diag(w[0:3]), w[3:6], np.diag(w[6:9]), w[9:12]
+    Tm = [rot_z(float(x_ref[k, 2])).T for k in range(N)]
+    C = np.cumsum(np.array(Tm), axis=0)
+    Ib_inv = np.diag(1.0 / np.asarray(p.inertia, dtype=np.float64))
+    T1 = [sum((C[i] - C[m] for i in range(m, N)), np.zeros((3, 3))) for m in range(N)]
+    T2 = [sum(((C[i] - C[m]).T @ W_th @ (C[i] - C[m]) for i in range(m, N)), np.zeros((3, 3))) for m in range(N)]
+
+    def S_w(j, m):   # 6 x 6 wrench-space block, j <= m
+        M = dt ** 4 * (T2[m] + (C[m] - C[j]).T @ W_th @ T1[m]) + (N - m) * dt ** 2 * W_om
+        sp = sum((i - j) * (i - m) for i in range(m, N))
+        out = np.zeros((6, 6))
+        out[0:3, 0:3] = M
+        out[3:6, 3:6] = np.diag(W_p * dt ** 4 * inv_m ** 2 * sp + W_v * dt ** 2 * inv_m ** 2 * (N - m))
+        return s * s * out
+
+    contacts = [(k, i) for k in range(N) for i in range(NC) if contact_hor[k, i]]
+    nu_ = 3 * len(contacts)
+    vi = np.array([NU * k + 3 * i + a for k, i in contacts for a in range(3)], dtype=int)
+    dxy = p.r_diag * s * s + p.sigma + 2.0 * rho
+    dz = p.r_diag * s * s + p.sigma + (4.0 * p.mu ** 2 + 1.0) * rho
+    D = np.tile(np.array([dxy, dxy, dz]), len(contacts))
+    Wj, uoff, csz = [], [], []
+    off = 0
+    for k in range(N):
+        cs = [i for i in range(NC) if contact_hor[k, i]]
+        Rz = Tm[k].T
+        blk = np.zeros((6, 3 * len(cs)))
+        for q, i in enumerate(cs):
+            blk[0:3, 3 * q:3 * q + 3] = Rz @ Ib_inv @ Rz.T @ skew(foot_hor[k, i] - pcom[k])
+            blk[3:6, 3 * q:3 * q + 3] = np.eye(3)
+        Wj.append(blk); uoff.append(off); csz.append(len(cs))
+        off += 3 * len(cs)
+    gsz = np.array([6 if c >= 3 else 3 * c for c in csz], dtype=int)
+    goff = np.concatenate([[0], np.cumsum(gsz)]).astype(int)
+    n_g = int(goff[-1])
+    Z = [np.eye(6) if csz[k] >= 3 else Wj[k] for k in range(N)]           # wrench coordinates -> g coordinates
+    Y = [Wj[k] if csz[k] >= 3 else np.eye(3 * csz[k]) for k in range(N)]   # force variables -> g coordinates
+    S = np.zeros((n_g, n_g))
+    for j in range(N):
+        for m in range(j, N):
+            if gsz[j] == 0 or gsz[m] == 0:
+                continue
+            blk = Z[j].T @ S_w(j, m) @ Z[m]
+            S[goff[j]:goff[j + 1], goff[m]:goff[m + 1]] = blk
+            if m > j:
+                S[goff[m]:goff[m + 1], goff[j]:goff[j + 1]] = blk.T
+    S = 0.5 * (S + S.T)
+    T = S.copy()
+    V = np.zeros((n_g, nu_))
+    Bd = np.zeros((nu_, nu_))
+    for k in range(N):
+        if gsz[k] == 0:
+            continue
+        us = slice(uoff[k], uoff[k] + 3 * csz[k]); gs = slice(goff[k], goff[k + 1])
+        Dk = D[us]
+        E = (Y[k] / Dk) @ Y[k].T
+        Einv = np.linalg.inv(E)
+        Einv = 0.5 * (Einv + Einv.T)
+        T[gs, gs] += Einv
+        V[gs, us] = Einv @ (Y[k] / Dk)
+        Bd[us, us] = np.diag(1.0 / Dk) - (Y[k] / Dk).T @ V[gs, us]
+    return dict(T=T, V=V, Bd=Bd, D=D, S=S, gsz=gsz, goff=goff, n_g=n_g, vi=vi, contacts=contacts, csz=np.array(csz))
+
+
+def wrench_kinv_op(wr):
+    """x~ = K^-1 rhs as the general kernel applies it: Bd rhs + V' (T^-1 (V rhs)), T^-1 explicit (W'W of its Cholesky factor)."""
+    Lc = np.linalg.cholesky(wr["T"])
+    Linv = _tri_inv(Lc)
+    Tinv = Linv.T @ Linv
+    V, Bd = wr["V"], wr["Bd"]
+    return lambda rhs: Bd @ rhs + V.T @ (Tinv @ (V @ rhs))
+
+
 def rho_vector(p: SrbdParams, l, u):
     """Per-row ADMM penalty: rho for inequalities, rho*rho_eq_scale for equalities (OSQP's rule)."""
     rho = np.full(l.shape, p.rho)
@@ -260,11 +355,13 @@ def rho_vector(p: SrbdParams, l, u):
 # --------------------------------------------------------------------------------------
 # a9: ADMM (OSQP Algorithm 1, reduced-KKT form)
 # --------------------------------------------------------------------------------------
-def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.float64, trace=None, info=None):
+def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.float64, trace=None, info=None, kinv_op=None):
     """The algorithm the HIP kernel runs, in the same order of operations.
 
     K = P + sigma I + A' diag(rho) A is factored once (Cholesky); every iteration applies the
     inverse.  P x is tracked by recursion (no matvec with P inside the loop).
+    kinv_op: optional callable applying K^-1 (the general kernel's wrench-space form, wrench_kinv_op()); default = the
+    explicit dense inverse.
     Returns (x, z, y, iters, status).
     """
     P = P.astype(dtype); q = q.astype(dtype); A = A.astype(dtype)
@@ -272,10 +369,12 @@ def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.
     n, m = P.shape[0], A.shape[0]
     rho = rho_vector(p, l, u).astype(dtype)
     sigma, alpha = dtype(p.sigma), dtype(p.alpha)
-    K = P + sigma * np.eye(n, dtype=dtype) + (A.T * rho) @ A
-    Lc = np.linalg.cholesky(K.astype(np.float64)).astype(dtype) if dtype == np.float64 else _chol(K)
-    Linv = _tri_inv(Lc)
-    Kinv = (Linv.T @ Linv).astype(dtype)
+    if kinv_op is None:
+        K = P + sigma * np.eye(n, dtype=dtype) + (A.T * rho) @ A
+        Lc = np.linalg.cholesky(K.astype(np.float64)).astype(dtype) if dtype == np.float64 else _chol(K)
+        Linv = _tri_inv(Lc)
+        Kinv = (Linv.T @ Linv).astype(dtype)
+        kinv_op = lambda r: Kinv @ r
     x = np.zeros(n, dtype) if x_init is None else np.asarray(x_init, dtype).copy()
     y = np.zeros(m, dtype) if y_init is None else np.asarray(y_init, dtype).copy()
     z = np.clip(A @ x, l, u)
@@ -285,7 +384,7 @@ def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.
     e_prim_last, vote_ok = np.inf, True
     for k in range(1, p.max_iter + 1):
         rhs = sigma * x - q + A.T @ (rho * z - y)
-        xt = Kinv @ rhs
+        xt = kinv_op(rhs)
         zt = A @ xt
         # P xt from the KKT identity: (P + sigma I) xt + A'(rho (zt - z) + y) = sigma x - q
         Pxt = sigma * (x - xt) - q - A.T @ (rho * (zt - z) + y)
@@ -324,6 +423,95 @@ def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.
                 status, iters = STATUS_SOLVED, k
                 break
     return x, z, y, iters, status
+
+
+def admm_solve_split(p: SrbdParams, P, q, A, l, u, wr, x_init=None, y_init=None, dtype=np.float32, info=None):
+    """The recursions of the general HIP kernel (srbdqp_wrench.hpp), in `dtype` (float32 = its fp32 instantiation).
+
+    Same algorithm as admm_solve(), rearranged so that the large gradient q never enters the iteration:
+      x~ = x_q + K^-1 (sigma x + A'(rho z - y)),  x_q = -K^-1 q computed ONCE in float64  (K^-1 = Bd + V' T^-1 V, `wr`
+      from wrench_reduce(); T^-1, V, Bd are rounded to `dtype` for the loop), and the dual residual is carried as
+      c = P x + q with c~ = sigma (x - x~) - A' nu.  In exact arithmetic the iterates equal admm_solve()'s.
+    The four maxima of a check are float32 in the kernels whatever `dtype` is.  Returns (x, z, y, iters, status)."""
+    n, m = P.shape[0], A.shape[0]
+    rho64 = rho_vector(p, l, u)
+    T = wr["T"]
+    Lc = np.linalg.cholesky(T)
+    Linv = _tri_inv(Lc)
+    Tinv64 = Linv.T @ Linv
+    V64, Bd64 = wr["V"], wr["Bd"]
+    xq = (-(Bd64 @ q + V64.T @ (Tinv64 @ (V64 @ q)))).astype(dtype)
+    Tinv, V, Bd = Tinv64.astype(dtype), V64.astype(dtype), Bd64.astype(dtype)
+    A = A.astype(dtype); rho = rho64.astype(dtype)
+    lo = np.maximum(l, -INF).astype(dtype); hi = np.minimum(u, INF).astype(dtype)
+    sigma, alpha = dtype(p.sigma), dtype(p.alpha)
+    oma = dtype(1.0 - p.alpha)
+    x = np.zeros(n, dtype) if x_init is None else np.asarray(x_init, dtype).copy()
+    y = np.zeros(m, dtype) if y_init is None else np.asarray(y_init, dtype).copy()
+    z = np.clip(A @ x, lo, hi)
+    c = (P @ x.astype(np.float64) + q).astype(dtype)
+    qd = q.astype(dtype)
+    f32 = lambda v: float(np.float32(v))
+    qn = f32(np.max(np.abs(q)))
+    status, iters = STATUS_MAX_ITER, p.max_iter
+    e_prim_last, vote_ok = np.inf, True
+    for k in range(1, p.max_iter + 1):
+        w = sigma * x + A.T @ (rho * z - y)
+        xt = xq + (Bd @ w + V.T @ (Tinv @ (V @ w)))
+        zt = A @ xt
+        ct = sigma * (x - xt) - A.T @ (rho * (zt - z) + y)
+        x = alpha * xt + oma * x
+        c = alpha * ct + oma * c
+        zh = alpha * zt + oma * z
+        zn = np.clip(zh + y / rho, lo, hi)
+        y = y + rho * (zh - zn)
+        z = zn
+        if (k + 1) % p.check_every == 0:
+            vote_ok = bool(np.max(np.abs(A @ x - z)) <= e_prim_last)
+        if k % p.check_every == 0 or k == p.max_iter:
+            if not (vote_ok or k == p.max_iter):
+                continue
+            Ax = A @ x
+            Aty = A.T @ y
+            r_prim = f32(np.max(np.abs(Ax - z)))
+            r_dual = f32(np.max(np.abs(c + Aty)))
+            n_prim = f32(max(np.max(np.abs(Ax)), np.max(np.abs(z))))
+            n_dual = max(f32(max(np.max(np.abs(c - qd)), np.max(np.abs(Aty)))), qn)
+            e_prim = p.eps_abs + p.eps_rel * n_prim
+            e_dual = p.eps_abs + p.eps_rel * n_dual
+            e_prim_last = e_prim
+            if info is not None:
+                info.update(r_prim=r_prim, n_prim=n_prim, r_dual=r_dual, n_dual=n_dual)
+            if not np.isfinite(r_prim + r_dual):
+                status, iters = STATUS_NUMERICAL, k
+                break
+            if r_prim <= e_prim and r_dual <= e_dual:
+                status, iters = STATUS_SOLVED, k
+                break
+    return x.astype(np.float64), z.astype(np.float64), y.astype(np.float64), iters, status
+
+
+def update_split(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None, warm=None, dtype=np.float32):
+    """Oracle twin of the general kernel's fp32 (or fp64) path: like update(), through wrench_reduce() +
+    admm_solve_split().  With dtype=float32 the inputs are first rounded to float32, as the _f32 entry points see them."""
+    if dtype == np.float32:
+        x0, x_ref, foot_hor = (np.asarray(v, np.float32).astype(np.float64) for v in (x0, x_ref, foot_hor))
+        pcom_hor = None if pcom_hor is None else np.asarray(pcom_hor, np.float32).astype(np.float64)
+    qp = build_qp(p, x0, x_ref, foot_hor, contact_hor, pcom_hor)
+    n, m = qp["P"].shape[0], qp["A"].shape[0]
+    red, vi, ri = presolve(qp, contact_hor)
+    uh = np.zeros(n); y = np.zeros(m)
+    if len(vi) == 0:
+        iters, status = 0, STATUS_SOLVED
+    else:
+        wr = wrench_reduce(p, x_ref, foot_hor, contact_hor, pcom_hor)
+        xi, yi = (None, None) if warm is None else (np.asarray(warm[0])[vi], np.asarray(warm[1])[ri])
+        xr_, _, yr_, iters, status = admm_solve_split(p, red["P"], red["q"], red["A"], red["l"], red["u"], wr, xi, yi, dtype=dtype)
+        uh[vi] = xr_
+        y[ri] = yr_
+    N = np.asarray(x_ref).shape[0]
+    return dict(u=(uh * p.force_scale).reshape(N, NU), x=rollout(qp, x0, uh, p.force_scale), iters=iters, status=status,
+                u_hat=uh, y=y, qp=qp)
 
 
 def _chol(K):

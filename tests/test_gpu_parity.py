@@ -186,7 +186,7 @@ def test_schedule_hint_only_reorders_work(torch_first, built_lib):
             u = torch.zeros((B, N, 12), dtype=torch.float64, device=dev)
             it = torch.zeros(B, dtype=torch.int32, device=dev)
             st = torch.zeros(B, dtype=torch.int32, device=dev)
-            eng.set_schedule_hint(it_prev.data_ptr() if it_prev is not None else 0)
+            eng.set_schedule_hint(it_prev.data_ptr() if it_prev is not None else 0, B)
             eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(),
                              status=st.data_ptr(), iters=it.data_ptr())
             eng.synchronize()
@@ -277,7 +277,7 @@ def test_two_streams_pipeline_distinct_batches_through_one_handle(torch_first, b
             u = torch.zeros((B, N, 12), dtype=torch.float64, device=dev)
             it = torch.zeros(B, dtype=torch.int32, device=dev)
             st = torch.zeros(B, dtype=torch.int32, device=dev)
-            eng.set_schedule_hint(hint.data_ptr() if hint is not None else 0)
+            eng.set_schedule_hint(hint.data_ptr() if hint is not None else 0, B)
             eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(),
                              status=st.data_ptr(), iters=it.data_ptr(), stream=stream)
             return u, it, st

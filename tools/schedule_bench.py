@@ -20,7 +20,7 @@ u = [torch.empty((B, N, 12), dtype=torch.float64, device=dev) for _ in range(S)]
 it = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(S)]
 st = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(S)]
 def step(i):
-    eng.set_schedule_hint(it[i % S].data_ptr() if i >= S else 0)
+    eng.set_schedule_hint(it[i % S].data_ptr() if i >= S else 0, B)
     eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u[i % S].data_ptr(), status=st[i % S].data_ptr(), iters=it[i % S].data_ptr(), stream=streams[i % S].cuda_stream)
 for i in range(4): step(i)
 torch.cuda.synchronize()
