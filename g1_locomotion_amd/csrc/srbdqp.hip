@@ -354,28 +354,42 @@ struct Carver {
 // last check (OSQP's rule, oracle restart_rho()).  One workgroup; the order of the list is arbitrary, every QP's
 // result is independent of it.
 __global__ __launch_bounds__(1024) void srbdqp_restart_select_kernel(const int32_t* status, const float* resid, int B, double rho0,
-                                                                     int32_t* list, int32_t* count, double* rho_qp, int cap) {
+                                                                     int32_t* list, int32_t* count, double* rho_qp) {
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += 1024) {
         if (status[i] != SRBDQP_MAX_ITER) continue;
         const int pos = atomicAdd(&cnt, 1);
-        if (pos >= cap) continue;
         list[pos] = i;
         const float* r = resid + (size_t)i * 4;
         const double num = (double)r[0] / fmax((double)r[1], 1e-30), den = (double)r[2] / fmax((double)r[3], 1e-30);
         double r1 = rho0;
-        if (num > 0.0 && den > 0.0 && num <= 1.0e30 && den <= 1.0e30) r1 = fmin(fmax(rho0 * sqrt(num / den), rho0 * 0.1), rho0 * 10.0);
+        if (num > 0.0 && den > 0.0 && num <= 1.0e30 && den <= 1.0e30) r1 = fmin(fmax(rho0 * sqrt(num / den), rho0 * 0.1), rho0 * 5.0);
         rho_qp[i] = r1;
     }
     __syncthreads();
-    if (threadIdx.x == 0) *count = cnt < cap ? cnt : cap;
+    if (threadIdx.x == 0) *count = cnt;
 }
 
-inline int restart_iter_of(const srbdqp_config& c) {
-    const bool family = resolve_kernel(c) == SRBDQP_KERNEL_COMPACT;   // AUTO, COMPACT and SPLIT
-    return (family && c.rho_restart_iter > 0 && c.rho_restart_iter < c.max_iter) ? c.rho_restart_iter : 0;
+// does a solve of this handle go to the general kernel (srbdqp_wrench.hpp)?  Mirrors launch() / launch_long().
+inline bool uses_wrench(const srbdqp_handle* h, int maxs) {
+    const int N = h->cfg.horizon;
+    if (h->cfg.kernel == SRBDQP_KERNEL_WRENCH || h->io_f32 || N == 24) return true;
+    return N > 10 && maxs > 2 && h->cfg.kernel != SRBDQP_KERNEL_GJ && h->cfg.kernel != SRBDQP_KERNEL_MFMA;
+}
+
+// Iteration at which a solve of this handle re-balances rho (0 = never).  srbdqp_config.rho_restart_iter: > 0 that
+// iteration, < 0 off, 0 = automatic: 100 (125 above N = 16) on the general kernel (its long horizons have a 1 - 10 % tail
+// of slow QPs, and at its batch sizes the second launch costs 3 - 5 %), off elsewhere (the N = 10 batch kernels run
+// 0.2 ms steps, where a second launch costs a quarter of the throughput: DESIGN.md).
+inline int restart_iter_of(const srbdqp_handle* h, int maxs) {
+    const srbdqp_config& c = h->cfg;
+    const int rk = resolve_kernel(c);
+    if (rk != SRBDQP_KERNEL_COMPACT && rk != SRBDQP_KERNEL_WRENCH) return 0;   // v0 / v1 have no restart
+    int r = c.rho_restart_iter;
+    if (r == 0) r = uses_wrench(h, maxs) ? (c.horizon <= 16 ? 100 : 125) : 0;
+    return (r > 0 && r < c.max_iter) ? r : 0;
 }
 
 // per-stream restart buffers for batches of up to B QPs with m rows
@@ -403,9 +417,11 @@ int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int m
     auto* slot = stream_slot(h, st);
     if (!slot) return SRBDQP_E_INVALID;
     const int B = a1.B;
-    const int grid2 = (B <= 64) ? B : ((B / 4 > 64) ? B / 4 : 64);
+    // every capped QP is listed and re-run, one per workgroup; the grid covers the worst case (all of them) and the
+    // workgroups beyond the count exit at once (an empty workgroup costs a few ns of dispatch)
+    const int grid2 = B;
     hipLaunchKernelGGL(srbdqp_restart_select_kernel, dim3(1), dim3(1024), 0, st, a1.status, slot->resid, B, h->cfg.rho,
-                       slot->list, slot->count, slot->rho, grid2);
+                       slot->list, slot->count, slot->rho);
     HIP_TRY(h, hipGetLastError());
     KArgs a2 = a1;
     a2.perm = slot->list;
@@ -448,7 +464,7 @@ int srbdqp_default_config(srbdqp_config* c) {
     for (int i = 0; i < 13; ++i) c->q_diag[i] = q[i];
     c->r_diag = 1.0e-4;
     c->force_scale = 100.0;
-    c->rho = 1.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
+    c->rho = 0.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
     c->eps_abs = 1.0e-6; c->eps_rel = 1.0e-6;
     c->rho_restart_iter = 0; c->reserved0 = 0;
     return SRBDQP_OK;
@@ -460,9 +476,14 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     if (cfg->struct_size != (int32_t)sizeof(srbdqp_config)) { g_create_err = "srbdqp_config.struct_size mismatch"; return SRBDQP_E_INVALID; }
     if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (N in {4, 8, 10, 12, 16, 20, 24})"; return SRBDQP_E_INVALID; }
     if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons above 10 exist only for the compact and the general kernel"; return SRBDQP_E_INVALID; }
-    if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) ||
-        cfg->max_iter < 1 || cfg->check_every < 1 || cfg->rho_restart_iter < 0 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
+    if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho >= 0) || !(cfg->sigma > 0) ||
+        cfg->max_iter < 1 || cfg->check_every < 1 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }
+    for (int i = 0; i < 3; ++i) if (!(cfg->inertia[i] > 0)) { g_create_err = "inertia must be positive"; return SRBDQP_E_INVALID; }
+    if (!(cfg->alpha > 0 && cfg->alpha < 2) || !(cfg->eps_abs >= 0) || !(cfg->eps_rel >= 0) || !(cfg->eps_abs + cfg->eps_rel > 0) ||
+        !(cfg->fz_min >= 0) || !(cfg->fz_min <= cfg->fz_max) || !(cfg->r_diag >= 0) || !(cfg->rho_eq_scale > 0)) {
+        g_create_err = "invalid constants (alpha in (0, 2), eps >= 0, 0 <= fz_min <= fz_max, r_diag >= 0)"; return SRBDQP_E_INVALID;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
@@ -472,6 +493,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     srbdqp_handle* h = new (std::nothrow) srbdqp_handle();
     if (!h) { g_create_err = "out of host memory"; return SRBDQP_E_NOMEM; }
     h->cfg = *cfg;
+    if (h->cfg.rho == 0.0) h->cfg.rho = (cfg->horizon <= 10) ? 1.0 : (cfg->horizon <= 16 ? 1.5 : 2.0);   // auto (oracle auto_rho())
     auto fail = [&](const char* what, hipError_t er) {
         g_create_err = std::string(what) + ": " + hipGetErrorString(er);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -593,7 +615,7 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     if (rc != SRBDQP_OK) return rc;
     rc = wait_done();
     if (rc != SRBDQP_OK) return rc;
-    if (restart_iter_of(h->cfg) && !h->stamps) {
+    if (restart_iter_of(h, maxs) && !h->stamps) {
         bool capped = false;
         for (int32_t q = 0; q < B; ++q) capped |= (h->stage_h.status[q] == SRBDQP_MAX_ITER);
         if (capped) {
@@ -680,7 +702,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
         a.perm = slot->perm;
     }
     int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
-    const int restart = (h->stamps || B < 1 || h->io_f32) ? 0 : restart_iter_of(h->cfg);
+    const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h, maxs);
     if (!restart) return launch(h, a, lst, maxs);
 
     // ---- two passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those

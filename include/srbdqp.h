@@ -81,9 +81,11 @@ typedef struct srbdqp_config {
                                     * <= 2 selects the smaller, higher-occupancy kernel instantiation. */
     int32_t rho_restart_iter;     /* one OSQP-style re-balancing of rho: a QP that has not converged after this many
                                    * iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual))
-                                   * (clipped to [rho/10, 10 rho]) and continues from its own (x, y) until max_iter
-                                   * iterations in total; iters[] counts both passes.  0 (default) or >= max_iter = off.  Compact and
-                                   * split kernels only.  Per device-API launch at most max(64, B/4) QPs are restarted. */
+                                   * (clipped to [rho/10, 5 rho]) and continues from its own (x, y) until max_iter
+                                   * iterations in total; iters[] counts both passes.  < 0 or >= max_iter = off; 0 (default) =
+                                   * automatic: 100 (125 above N = 16) on the general kernel, off on the others.  Runs as
+                                   * a second launch over the QPs the first pass left at its cap (device-side selection,
+                                   * every one of them is continued). */
     int32_t reserved0;
     double dt;                    /* run_simulation.py:169 */
     double mass;                  /* wbid.py:291 model.getMass() */
@@ -93,7 +95,9 @@ typedef struct srbdqp_config {
     double q_diag[SRBDQP_NX];     /* state tracking weights */
     double r_diag;                /* force regularisation */
     double force_scale;           /* u = force_scale * u_hat */
-    double rho, rho_eq_scale, sigma, alpha, eps_abs, eps_rel;   /* ADMM (OSQP Algorithm 1) */
+    double rho, rho_eq_scale, sigma, alpha, eps_abs, eps_rel;   /* ADMM (OSQP Algorithm 1).  rho = 0 (the default) picks the
+                                   * penalty from the horizon: 1 up to N = 10, 1.5 up to 16, 2 beyond.  The fp32 entry points raise
+                                   * eps_abs / eps_rel below 2e-6 to 2e-6 (resolution of fp32 residuals). */
 } srbdqp_config;
 
 typedef struct srbdqp_handle srbdqp_handle;

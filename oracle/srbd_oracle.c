@@ -317,7 +317,7 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
     {   /* OSQP's re-balancing from the fp32 maxima of the last check (srbd_oracle.py restart_rho) */
         const double num = last_rp / fmax(last_np, 1e-30), den = last_rd / fmax(last_nd, 1e-30);
         double r1 = p->rho;
-        if (num > 0.0 && den > 0.0 && num <= INF && den <= INF) r1 = fmin(fmax(p->rho * sqrt(num / den), p->rho * 0.1), p->rho * 10.0);
+        if (num > 0.0 && den > 0.0 && num <= INF && den <= INF) r1 = fmin(fmax(p->rho * sqrt(num / den), p->rho * 0.1), p->rho * 5.0);
         for (int i = 0; i < mr; ++i) rho[i] = r1;
         iters_base = restart;
     }

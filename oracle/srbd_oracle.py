@@ -76,7 +76,7 @@ class SrbdParams:
     max_iter: int = 250
     check_every: int = 5
     # one OSQP-style re-balancing of rho (presolved path only): a QP that has not converged after rho_restart_iter
-    # iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual)), clipped to [rho/10, 10 rho] (wider clips stop further from the optimum on the same residual test), and
+    # iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual)), clipped to [rho/10, 5 rho] (wider clips stop further from the optimum on the same residual test), and
     # continues from its own (x, y) until max_iter iterations in total.  0 (or >= max_iter) = off = the default (100 solves
     # 99.9 % instead of 99.4 % of the config-2 QPs; on the GPU the second pass costs ~20 % of the batch throughput).
     rho_restart_iter: int = 0
@@ -345,6 +345,20 @@ def wrench_kinv_op(wr):
     return lambda rhs: Bd @ rhs + V.T @ (Tinv @ (V @ rhs))
 
 
+def auto_rho(N: int) -> float:
+    """The engine's default ADMM penalty (srbdqp_config.rho = 0): 1 up to N = 10, 1.5 up to N = 16, 2 beyond.  Scanned on
+    the synthetic distributions of SURVEY 8(d) at N = 8 ... 24, all schedules: the fastest fixed rho grows with the horizon
+    (about N / 7), but above 2 the residual test is passed further and further from the exact optimum (p99 0.3 - 1.5 N at
+    rho >= 3 against <= 0.05 N at rho <= 2), so the default stops there."""
+    return 1.0 if N <= 10 else (1.5 if N <= 16 else 2.0)
+
+
+def params_for(N: int, **kw) -> SrbdParams:
+    """SrbdParams as the engine runs horizon N by default (rho = auto_rho(N) unless given)."""
+    kw.setdefault("rho", auto_rho(N))
+    return SrbdParams(**kw)
+
+
 def rho_vector(p: SrbdParams, l, u):
     """Per-row ADMM penalty: rho for inequalities, rho*rho_eq_scale for equalities (OSQP's rule)."""
     rho = np.full(l.shape, p.rho)
@@ -506,7 +520,17 @@ def update_split(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None,
     else:
         wr = wrench_reduce(p, x_ref, foot_hor, contact_hor, pcom_hor)
         xi, yi = (None, None) if warm is None else (np.asarray(warm[0])[vi], np.asarray(warm[1])[ri])
-        xr_, _, yr_, iters, status = admm_solve_split(p, red["P"], red["q"], red["A"], red["l"], red["u"], wr, xi, yi, dtype=dtype)
+        args = (red["P"], red["q"], red["A"], red["l"], red["u"])
+        if 0 < p.rho_restart_iter < p.max_iter:   # the general kernel's in-kernel rho restart (same rule as solve_with_restart)
+            info = {}
+            xr_, _, yr_, iters, status = admm_solve_split(replace(p, max_iter=p.rho_restart_iter), *args, wr, xi, yi, dtype=dtype, info=info)
+            if status == STATUS_MAX_ITER:
+                p2 = replace(p, rho=restart_rho(p, info), max_iter=p.max_iter - p.rho_restart_iter)
+                wr2 = wrench_reduce(p2, x_ref, foot_hor, contact_hor, pcom_hor)
+                xr_, _, yr_, it2, status = admm_solve_split(p2, *args, wr2, xr_, yr_, dtype=dtype)
+                iters = p.rho_restart_iter + it2
+        else:
+            xr_, _, yr_, iters, status = admm_solve_split(p, *args, wr, xi, yi, dtype=dtype)
         uh[vi] = xr_
         y[ri] = yr_
     N = np.asarray(x_ref).shape[0]
@@ -560,7 +584,7 @@ def restart_rho(p: SrbdParams, info):
     den = float(info["r_dual"]) / max(float(info["n_dual"]), 1e-30)
     if not (num > 0.0 and den > 0.0 and np.isfinite(num) and np.isfinite(den)):
         return float(p.rho)
-    return float(min(max(p.rho * np.sqrt(num / den), p.rho * 0.1), p.rho * 10.0))
+    return float(min(max(p.rho * np.sqrt(num / den), p.rho * 0.1), p.rho * 5.0))
 
 
 def solve_with_restart(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.float64):

@@ -38,8 +38,9 @@ def test_config_struct_and_defaults_match_the_oracle(built_lib):
     assert cfg.struct_size == C.sizeof(_lib.Config)
     p = orc.SrbdParams()
     assert cfg.horizon == 10 and cfg.max_iter == p.max_iter and cfg.check_every == p.check_every and cfg.rho_restart_iter == p.rho_restart_iter
-    for k in ("dt", "mass", "mu", "fz_min", "fz_max", "r_diag", "force_scale", "rho", "rho_eq_scale", "sigma", "alpha", "eps_abs", "eps_rel"):
+    for k in ("dt", "mass", "mu", "fz_min", "fz_max", "r_diag", "force_scale", "rho_eq_scale", "sigma", "alpha", "eps_abs", "eps_rel"):
         assert getattr(cfg, k) == getattr(p, k), k
+    assert cfg.rho == 0.0 and orc.auto_rho(cfg.horizon) == p.rho          # 0 = chosen from the horizon (oracle auto_rho)
     assert tuple(cfg.inertia) == tuple(p.inertia) and tuple(cfg.q_diag) == tuple(p.q_diag)
     # the header's status / error codes are the ones the Python side and the oracle use
     hdr = open(os.path.join(ROOT, "include", "srbdqp.h")).read()
@@ -51,8 +52,10 @@ def test_config_struct_and_defaults_match_the_oracle(built_lib):
 
 def test_create_rejects_bad_configs_before_touching_the_device(built_lib):
     from g1_locomotion_amd import _lib
-    for mutate in (lambda c: setattr(c, "horizon", 7), lambda c: setattr(c, "struct_size", 8), lambda c: setattr(c, "rho", 0.0),
-                   lambda c: setattr(c, "max_iter", 0), lambda c: setattr(c, "max_contacts_per_step", 5), lambda c: c.q_diag.__setitem__(0, -1.0)):
+    for mutate in (lambda c: setattr(c, "horizon", 7), lambda c: setattr(c, "struct_size", 8), lambda c: setattr(c, "rho", -1.0),
+                   lambda c: setattr(c, "max_iter", 0), lambda c: setattr(c, "max_contacts_per_step", 5), lambda c: c.q_diag.__setitem__(0, -1.0),
+                   lambda c: c.inertia.__setitem__(1, 0.0), lambda c: setattr(c, "alpha", 2.5), lambda c: setattr(c, "eps_abs", -1e-6),
+                   lambda c: setattr(c, "fz_min", 2000.0), lambda c: setattr(c, "r_diag", -1.0), lambda c: setattr(c, "eps_rel", float("nan"))):
         cfg = _lib.default_config()
         mutate(cfg)
         h = C.c_void_p()

@@ -160,8 +160,8 @@ def test_ragged_horizons_bucketed_launch(torch_first, built_lib):
     eng = RaggedMPC(horizons=(8, 12, 16, 20))
     res = eng.solve(problems)
     eng.close()
-    p = orc.SrbdParams()
     for pr, r in zip(problems, res):
+        p = orc.params_for(pr["x_ref"].shape[0])
         ref = orc.update(p, pr["x0"], pr["x_ref"], pr["foot"], pr["contact"])
         assert r["status"] == ref["status"] and abs(r["iters"] - ref["iters"]) <= p.check_every
         assert r["u"].shape == pr["foot"].shape and np.abs(r["u"] - ref["u"]).max() <= TOL_TWIN_N
@@ -208,7 +208,7 @@ def test_large_batch_against_c_oracle(torch_first, built_lib, N, pattern, B):
         rng = np.random.default_rng(17)
         ct = (rng.random(ct.shape) < 0.6).astype(np.uint8)
         ct[0] = 0; ct[1] = 1; ct[2, :, 1:] = 0            # flight, full double support, a single heel point
-    p = orc.SrbdParams()
+    p = orc.params_for(N)
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     with _engine(N) as eng:
         out = eng.solve(x0, xr, ft, ct)

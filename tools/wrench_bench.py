@@ -12,6 +12,7 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 rho = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
 eps = float(sys.argv[5]) if len(sys.argv) > 5 else 1e-6
 max_iter = int(sys.argv[6]) if len(sys.argv) > 6 else 250
+restart = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=2026, schedule=sched)
 dev = torch.device("cuda", 0)
 res = {}
@@ -21,7 +22,7 @@ for name, f32 in (("f64", False), ("f32", True)):
     u = torch.zeros((B, N, 12), dtype=tdt, device=dev)
     st = torch.zeros(B, dtype=torch.int32, device=dev)
     it = torch.zeros(B, dtype=torch.int32, device=dev)
-    with BatchMPC(horizon=N, kernel=_lib.KERNEL_WRENCH, rho=rho, eps_abs=eps, eps_rel=eps, max_iter=max_iter) as eng:
+    with BatchMPC(horizon=N, kernel=_lib.KERNEL_WRENCH, rho=rho, eps_abs=eps, eps_rel=eps, max_iter=max_iter, rho_restart_iter=restart) as eng:
         def run():
             eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(), status=st.data_ptr(), iters=it.data_ptr(), f32=f32)
         run(); eng.synchronize()
@@ -32,7 +33,7 @@ for name, f32 in (("f64", False), ("f32", True)):
         kn = eng.kernel_name()
     itc, stc = it.cpu().numpy(), st.cpu().numpy()
     res[name] = (itc, stc, u.cpu().numpy().astype(np.float64))
-    print(f"{name} {kn} N={N} {sched} B={B} rho={rho} eps={eps}: {B / dt / 1e6:.3f} M QP/s  {dt * 1e3:.2f} ms  mean iters {itc.mean():.1f} p50 {np.median(itc):.0f} p99 {np.percentile(itc, 99):.0f}"
+    print(f"{name} {kn} N={N} {sched} B={B} rho={rho} eps={eps} restart={restart} max_iter={max_iter}: {B / dt / 1e6:.3f} M QP/s  {dt * 1e3:.2f} ms  mean iters {itc.mean():.1f} p50 {np.median(itc):.0f} p99 {np.percentile(itc, 99):.0f}"
           f" max {itc.max()}  solved {(stc == 1).mean():.5f}  status counts {dict(zip(*np.unique(stc, return_counts=True)))}", flush=True)
 i64, s64, u64 = res["f64"]; i32, s32, u32 = res["f32"]
 bad = np.where(s32 != 1)[0]
