@@ -307,7 +307,7 @@ def roofline(kname, N, B, mean_iters, kernel_ms, peak, esz, ms_per_step, S):
          "frac_note": "ALGORITHMIC-equivalent: SURVEY 8(d)'s W(N, K) of the dense 12N-variable path over the live kernel time; "
                       "a throughput yardstick, not a utilisation -- see frac_executed",
          "frac_executed": None, "traffic": None,
-         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*_pmc_summary.json)",
+         "traffic_unit": "bytes per solve = per launch of this step's kernels (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*_pmc_summary.json)",
          "algorithmic_bytes_per_launch": abytes, "kernel": kname, "kernel_ms": kernel_ms,
          "kernel_ms_note": "one solve at a time (5 isolated solves after warm-up, HIP events on the launch stream; with the rho "
                            "restart on, a solve = the first pass + the selection kernel + the pass over the capped QPs); the timed "
@@ -326,11 +326,12 @@ def roofline(kname, N, B, mean_iters, kernel_ms, peak, esz, ms_per_step, S):
                 best = d
                 best["_file"] = f
         if best is not None:
-            r["traffic"] = best["hbm"]["traffic_bytes_per_launch"]
+            r["traffic"] = best["hbm"].get("traffic_bytes_per_solve", best["hbm"]["traffic_bytes_per_launch"])
             ex = best.get("executed")
             if ex:
-                r["executed_flops_per_launch"] = ex["flops_per_launch"]
-                r["frac_executed"] = ex["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12 / peak
+                fl = ex.get("flops_per_solve", ex["flops_per_launch"])
+                r["executed_flops_per_launch"] = fl
+                r["frac_executed"] = fl / (kernel_ms * 1e-3) / 1e12 / peak
                 r["frac_executed_note"] = ex["note"]
                 r["bound"] = ex["bound"]
                 r["utilisation"] = ex["utilisation"]

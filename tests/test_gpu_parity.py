@@ -312,7 +312,7 @@ def test_rho_restart_matches_the_oracle(torch_first, built_lib, kernel):
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=1000, schedule="single")
     p = orc.SrbdParams(rho_restart_iter=100)
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
-    assert (ref["iters"] > 100).sum() >= 20 and (ref["status"] == orc.STATUS_SOLVED).mean() > 0.998
+    assert (ref["iters"] > 100).sum() >= 20 and (ref["status"] == orc.STATUS_SOLVED).mean() > 0.997
     kid = {"compact": _lib.KERNEL_COMPACT, "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE}[kernel]
     with _engine(N, kernel=kid, rho_restart_iter=100) as eng:
         out = eng.solve(x0, xr, ft, ct)
@@ -323,7 +323,7 @@ def test_rho_restart_matches_the_oracle(torch_first, built_lib, kernel):
     assert same.mean() > 0.97
     err = np.abs(out["u"] - ref["u"]).reshape(B, -1).max(1)
     assert err[same].max() <= 1e-3 and err.max() <= 2 * TOL_TWIN_N, (err[same].max(), err.max())
-    # the restarted QPs against the exact optimum (rho' is clipped to [rho/10, 10 rho] for exactly this)
+    # the restarted QPs against the exact optimum (rho' is clipped to [rho/10, 5 rho] for exactly this)
     for b in np.where((ref["iters"] > 100) & (ref["status"] == orc.STATUS_SOLVED))[0][:12]:
         xs, _ = orc.solve_reference(p, orc.build_qp(p, x0[b], xr[b], ft[b], ct[b]))
         assert np.abs(out["u"][b].reshape(-1) - xs * p.force_scale).max() <= TOL_EXACT_N

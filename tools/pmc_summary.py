@@ -14,6 +14,7 @@ def main():
     pmc_dir, stats_dir, out, kname, B, N, esz = sys.argv[1:8]
     B, N, esz = int(B), int(N), int(esz)
     rnd = int(sys.argv[8]) if len(sys.argv) > 8 else 2
+    lps = float(sys.argv[9]) if len(sys.argv) > 9 else 1.0     # launches of the dominant kernel per solve (rho restart on: 2)
     from pmc_parse import parse
     # kernels in the stats: pick the srbdqp solver kernels (not the 1-workgroup helper kernels)
     stats = {}
@@ -88,9 +89,12 @@ def main():
          "kernel_avg_us_rocprof_kernel_trace": tot_us,
          "hbm": {"fetch_bytes_corrected_x2": tot_fetch, "write_bytes": tot_write, "traffic_bytes_per_launch": tot_fetch + tot_write,
                  "algorithmic_bytes_per_launch": alg,
+                 "traffic_bytes_per_solve": (tot_fetch + tot_write) * lps,
                  "note": "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled per MI355X_MICROARCH.md (HBM section); WRITE_SIZE taken as is; "
-                         "all solver kernels of a solve summed (weighted by their launches per solve)"},
-         "executed": {"flops_per_launch": tot_flops, "peak_TFLOPs": PEAK[esz],
+                         "per launch = the mean over the launches of the dominant kernel (with the rho restart on, a solve is two launches of "
+                         "it: the full pass and the pass over the capped QPs); per solve = x launches_per_solve"},
+         "launches_per_solve": lps,
+         "executed": {"flops_per_launch": tot_flops, "flops_per_solve": tot_flops * lps, "peak_TFLOPs": PEAK[esz],
                       "TFLOPs_at_rocprof_avg": tot_flops / (tot_us * 1e-6) / 1e12, "frac_at_rocprof_avg": tot_flops / (tot_us * 1e-6) / 1e12 / PEAK[esz],
                       "bound": bound,
                       "utilisation": {"valu_busy": vu, "mfma_busy": mu, "lds_busy": lu, "hbm_frac_of_8TBps": hbm_frac, "wave_time_split": ws,
