@@ -75,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1)
     ap.add_argument("--batch", type=int, default=0, help="QPs per GPU per step (default: the config's)")
-    ap.add_argument("--kernel", choices=["auto", "gj", "mfma", "compact", "split", "wave", "wrench"], default="auto",
+    ap.add_argument("--kernel", choices=["auto", "compact", "split", "wave", "wrench"], default="auto",
                     help="auto = the fastest parity-green kernel for the config")
     ap.add_argument("--streams", type=int, default=2,
                     help="consecutive steps alternate over this many HIP streams, so the straggler tail of one batch "
@@ -172,8 +172,8 @@ def main(argv=None):
     else:
         from g1_locomotion_amd import BatchMPC, _lib
         SOLVED = _lib.SOLVED
-        kid = {"auto": _lib.KERNEL_AUTO, "gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "compact": _lib.KERNEL_COMPACT,
-               "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE, "wrench": _lib.KERNEL_WRENCH}[args.kernel]
+        kid = {"auto": _lib.KERNEL_AUTO, "compact": _lib.KERNEL_COMPACT, "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE,
+               "wrench": _lib.KERNEL_WRENCH}[args.kernel]
         eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=cfg["maxs"],
                        **({"max_iter": args.max_iter} if args.max_iter > 0 else {}),
                        **({"rho_restart_iter": args.rho_restart} if args.rho_restart != 0 else {}))

@@ -21,7 +21,7 @@ SOLVED, MAX_ITER, NUMERICAL, CONTACT_BOUND = 1, 2, -1, -2
 FLAG_TIMING = 1
 FLAG_NO_SPIN = 2
 FLAG_SETUP4 = 4
-KERNEL_AUTO, KERNEL_GJ, KERNEL_MFMA, KERNEL_COMPACT, KERNEL_SPLIT, KERNEL_WAVE, KERNEL_WRENCH = 0, 1, 2, 3, 4, 5, 6
+KERNEL_AUTO, KERNEL_COMPACT, KERNEL_SPLIT, KERNEL_WAVE, KERNEL_WRENCH = 0, 3, 4, 5, 6   # 1, 2: the retired round-1 baselines
 
 EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",

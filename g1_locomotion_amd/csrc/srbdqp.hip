@@ -10,10 +10,10 @@
 #include <chrono>
 #include <string>
 #include <unordered_set>
+#include <vector>
 
 #include "srbdqp.h"
 #include "srbdqp_common.hpp"
-#include "srbdqp_gj.hpp"
 #include "srbdqp_mfma.hpp"
 #include "srbdqp_compact.hpp"
 #include "srbdqp_split.hpp"
@@ -122,9 +122,7 @@ bool horizon_supported(int N) { return N == 4 || N == 8 || N == 10 || N == 12 ||
 
 int resolve_kernel(const srbdqp_config& c) {
     if (c.kernel == SRBDQP_KERNEL_WRENCH) return SRBDQP_KERNEL_WRENCH;
-    if (c.kernel == SRBDQP_KERNEL_GJ) return SRBDQP_KERNEL_GJ;
-    if (c.kernel == SRBDQP_KERNEL_MFMA) return SRBDQP_KERNEL_MFMA;
-    return SRBDQP_KERNEL_COMPACT;
+    return SRBDQP_KERNEL_COMPACT;   // AUTO, COMPACT, SPLIT and WAVE: the presolved family of srbdqp_compact.hpp
 }
 
 void fill_args(const srbdqp_config& c, KArgs& a) {
@@ -161,6 +159,19 @@ int set_lds_once(srbdqp_handle* h, K kernel, size_t lds) {
 // (launch_wave); smaller ones, the staged path and the big instantiations use the 4-wave kernel.  Measured cross-over of
 // the per-call time (tools/threshold_probe.py): 512.
 constexpr int kSplitMinBatch = 512;
+
+// Batches of at least this many QPs with more than 2 stance contacts in a step go to the general kernel at N <= 10 too
+// (measured, tools/schedule_bench.py: N = 10 double support 10.8 M QP/s against 4.2 M on the 4-wave compact kernel, mixed
+// gait 10.4 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
+constexpr int kWrenchMinBatch = 256;
+
+// does a solve of B QPs on this handle go to the general kernel (srbdqp_wrench.hpp)?  launch() / launch_long() ask this.
+inline bool uses_wrench(const srbdqp_handle* h, int maxs, int B) {
+    const int N = h->cfg.horizon;
+    if (h->cfg.kernel == SRBDQP_KERNEL_WRENCH || h->io_f32 || N == 24) return true;
+    if (N > 10) return maxs > 2;
+    return h->cfg.kernel == SRBDQP_KERNEL_AUTO && maxs > 2 && B >= kWrenchMinBatch && !h->stamps && !h->signal_next;
+}
 
 // KERNEL_SPLIT (A/B): the one-wave set-up and the one-wave ADMM as two kernels with the hand-over through HBM.
 
@@ -206,7 +217,8 @@ int launch_wave(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     constexpr size_t lds1 = srbdqp::Setup1Smem<N, MAXS>::bytes;
     static const std::string nm = "wave_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
-    hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
+    if (a.mode == 1) hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, true, true>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
+    else hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
     HIP_TRY(h, hipGetLastError());
     return SRBDQP_OK;
 }
@@ -215,41 +227,30 @@ template <int N, int MAXS>
 int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     if constexpr (srbdqp::Setup1Smem<N, MAXS>::supported) {
         const bool want = h->cfg.kernel == SRBDQP_KERNEL_WAVE || (h->cfg.kernel == SRBDQP_KERNEL_AUTO && a.B >= kSplitMinBatch);
-        if (want && a.mode == 0 && (!a.stamps || h->cfg.kernel == SRBDQP_KERNEL_WAVE) && !a.done_flag) return launch_wave<N, MAXS>(h, a, st);
+        if (want && (!a.stamps || h->cfg.kernel == SRBDQP_KERNEL_WAVE) && !a.done_flag) return launch_wave<N, MAXS>(h, a, st);
     }
     if constexpr (srbdqp::SplitWs<N, MAXS>::supported) {
         if (h->cfg.kernel == SRBDQP_KERNEL_SPLIT && a.mode == 0 && !a.stamps && !a.done_flag) return launch_split<N, MAXS>(h, a, st);
     }
     constexpr size_t lds = srbdqp::CompactTraits<N, MAXS>::lds_bytes;
-    int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS>, lds);
-    if (rc != SRBDQP_OK) return rc;
     static const std::string nm = "compact_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
+    if (a.mode == 1) {   // assembly dump: the same kernel, stopped before its factorisation
+        int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, false, true>, lds);
+        if (rc != SRBDQP_OK) return rc;
+        hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, false, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), lds, st, a);
+        return SRBDQP_OK;
+    }
+    int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS>, lds);
+    if (rc != SRBDQP_OK) return rc;
     hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), lds, st, a);
     return SRBDQP_OK;
 }
 
 template <int N>
-int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int variant, int maxs) {
-    const dim3 grid((unsigned)a.B), block(srbdqp::kThreads);
-    int rc = SRBDQP_OK;
-    if (variant == SRBDQP_KERNEL_COMPACT) {
-        rc = (maxs <= 2) ? launch_compact<N, 2>(h, a, st) : launch_compact<N, 4>(h, a, st);
-        if (rc != SRBDQP_OK) return rc;
-    } else if (variant == SRBDQP_KERNEL_MFMA && srbdqp::MfmaTraits<N>::supported) {
-        constexpr size_t lds = srbdqp::MfmaTraits<N>::lds_bytes;
-        rc = set_lds_once(h, &srbdqp::srbdqp_mfma_kernel<N>, lds);
-        if (rc != SRBDQP_OK) return rc;
-        h->kname = srbdqp::MfmaTraits<N>::name;
-        hipLaunchKernelGGL(srbdqp::srbdqp_mfma_kernel<N>, grid, block, lds, st, a);
-    } else {
-        constexpr size_t lds = srbdqp::GjSmem<N>::bytes;
-        rc = set_lds_once(h, &srbdqp::srbdqp_gj_kernel<N>, lds);
-        if (rc != SRBDQP_OK) return rc;
-        static const std::string nm = "gj_f64_n" + std::to_string(N);
-        h->kname = nm.c_str();
-        hipLaunchKernelGGL(srbdqp::srbdqp_gj_kernel<N>, grid, block, lds, st, a);
-    }
+int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
+    int rc = (maxs <= 2) ? launch_compact<N, 2>(h, a, st) : launch_compact<N, 4>(h, a, st);
+    if (rc != SRBDQP_OK) return rc;
     HIP_TRY(h, hipGetLastError());
     return SRBDQP_OK;
 }
@@ -297,7 +298,7 @@ template <int N>
 int launch_long(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
     // the compact kernel exists only with <= 2 stance contacts per step at these horizons; anything else (and every
     // fp32 call) goes to the general kernel
-    if (maxs > 2 || h->io_f32 || a.mode == 1 || h->cfg.kernel == SRBDQP_KERNEL_WRENCH) return launch_wrench<N>(h, a, st);
+    if (uses_wrench(h, maxs, a.qp_span > a.B ? a.qp_span : a.B)) return launch_wrench<N>(h, a, st);
     int rc = launch_compact<N, 2>(h, a, st);
     if (rc != SRBDQP_OK) return rc;
     HIP_TRY(h, hipGetLastError());
@@ -307,15 +308,14 @@ int launch_long(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
 // pass: 0 = the only launch of a solve, 1 = first of two (restart follows), 2 = second of two
 int launch(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs = 4, int pass = 0) {
     if (a.B <= 0) return SRBDQP_OK;
-    const bool force_wrench = h->cfg.kernel == SRBDQP_KERNEL_WRENCH || h->io_f32;
-    const int variant = (a.mode == 1) ? SRBDQP_KERNEL_GJ : resolve_kernel(h->cfg);
+    const bool force_wrench = uses_wrench(h, maxs, a.qp_span > a.B ? a.qp_span : a.B);
     const bool timing = (h->cfg.flags & SRBDQP_FLAG_TIMING) != 0;
     if (timing && pass != 2) { HIP_TRY(h, hipEventRecord(h->ev0, st)); h->ev_mid_valid = false; }
     int rc;
     switch (h->cfg.horizon) {
-        case 4: rc = force_wrench ? launch_wrench<4>(h, a, st) : launch_n<4>(h, a, st, variant, maxs); break;
-        case 8: rc = force_wrench ? launch_wrench<8>(h, a, st) : launch_n<8>(h, a, st, variant, maxs); break;
-        case 10: rc = force_wrench ? launch_wrench<10>(h, a, st) : launch_n<10>(h, a, st, variant, maxs); break;
+        case 4: rc = force_wrench ? launch_wrench<4>(h, a, st) : launch_n<4>(h, a, st, maxs); break;
+        case 8: rc = force_wrench ? launch_wrench<8>(h, a, st) : launch_n<8>(h, a, st, maxs); break;
+        case 10: rc = force_wrench ? launch_wrench<10>(h, a, st) : launch_n<10>(h, a, st, maxs); break;
         case 12: rc = launch_long<12>(h, a, st, maxs); break;
         case 16: rc = launch_long<16>(h, a, st, maxs); break;
         case 20: rc = launch_long<20>(h, a, st, maxs); break;
@@ -372,23 +372,16 @@ __global__ __launch_bounds__(1024) void srbdqp_restart_select_kernel(const int32
     if (threadIdx.x == 0) *count = cnt;
 }
 
-// does a solve of this handle go to the general kernel (srbdqp_wrench.hpp)?  Mirrors launch() / launch_long().
-inline bool uses_wrench(const srbdqp_handle* h, int maxs) {
-    const int N = h->cfg.horizon;
-    if (h->cfg.kernel == SRBDQP_KERNEL_WRENCH || h->io_f32 || N == 24) return true;
-    return N > 10 && maxs > 2 && h->cfg.kernel != SRBDQP_KERNEL_GJ && h->cfg.kernel != SRBDQP_KERNEL_MFMA;
-}
-
 // Iteration at which a solve of this handle re-balances rho (0 = never).  srbdqp_config.rho_restart_iter: > 0 that
 // iteration, < 0 off, 0 = automatic: 100 (125 above N = 16) on the general kernel (its long horizons have a 1 - 10 % tail
 // of slow QPs, and at its batch sizes the second launch costs 3 - 5 %), off elsewhere (the N = 10 batch kernels run
 // 0.2 ms steps, where a second launch costs a quarter of the throughput: DESIGN.md).
-inline int restart_iter_of(const srbdqp_handle* h, int maxs) {
+inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B) {
     const srbdqp_config& c = h->cfg;
     const int rk = resolve_kernel(c);
     if (rk != SRBDQP_KERNEL_COMPACT && rk != SRBDQP_KERNEL_WRENCH) return 0;   // v0 / v1 have no restart
     int r = c.rho_restart_iter;
-    if (r == 0) r = uses_wrench(h, maxs) ? (c.horizon <= 16 ? 100 : 125) : 0;
+    if (r == 0) r = (uses_wrench(h, maxs, B) && c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : 0;
     return (r > 0 && r < c.max_iter) ? r : 0;
 }
 
@@ -420,6 +413,7 @@ int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int m
     // every capped QP is listed and re-run, one per workgroup; the grid covers the worst case (all of them) and the
     // workgroups beyond the count exit at once (an empty workgroup costs a few ns of dispatch)
     const int grid2 = B;
+    (void)maxs;
     hipLaunchKernelGGL(srbdqp_restart_select_kernel, dim3(1), dim3(1024), 0, st, a1.status, slot->resid, B, h->cfg.rho,
                        slot->list, slot->count, slot->rho);
     HIP_TRY(h, hipGetLastError());
@@ -475,7 +469,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(srbdqp_config)) { g_create_err = "srbdqp_config.struct_size mismatch"; return SRBDQP_E_INVALID; }
     if (!horizon_supported(cfg->horizon)) { g_create_err = "unsupported horizon (N in {4, 8, 10, 12, 16, 20, 24})"; return SRBDQP_E_INVALID; }
-    if (cfg->horizon > 10 && (cfg->kernel == SRBDQP_KERNEL_GJ || cfg->kernel == SRBDQP_KERNEL_MFMA)) { g_create_err = "horizons above 10 exist only for the compact and the general kernel"; return SRBDQP_E_INVALID; }
+    if (cfg->kernel != SRBDQP_KERNEL_AUTO && cfg->kernel != SRBDQP_KERNEL_COMPACT && cfg->kernel != SRBDQP_KERNEL_SPLIT &&
+        cfg->kernel != SRBDQP_KERNEL_WAVE && cfg->kernel != SRBDQP_KERNEL_WRENCH) { g_create_err = "unknown srbdqp_config.kernel (the round-1 baselines v0 / v1 are retired)"; return SRBDQP_E_INVALID; }
     if (!(cfg->dt > 0) || !(cfg->mass > 0) || !(cfg->force_scale > 0) || !(cfg->rho >= 0) || !(cfg->sigma > 0) ||
         cfg->max_iter < 1 || cfg->check_every < 1 || !(cfg->mu >= 0) || cfg->max_contacts_per_step < 0 || cfg->max_contacts_per_step > 4) { g_create_err = "invalid constants"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }
@@ -615,7 +610,7 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     if (rc != SRBDQP_OK) return rc;
     rc = wait_done();
     if (rc != SRBDQP_OK) return rc;
-    if (restart_iter_of(h, maxs) && !h->stamps) {
+    if (restart_iter_of(h, maxs, B) && !h->stamps) {
         bool capped = false;
         for (int32_t q = 0; q < B; ++q) capped |= (h->stage_h.status[q] == SRBDQP_MAX_ITER);
         if (capped) {
@@ -702,7 +697,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
         a.perm = slot->perm;
     }
     int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
-    const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h, maxs);
+    const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h, maxs, B);
     if (!restart) return launch(h, a, lst, maxs);
 
     // ---- two passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those
@@ -833,6 +828,18 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const dou
     if (B == 0) return SRBDQP_OK;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t N = (size_t)h->cfg.horizon, n = 12 * N, m = 20 * N, b = (size_t)B;
+    int maxs = h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4;
+    if (h->cfg.max_contacts_per_step <= 0) {   // as the host-buffer solve: the instantiation follows the batch's own contact flags
+        int worst = 0;
+        for (size_t q = 0; q < b * N && worst <= 2; ++q) {
+            const uint8_t* c = contact + 4 * q;
+            const int cnt = (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
+            if (cnt > worst) worst = cnt;
+        }
+        maxs = (worst <= 2) ? 2 : 4;
+    }
+    h->io_f32 = false;
+    if (uses_wrench(h, maxs, B)) { h->err = "this configuration solves on the general kernel: use srbdqp_assemble_wrench_f64"; return SRBDQP_E_INVALID; }
     auto carve = [&](Carver& c, double*& dx0, double*& dxr, double*& dft, uint8_t*& dct, double*& dpc, double*& dP,
                      double*& dq, double*& dl, double*& du) {
         dx0 = c.take<double>(b * 13); dxr = c.take<double>(b * N * 13); dft = c.take<double>(b * N * 12);
@@ -853,19 +860,56 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const dou
     HIP_TRY(h, hipMemcpyAsync(dft, foot, b * N * 12 * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(dct, contact, b * N * 4, hipMemcpyHostToDevice, st));
     if (pcom) HIP_TRY(h, hipMemcpyAsync(dpc, pcom, b * N * 3 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemsetAsync(dP, 0, b * n * n * 8, st));
+    HIP_TRY(h, hipMemsetAsync(dq, 0, b * n * 8, st));
+    HIP_TRY(h, hipMemsetAsync(dl, 0, b * m * 8, st));
+    HIP_TRY(h, hipMemsetAsync(du, 0, b * m * 8, st));
     KArgs a;
     std::memset(&a, 0, sizeof(a));
     fill_args(h->cfg, a);
     a.x0 = dx0; a.xref = dxr; a.foot = dft; a.contact = dct; a.pcom = dpc;
     a.P_out = dP; a.q_out = dq; a.l_out = dl; a.ub_out = du;
     a.B = B; a.mode = 1;
-    rc = launch(h, a, st);
+    rc = launch(h, a, st, maxs);                 // the kernel a solve of this batch would run, stopped before its factorisation
     if (rc != SRBDQP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(P_out, dP, b * n * n * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(q_out, dq, b * n * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(l_out, dl, b * m * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(ub_out, du, b * m * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipStreamSynchronize(st));
+    HIP_TRY(h, hipGetLastError());
+    // compact K, q, map -> full-size P, q in the original variable order (on the host: bookkeeping, not the hot path)
+    std::vector<double> K(n * n), qc(n), mp(m);
+    const double rho = h->cfg.rho, aa = 4.0 * h->cfg.mu * h->cfg.mu + 1.0, sc = h->cfg.force_scale;
+    for (size_t q = 0; q < b; ++q) {
+        HIP_TRY(h, hipMemcpyAsync(K.data(), dP + q * n * n, n * n * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(qc.data(), dq + q * n, n * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(mp.data(), dl + q * m, m * 8, hipMemcpyDeviceToHost, st));
+        double nad = 0.0;
+        HIP_TRY(h, hipMemcpyAsync(&nad, du + q * m, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        double* P = P_out + q * n * n;
+        double* qq = q_out + q * n;
+        std::fill(P, P + n * n, 0.0);
+        std::fill(qq, qq + n, 0.0);
+        if (nad < 0.0) { h->err = "a QP of the batch violates max_contacts_per_step"; return SRBDQP_E_INVALID; }
+        const int na = (int)nad, ne = 3 * na;
+        for (int r = 0; r < ne; ++r) {
+            const int vr = 3 * (int)mp[r / 3] + r % 3;
+            qq[vr] = qc[r];
+            for (int c = 0; c < ne; ++c) {
+                const int vc = 3 * (int)mp[c / 3] + c % 3;
+                double v = K[(size_t)r * n + c];
+                if (r == c) v -= h->cfg.sigma + rho * ((r % 3 < 2) ? 2.0 : aa);
+                P[(size_t)vr * n + vc] = v;
+            }
+        }
+        // a8: rows 20 k + 5 i + j of step k, contact i
+        for (size_t k = 0; k < N; ++k)
+            for (int i = 0; i < 4; ++i) {
+                const bool on = contact[(q * N + k) * 4 + i] != 0;
+                double* lo = l_out + q * m + 20 * k + 5 * i;
+                double* hi = ub_out + q * m + 20 * k + 5 * i;
+                for (int j = 0; j < 4; ++j) { lo[j] = -srbdqp::kInf; hi[j] = 0.0; }
+                lo[4] = on ? h->cfg.fz_min / sc : 0.0;
+                hi[4] = on ? h->cfg.fz_max / sc : 0.0;
+            }
+    }
     return SRBDQP_OK;
 }
 

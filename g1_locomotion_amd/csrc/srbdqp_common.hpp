@@ -1,10 +1,9 @@
 // srbdqp_common.hpp -- device-side building blocks shared by every kernel variant of the SRBD QP hot path.
 //
-// One workgroup (256 threads = 4 wave64) solves one QP; everything between the input load and the output
-// store lives in LDS / registers.  The phases mirror SURVEY.md section 8(a):
-//   a5 linearise  -> load_and_linearise()      a6 condense -> build_G()  (G = Q^1/2 * s * B_qp, packed block-lower)
-//   a7 gradient   -> build_gradient()          a8 bounds   -> row_bounds()
-//   a9 ADMM       -> admm_loop()               a10 rollout -> rollout_and_store()
+// Everything between the input load and the output store lives in LDS / registers.  The phases mirror SURVEY.md
+// section 8(a): a5 linearise -> load_and_linearise(); a6 + a7 condensation, Hessian, gradient in closed form and a8 the
+// friction-cone rows -> the kernels themselves (srbdqp_compact.hpp, srbdqp_setup1.hpp, srbdqp_wrench.hpp); a9 ADMM ->
+// their loops; a10 rollout -> rollout_and_store().
 // The reference implementation of these steps is the absent submodule g1_mpc (see oracle/srbd_oracle.py header);
 // the conventions come from its call sites g1_mujoco_sim/src/run_simulation.py:73-111.
 #pragma once
@@ -89,36 +88,6 @@ struct Dims {
     static constexpr int VE = (n + kThreads - 1) / kThreads;   // variables per thread
 };
 
-// offset of packed G row k = 12 i + kk (length 12 (i+1))
-__device__ __forceinline__ int g_row_off(int i, int kk) { return 72 * i * (i + 1) + 12 * kk * (i + 1); }
-
-// LDS carve shared by all variants (doubles).  Everything 16-byte aligned.
-template <int N>
-struct Smem {
-    static constexpr int n = Dims<N>::n, m = Dims<N>::m;
-    static constexpr int up2(int v) { return (v + 1) & ~1; }
-    static constexpr int o_x0 = 0;                          // 13 (+1)
-    static constexpr int o_xref = o_x0 + 14;                // N*13
-    static constexpr int o_foot = o_xref + up2(N * 13);     // N*12
-    static constexpr int o_pcom = o_foot + N * 12;          // N*3
-    static constexpr int o_tm = o_pcom + up2(N * 3);        // N*9   Rz' per step
-    static constexpr int o_cp = o_tm + up2(N * 9);          // N*9   prefix sums of Rz'
-    static constexpr int o_J = o_cp + up2(N * 9);           // N*36  Iw^-1 [r]x per step
-    static constexpr int o_eh = o_J + N * 36;               // n     Q^1/2 (A_qp x0 - x_ref)
-    static constexpr int o_q = o_eh + n;                    // n     gradient
-    static constexpr int o_rhs = o_q + n;                   // n (+8 pad)
-    static constexpr int o_xt = o_rhs + n + 8;              // n
-    static constexpr int o_w = o_xt + n;                    // m     rho z - y   /  y on check iterations
-    static constexpr int o_nu = o_w + m;                    // m     rho (zt - z) + y
-    static constexpr int o_xs = o_nu + m;                   // n     x on check iterations / omega,v in rollout
-    static constexpr int o_ys = o_xs + n;                   // m     y on check iterations
-    static constexpr int o_red = o_ys + m;                  // 8*8   block reductions
-    static constexpr int o_ct = o_red + 64;                 // N*4 bytes of contact flags (as doubles: N/2)
-    static constexpr int o_misc = o_ct + up2((N * 4 + 7) / 8);
-    static constexpr int o_sq = o_misc + 8;                 // 12    sqrt(q_diag) (lane-indexed reads must not hit the kernarg segment)
-    static constexpr int o_end = o_sq + 12;
-};
-
 // ---------------------------------------------------------------------------------------------------------
 // a5: load inputs (coalesced), linearise every horizon step
 // ---------------------------------------------------------------------------------------------------------
@@ -188,77 +157,6 @@ __device__ void load_and_linearise(const KArgs& a, int b, double* sm) {
     __syncthreads();
 }
 
-// one entry of the (unweighted) condensed input matrix: row kk of block (i, j), column cc; j <= i
-template <int N, class L>
-__device__ __forceinline__ double bqp_entry(const KArgs& a, const double* sm, int i, int kk, int j, int cc) {
-    using S = L;
-    const int ax = cc % 3;
-    const double* J = sm + S::o_J + j * 36;
-    if (kk < 3) {
-        const double* Ci = sm + S::o_cp + i * 9 + kk * 3;
-        const double* Cj = sm + S::o_cp + j * 9 + kk * 3;
-        const double v = (Ci[0] - Cj[0]) * J[cc] + (Ci[1] - Cj[1]) * J[12 + cc] + (Ci[2] - Cj[2]) * J[24 + cc];
-        return a.dt * a.dt * v;
-    } else if (kk < 6) {
-        return (kk - 3 == ax) ? (double)(i - j) * a.dt * a.dt * a.inv_mass : 0.0;
-    } else if (kk < 9) {
-        return a.dt * J[(kk - 6) * 12 + cc];
-    } else {
-        return (kk - 9 == ax) ? a.dt * a.inv_mass : 0.0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// a6: condensation.  G = Q^1/2 * s * B_qp without the (all-zero) gravity rows, packed block-lower-triangular:
-// row k = 12 i + kk holds columns 0 .. 12 (i+1) - 1 at g_row_off(i, kk).  One entry per thread and step, block by
-// block (block = 12 x 12 entries of B_qp(i, j), j <= i); every LDS load is unconditional and the four row classes
-// (theta / p / omega / v) are selected arithmetically, so a wave never diverges.
-// ---------------------------------------------------------------------------------------------------------
-template <int N, class L>
-__device__ void build_G(const KArgs& a, double* sm, double* G) {
-    using S = L;
-    constexpr int NBLK = N * (N + 1) / 2;
-    const int t = threadIdx.x;
-    // block table: blk -> (i, j), j <= i  (kept in the reduction scratch; done with it before anyone reduces)
-    int* tab = reinterpret_cast<int*>(sm + S::o_red);
-    if (t < NBLK) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= t) ++i;
-        tab[t] = (i << 8) | (t - i * (i + 1) / 2);
-    }
-    __syncthreads();
-    // thread = (block group g of 3, row-pair type, rr, cc): type 0 writes the theta row rr and the omega row rr of
-    // a block, type 1 the p row rr and the v row rr; all index arithmetic is hoisted out of the block loop
-    const int g = t / 72, u = t - 72 * g;
-    const int type = u / 36, v = u - 36 * type;
-    const int rr = v / 12, cc = v - 12 * rr, ax = cc % 3;
-    const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = a.dt * a.dt * a.inv_mass;
-    const double wA = sm[S::o_sq + (type ? 3 : 0) + rr] * a.s;      // weight of the first row of the pair
-    const double wB = sm[S::o_sq + (type ? 9 : 6) + rr] * a.s;      // ... of the second
-    const int rowA = (type ? 3 : 0) + rr, rowB = (type ? 9 : 6) + rr;
-    if (g < 3) {
-        for (int blk = g; blk < NBLK; blk += 3) {
-            const int ij = tab[blk], i = ij >> 8, j = ij & 255;
-            const int len = 12 * (i + 1);
-            double* dst = G + 72 * i * (i + 1) + 12 * j + cc;
-            double vA, vB;
-            if (type == 0) {
-                const double* J = sm + S::o_J + j * 36 + cc;
-                const double* Ci = sm + S::o_cp + i * 9 + rr * 3;
-                const double* Cj = sm + S::o_cp + j * 9 + rr * 3;
-                const double j0 = J[0], j1 = J[12], j2 = J[24];
-                vA = dt2 * ((Ci[0] - Cj[0]) * j0 + (Ci[1] - Cj[1]) * j1 + (Ci[2] - Cj[2]) * j2);
-                vB = dt * ((rr == 0) ? j0 : (rr == 1) ? j1 : j2);
-            } else {
-                vA = (rr == ax) ? (double)(i - j) * dt2m : 0.0;
-                vB = (rr == ax) ? dtm : 0.0;
-            }
-            dst[len * rowA] = wA * vA;
-            dst[len * rowB] = wB * vB;
-        }
-    }
-}
-
 // free response (A_qp x0) entry for predicted state x_{i+1}, dynamic component kk (0..11)
 template <int N, class L>
 __device__ __forceinline__ double free_response(const KArgs& a, const double* sm, int i, int kk) {
@@ -278,95 +176,6 @@ __device__ __forceinline__ double free_response(const KArgs& a, const double* sm
         if (kk == 11) v += (double)(i + 1) * a.dt * x0[12];
         return v;
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// a7 (gradient half): q = G' * Q^1/2 (A_qp x0 - x_ref).  Two threads per column (even / odd rows of every block row).
-// ---------------------------------------------------------------------------------------------------------
-template <int N, class L>
-__device__ void build_gradient(const KArgs& a, double* sm, const double* G) {
-    using S = L;
-    constexpr int n = Dims<N>::n;
-    static_assert(2 * n <= kThreads, "two threads per column");
-    const int t = threadIdx.x;
-    for (int k = t; k < n; k += kThreads) {
-        const int i = k / 12, kk = k - 12 * i;
-        sm[S::o_eh + k] = sm[S::o_sq + kk] * (free_response<N, L>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
-    }
-    __syncthreads();
-    const int c = t >> 1, h = t & 1;
-    double acc = 0.0;
-    if (c < n) {
-        for (int i = c / 12; i < N; ++i) {
-            const int len = 12 * (i + 1);
-            const double* col = G + 72 * i * (i + 1) + len * h + c;
-            const double* e = sm + S::o_eh + 12 * i + h;
-            double p0 = col[0] * e[0], p1 = col[2 * len] * e[2], p2 = col[4 * len] * e[4];
-            p0 = fma(col[6 * len], e[6], p0);
-            p1 = fma(col[8 * len], e[8], p1);
-            p2 = fma(col[10 * len], e[10], p2);
-            acc += (p0 + p1) + p2;
-        }
-    }
-    {   // sum the two halves (lanes 2c, 2c+1)
-        int lo = __double2loint(acc), hi = __double2hiint(acc);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
-        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
-        acc += __hiloint2double(hi, lo);
-    }
-    if (c < n && h == 0) sm[S::o_q + c] = acc;
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// a8: friction-cone / normal-force rows.  Row r = 20 k + 5 ci + j.
-// ---------------------------------------------------------------------------------------------------------
-struct RowInfo { int v0; int j; double lo, hi, rho; };
-
-template <int N, class L>
-__device__ __forceinline__ RowInfo row_info(const KArgs& a, const double* sm, int r) {
-    using S = L;
-    const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
-    RowInfo ri;
-    const int k = r / 20, rr = r - 20 * k, ci = rr / 5;
-    ri.j = rr - 5 * ci;
-    ri.v0 = 12 * k + 3 * ci;
-    const bool on = sct[k * 4 + ci] != 0;
-    if (ri.j < 4) { ri.lo = -kInf; ri.hi = 0.0; ri.rho = a.rho; }
-    else { ri.lo = on ? a.fzmin_s : 0.0; ri.hi = on ? a.fzmax_s : 0.0; ri.rho = on ? a.rho : a.rho_eq; }
-    return ri;
-}
-
-// (A v)_r from a vector v in LDS
-__device__ __forceinline__ double apply_A_row(const double* v, const RowInfo& ri, double mu) {
-    const double fz = v[ri.v0 + 2];
-    switch (ri.j) {
-        case 0: return v[ri.v0] - mu * fz;
-        case 1: return -v[ri.v0] - mu * fz;
-        case 2: return v[ri.v0 + 1] - mu * fz;
-        case 3: return -v[ri.v0 + 1] - mu * fz;
-        default: return fz;
-    }
-}
-
-// (A' w)_c from a row vector w in LDS
-__device__ __forceinline__ double apply_At_col(const double* w, int c, double mu) {
-    const int k = c / 12, cc = c - 12 * k, ci = cc / 3, ax = cc - 3 * ci;
-    const double* p = w + 20 * k + 5 * ci;
-    if (ax == 0) return p[0] - p[1];
-    if (ax == 1) return p[2] - p[3];
-    return -mu * (p[0] + p[1] + p[2] + p[3]) + p[4];
-}
-
-// diagonal of A' diag(rho) A for variable c
-template <int N, class L>
-__device__ __forceinline__ double rho_diag(const KArgs& a, const double* sm, int c) {
-    using S = L;
-    const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
-    const int k = c / 12, cc = c - 12 * k, ci = cc / 3, ax = cc - 3 * ci;
-    if (ax < 2) return 2.0 * a.rho;
-    const double r5 = sct[k * 4 + ci] ? a.rho : a.rho_eq;
-    return 4.0 * a.mu * a.mu * a.rho + r5;
 }
 
 // block-wide max of up to NV values per thread; result broadcast to all threads.  2 barriers.
@@ -449,151 +258,6 @@ __device__ void rollout_and_store(const KArgs& a, int b, double* sm, const doubl
         }
         xo[idx] = v;
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// a9: ADMM (OSQP Algorithm 1, reduced KKT form) with the explicit inverse K^-1 held in registers:
-// thread (r = t>>1, h = t&1) owns K^-1[r][CH*h .. CH*h+CH-1] in kin[].  Mirrors oracle admm_solve() operation
-// for operation.  Preconditions: xs = x^0 (scaled), xt = P x^0, q set, and a barrier has passed.
-// On return xs holds the scaled solution, ys the dual; returns the iteration count, *status_out the status.
-// ---------------------------------------------------------------------------------------------------------
-template <int N, class L, int CH>
-__device__ int admm_loop(const KArgs& a, int b, double* sm, const double (&kin)[CH], int* status_out) {
-    using S = L;
-    constexpr int n = Dims<N>::n, m = Dims<N>::m, ME = Dims<N>::ME, VE = Dims<N>::VE;
-    const int t = threadIdx.x;
-    const int r = t >> 1, h = t & 1;
-    double* rhs = sm + S::o_rhs;
-    double* xt = sm + S::o_xt;
-    double* w = sm + S::o_w;
-    double* nu = sm + S::o_nu;
-    double* xs = sm + S::o_xs;
-    double* ys = sm + S::o_ys;
-    double* red = sm + S::o_red;
-    const double sigma = a.sigma, alpha = a.alpha, mu = a.mu;
-
-    double x[VE], px[VE], qv[VE];
-    double z[ME], y[ME];
-    RowInfo ri[ME];
-#pragma unroll
-    for (int e = 0; e < ME; ++e) {
-        const int i = t + e * kThreads;
-        ri[e] = row_info<N, L>(a, sm, i < m ? i : 0);
-    }
-    double qn[1] = {0.0};
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-        const int c = t + e * kThreads;
-        x[e] = 0.0; px[e] = 0.0; qv[e] = 0.0;
-        if (c < n) { qv[e] = sm[S::o_q + c]; x[e] = xs[c]; px[e] = xt[c]; }
-        qn[0] = fmax(qn[0], fabs(qv[e]));
-    }
-#pragma unroll
-    for (int e = 0; e < ME; ++e) {
-        const int i = t + e * kThreads;
-        z[e] = 0.0; y[e] = 0.0;
-        if (i < m) {
-            if (a.warm_y) y[e] = a.warm_y[(size_t)b * m + i];
-            const double ax = apply_A_row(xs, ri[e], mu);
-            z[e] = fmin(fmax(ax, ri[e].lo), ri[e].hi);
-            w[i] = ri[e].rho * z[e] - y[e];
-        }
-    }
-    block_max<1>(qn, red);   // also orders the w[] writes before the reads below
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-        const int c = t + e * kThreads;
-        if (c < n) rhs[c] = sigma * x[e] - qv[e] + apply_At_col(w, c, mu);
-    }
-    __syncthreads();
-
-    int status = 2, iters = a.max_iter;   // SRBDQP_MAX_ITER
-    for (int k = 1; k <= a.max_iter; ++k) {
-        const bool check = (k % a.check_every == 0) || (k == a.max_iter);
-        // ---- x~ = K^-1 rhs
-        {
-            double acc0 = 0.0, acc1 = 0.0;
-            const double2* rv = reinterpret_cast<const double2*>(rhs + CH * h);
-#pragma unroll
-            for (int cc = 0; cc < CH; cc += 2) {
-                const double2 v = rv[cc >> 1];
-                acc0 = fma(kin[cc], v.x, acc0);
-                acc1 = fma(kin[cc + 1], v.y, acc1);
-            }
-            double acc = acc0 + acc1;
-            acc += __shfl_xor(acc, 1);
-            if (h == 0 && r < n) xt[r] = acc;
-        }
-        __syncthreads();
-        // ---- constraint rows: z~, nu, relaxation, projection, dual update
-#pragma unroll
-        for (int e = 0; e < ME; ++e) {
-            const int i = t + e * kThreads;
-            if (i < m) {
-                const double rho = ri[e].rho;
-                const double zt = apply_A_row(xt, ri[e], mu);
-                nu[i] = rho * (zt - z[e]) + y[e];
-                const double zh = alpha * zt + (1.0 - alpha) * z[e];
-                const double zn = fmin(fmax(zh + y[e] / rho, ri[e].lo), ri[e].hi);
-                y[e] = y[e] + rho * (zh - zn);
-                z[e] = zn;
-                w[i] = rho * zn - y[e];
-                if (check) ys[i] = y[e];
-            }
-        }
-        __syncthreads();
-        // ---- variables: P x~ from the KKT identity, relaxation, next right-hand side
-#pragma unroll
-        for (int e = 0; e < VE; ++e) {
-            const int c = t + e * kThreads;
-            if (c < n) {
-                const double xtc = xt[c];
-                const double pxt = sigma * (x[e] - xtc) - qv[e] - apply_At_col(nu, c, mu);
-                x[e] = alpha * xtc + (1.0 - alpha) * x[e];
-                px[e] = alpha * pxt + (1.0 - alpha) * px[e];
-                rhs[c] = sigma * x[e] - qv[e] + apply_At_col(w, c, mu);
-                if (check) xs[c] = x[e];
-            }
-        }
-        __syncthreads();
-        if (check) {
-            double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // r_prim, |Ax|, |z|  /  r_dual, max(|Px|,|A'y|)
-#pragma unroll
-            for (int e = 0; e < ME; ++e) {
-                const int i = t + e * kThreads;
-                if (i < m) {
-                    const double ax = apply_A_row(xs, ri[e], mu);
-                    v[0] = fmax(v[0], fabs(ax - z[e]));
-                    v[1] = fmax(v[1], fmax(fabs(ax), fabs(z[e])));
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const int c = t + e * kThreads;
-                if (c < n) {
-                    const double aty = apply_At_col(ys, c, mu);
-                    const double rd = fabs(px[e] + qv[e] + aty);
-                    // propagate NaN/Inf through the max (fmax would drop a NaN)
-                    v[2] = (rd != rd) ? rd : fmax(v[2], rd);
-                    v[3] = fmax(v[3], fmax(fabs(px[e]), fabs(aty)));
-                }
-            }
-            v[4] = (v[2] != v[2] || v[0] != v[0]) ? 1.0 : 0.0;
-            block_max<5>(v, red);
-            const double e_prim = a.eps_abs + a.eps_rel * v[1];
-            const double e_dual = a.eps_abs + a.eps_rel * fmax(v[3], qn[0]);
-            const bool bad = (v[4] != 0.0) || !(fabs(v[0]) <= kInf) || !(fabs(v[2]) <= kInf);
-            if (bad) { status = -1; iters = k; break; }
-            if (v[0] <= e_prim && v[2] <= e_dual) { status = 1; iters = k; break; }
-        }
-    }
-    // duals for warm starts (ys is current whenever we leave through a check iteration, which is always)
-    if (a.y_out) {
-#pragma unroll
-        for (int e = 0; e < ME; ++e) { const int i = t + e * kThreads; if (i < m) a.y_out[(size_t)b * m + i] = y[e]; }
-    }
-    *status_out = status;
-    return iters;
 }
 
 }  // namespace srbdqp

@@ -306,9 +306,25 @@ struct SplitWs {
     static constexpr int doubles = o_kinv + S::nmax * KS;
 };
 
+// Assembly dump shared by the compact and the one-wave kernels (mode 1): the reduced-KKT matrix K = P + sigma I + A' rho A
+// of the PRESOLVED QP exactly as the kernel holds it before its factorisation (upper tiles, C layout -> `tiles(put)`
+// enumerates (row, col, value)), written dense at P_out with row stride 12N (both triangles), the compact gradient at
+// q_out, the compaction map (compact contact -> original contact 4 k + i) at l_out and na at ub_out[0].
+template <int N, class Tiles>
+__device__ __forceinline__ void dump_presolved(const KArgs& a, int b, int n_eff, int na, const double* qc, const uint8_t* act, Tiles&& tiles) {
+    constexpr int n = 12 * N, m = 20 * N;
+    double* P = a.P_out + (size_t)b * n * n;
+    tiles([&](int r, int c, double v) {
+        if (r < n_eff && c < n_eff) { P[(size_t)r * n + c] = v; P[(size_t)c * n + r] = v; }
+    });
+    for (int c = threadIdx.x; c < n_eff; c += blockDim.x) a.q_out[(size_t)b * n + c] = qc[c];
+    for (int e = threadIdx.x; e < na; e += blockDim.x) a.l_out[(size_t)b * m + e] = (double)act[e];
+    if (threadIdx.x == 0) a.ub_out[(size_t)b * m] = (double)na;
+}
+
 // One QP (index b) on one 256-thread workgroup; sm = the workgroup's dynamic LDS (CompactSmem<N, MAXS>::bytes).
 // Every exit is workgroup-uniform and leaves no state in LDS that a later call would rely on.
-template <int N, int MAXS, bool SPLIT = false>
+template <int N, int MAXS, bool SPLIT = false, bool DUMP = false>
 __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* sm) {
     using S = CompactSmem<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m;
@@ -385,6 +401,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
     const int na = imisc[0];
     const int n_eff = 3 * na;
     if (imisc[1] != 0 || na == 0) {   // bound violated (status -2) or nothing to solve (all forces 0)
+        if constexpr (DUMP) { if (t == 0) a.ub_out[(size_t)b * m] = (imisc[1] != 0) ? -1.0 : 0.0; return; }   // assembly dump: nothing to show
         for (int c = t; c < n; c += kThreads) sm[S::o_xs + c] = 0.0;
         if (a.y_out) for (int i = t; i < m; i += kThreads) a.y_out[(size_t)b * m + i] = 0.0;
         if (t == 0) {
@@ -645,6 +662,17 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
     SRBDQP_STAMP(a, b, 4);
     __syncthreads();
     SRBDQP_STAMP(a, b, 5);
+    if constexpr (DUMP) {   // assembly dump (srbdqp_assemble_f64): K of the presolved QP, its gradient, the compaction map
+        dump_presolved<N>(a, b, n_eff, na, sm + S::o_q, act, [&](auto&& put) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s)
+                if (ta[s] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) put(16 * ta[s] + kq + 4 * q, 16 * tb[s] + mcol, acc[s][q]);
+                }
+        });
+        return;
+    }
 
     // ================= phase F =================
     SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
@@ -852,7 +880,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
     }   // !SPLIT
 }
 
-template <int N, int MAXS, bool SPLIT = false>
+template <int N, int MAXS, bool SPLIT = false, bool DUMP = false>
 __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) void srbdqp_compact_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if ((int)blockIdx.x >= a.B) return;
@@ -860,7 +888,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
         signal_done(a);
         return;
     }
-    compact_qp<N, MAXS, SPLIT>(a, SRBDQP_QP_INDEX(a), sm);
+    compact_qp<N, MAXS, SPLIT, DUMP>(a, SRBDQP_QP_INDEX(a), sm);
 }
 
 template <int N, int MAXS>

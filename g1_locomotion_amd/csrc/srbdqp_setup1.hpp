@@ -63,7 +63,7 @@ struct Setup1Smem {
 // FUSED = true : the whole solve on this wave ("wave" kernel): the K^-1 tiles are turned into one row per lane through
 //                the 2 KB transpose tile, then the ADMM iterations and the roll-out of srbdqp_split.hpp follow in place --
 //                nothing but the inputs and the outputs touches HBM.
-template <int N, int MAXS, bool FUSED>
+template <int N, int MAXS, bool FUSED, bool DUMP = false>
 __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     using S = CompactSmem<N, MAXS>;
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     double* xs0 = sm + L1::o_mt;                             // scratch vectors of the early exit (n + 12N doubles; M is not built)
     static_assert(L1::o_end - L1::o_mt >= n + 12 * N, "early-exit scratch");
     if (imisc[1] != 0 || na == 0) {   // bound violated (status -2) or nothing to solve (all forces 0): finished here
+        if constexpr (DUMP) { if (lane == 0) a.ub_out[(size_t)b * m] = (imisc[1] != 0) ? -1.0 : 0.0; return; }   // assembly dump: nothing to show
         for (int c = lane; c < n; c += 64) xs0[c] = 0.0;
         if (a.y_out) for (int i = lane; i < m; i += 64) a.y_out[(size_t)b * m + i] = 0.0;
         if (lane == 0) {
@@ -354,6 +355,17 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     __syncthreads();   // the phase-A arrays are dead; the scratch tile is used from here on
     WSTAMP(a, b, 4);
     WSTAMP(a, b, 5);
+    if constexpr (DUMP) {   // assembly dump (srbdqp_assemble_f64), see dump_presolved()
+        dump_presolved<N>(a, b, n_eff, na, sm + S::o_q, act, [&](auto&& put) {
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                for (int tb = ta; tb < NT; ++tb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) put(16 * ta + kq + 4 * q, 16 * tb + mcol, Kt[ta][tb][q]);
+        });
+        return;
+    }
 
     // A-operand form of a C-layout tile X (operand[r] at lane (i, k') = X[i][4r + k']): through the wave-private tile
     double* scr = sm + L1::o_scr;

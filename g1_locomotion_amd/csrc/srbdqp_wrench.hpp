@@ -61,8 +61,8 @@ struct WrenchSmem {
     static constexpr int o_ct = o_red + 32;               // 4N bytes of contact flags
     static constexpr int o_misc = o_ct + up2((N * 4 + 7) / 8);   // [0] numerical failure
     static constexpr int o_sq = o_misc + 4;               // 12   sqrt(q_diag)
-    static constexpr int o_int = o_sq + 12;               // ints: gsz[N], goff[N + 1], n_g, na
-    static constexpr int o_R = o_int + up2((2 * N + 6) / 2 + 1);
+    static constexpr int o_int = o_sq + 12;               // ints: gsz[N], goff[N + 1], n_g, na, wrench flag[N]
+    static constexpr int o_R = o_int + up2((3 * N + 6) / 2 + 1);
     // ---- phase A (closed-form assembly)
     static constexpr int o_xref = o_R;                    // 13N
     static constexpr int o_foot = o_xref + up2(N * 13);   // 12N
@@ -165,12 +165,23 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
         R acc0 = R(0), acc1 = R(0), acc2 = R(0), acc3 = R(0);
         const R* src = vb + CH * h;                         // CH even; VB multiple of 8: 16-byte aligned for double, 8-byte for float
         if constexpr (sizeof(R) == 4) {
-            const R2* s2 = reinterpret_cast<const R2*>(src);
+            // columns past CH read the zero padding of the buffer and meet kin = 0
+            if ((CH & 3) == 0 && (CHMAX & 3) == 0) {            // wave-uniform: the second half starts 16-byte aligned
+                const R4* s4 = reinterpret_cast<const R4*>(src);
 #pragma unroll
-            for (int c = 0; c < CHMAX / 2; ++c) {
-                const R2 vv = s2[c];                            // columns past CH: zero padding of the buffer x zero kin
-                if (c & 1) { acc2 = fma(kin[2 * c], vv[0], acc2); acc3 = fma(kin[2 * c + 1], vv[1], acc3); }
-                else { acc0 = fma(kin[2 * c], vv[0], acc0); acc1 = fma(kin[2 * c + 1], vv[1], acc1); }
+                for (int c = 0; c < CHMAX / 4; ++c) {
+                    const R4 vv = s4[c];
+                    acc0 = fma(kin[4 * c], vv[0], acc0); acc1 = fma(kin[4 * c + 1], vv[1], acc1);
+                    acc2 = fma(kin[4 * c + 2], vv[2], acc2); acc3 = fma(kin[4 * c + 3], vv[3], acc3);
+                }
+            } else {
+                const R2* s2 = reinterpret_cast<const R2*>(src);
+#pragma unroll
+                for (int c = 0; c < CHMAX / 2; ++c) {
+                    const R2 vv = s2[c];
+                    if (c & 1) { acc2 = fma(kin[2 * c], vv[0], acc2); acc3 = fma(kin[2 * c + 1], vv[1], acc3); }
+                    else { acc0 = fma(kin[2 * c], vv[0], acc0); acc1 = fma(kin[2 * c + 1], vv[1], acc1); }
+                }
             }
         } else {
             const R2* s2 = reinterpret_cast<const R2*>(src);
@@ -223,6 +234,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     int* igsz = reinterpret_cast<int*>(sm + S::o_int);            // gsz[N]
     int* igoff = igsz + N;                                        // goff[N + 1]
     int* imisc = igoff + N + 1;                                   // [0] n_g, [1] na
+    int* iwr = imisc + 2;                                         // [N] 1 = the step uses its 6 wrench coordinates
     uint8_t* sct = reinterpret_cast<uint8_t*>(sm + S::o_ct);
     uint8_t* gstep = reinterpret_cast<uint8_t*>(sm + S::o_gs);
     const double* SQ = sm + S::o_sq;
@@ -272,7 +284,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             for (int k = 0; k < N; ++k) {
                 const int c = sct[4 * k] + sct[4 * k + 1] + sct[4 * k + 2] + sct[4 * k + 3];
                 const int g = (c >= 3) ? 6 : 3 * c;
-                igsz[k] = g; igoff[k] = off;
+                igsz[k] = g; igoff[k] = off; iwr[k] = (c >= 3) ? 1 : 0;
                 for (int r = 0; r < g; ++r) gstep[off + r] = (uint8_t)k;
                 off += g; na += c;
             }
@@ -648,19 +660,28 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                     const bool in = (r < n_g) && (c < n_g);
                     const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;
                     const int j = gstep[lo], mm = gstep[hi];
-                    const double* z1 = ZT + 6 * lo;
-                    const double* z2 = ZT + 6 * hi;
                     const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
-                    const double x0 = z2[0], x1 = z2[1], x2 = z2[2];
-                    double v = z1[0] * (M[0] * x0 + M[1] * x1 + M[2] * x2) + z1[1] * (M[3] * x0 + M[4] * x1 + M[5] * x2) +
-                               z1[2] * (M[6] * x0 + M[7] * x1 + M[8] * x2);
                     const int Ls = N - mm, d = mm - j;
                     const double sp = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2)), ls = (double)Ls;
+                    const int l1 = lo - igoff[j], l2 = hi - igoff[mm];
+                    double v;
+                    if (iwr[j] & iwr[mm]) {
+                        // both are wrench coordinates (unit vectors): the entry is a table look-up
+                        const int a1 = (l1 >= 3) ? l1 - 3 : 0;
+                        const double dg = SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls;
+                        v = (l1 < 3 && l2 < 3) ? M[3 * l1 + l2] : ((l1 >= 3 && l1 == l2) ? dg : 0.0);
+                    } else {
+                        const double* z1 = ZT + 6 * lo;
+                        const double* z2 = ZT + 6 * hi;
+                        const double x0 = z2[0], x1 = z2[1], x2 = z2[2];
+                        v = z1[0] * (M[0] * x0 + M[1] * x1 + M[2] * x2) + z1[1] * (M[3] * x0 + M[4] * x1 + M[5] * x2) +
+                            z1[2] * (M[6] * x0 + M[7] * x1 + M[8] * x2);
 #pragma unroll
-                    for (int a1 = 0; a1 < 3; ++a1)
-                        v = fma(z1[3 + a1] * z2[3 + a1], SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls, v);
+                        for (int a1 = 0; a1 < 3; ++a1)
+                            v = fma(z1[3 + a1] * z2[3 + a1], SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls, v);
+                    }
                     double val = s2 * v;
-                    if (j == mm) val += sm[S::o_ei + 36 * j + 6 * (lo - igoff[j]) + (hi - igoff[j])];
+                    if (j == mm) val += sm[S::o_ei + 36 * j + 6 * l1 + l2];
                     acc[s][q] = in ? val : ((r == c) ? 1.0 : 0.0);               // padding -> identity
                 }
             }

@@ -127,7 +127,8 @@ class BatchMPC:
         return dict(u=u, x=x, y=y, status=status, iters=iters)
 
     def assemble(self, x0, x_ref, foot, contact, pcom=None):
-        """QP data in the scaled variables: dict(P (B,n,n), q (B,n), l (B,m), u (B,m))."""
+        """QP data in the scaled variables as the shipped compact / one-wave kernel builds it (srbdqp_assemble_f64):
+        dict(P (B,n,n), q (B,n), l (B,m), u (B,m)); rows / columns of swing-contact variables are 0 (presolve)."""
         N, n, m = self.N, self.n, self.m
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         B = x0.size // NX

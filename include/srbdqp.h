@@ -54,9 +54,8 @@ extern "C" {
 
 /* srbdqp_config.kernel: which implementation of the hot path runs */
 #define SRBDQP_KERNEL_AUTO  0     /* the fastest parity-green kernel */
-#define SRBDQP_KERNEL_GJ    1     /* v0: VALU assembly + in-LDS Gauss-Jordan inverse */
-#define SRBDQP_KERNEL_MFMA  2     /* v1: fp64-MFMA contraction + tiled Cholesky inverse, all 12N variables */
-#define SRBDQP_KERNEL_COMPACT 3   /* v2: v1's pipeline on the presolved QP (swing-contact variables eliminated) */
+/* 1, 2: the round-1 baselines v0 (Gauss-Jordan) and v1 (all 12N variables on the matrix cores), retired in round 2 */
+#define SRBDQP_KERNEL_COMPACT 3   /* 4 waves per QP on the presolved QP (swing-contact variables eliminated), closed-form assembly */
 #define SRBDQP_KERNEL_SPLIT 4     /* two kernels, one wave per QP each: set-up, then ADMM + roll-out, K^-1 handed over through
                                      HBM (<= 64 presolved variables, otherwise falls back to COMPACT); kept for A/B */
 #define SRBDQP_KERNEL_WAVE 5      /* the whole solve on one wave per QP, K tiles register-resident, no barrier, no hand-over;
@@ -158,10 +157,16 @@ int srbdqp_solve_batch_device_f32(srbdqp_handle* h, int32_t B,
                                   float* u_out, float* x_out, float* y_out,
                                   int32_t* status, int32_t* iters, void* stream);
 
-/* ~ the QP-assembly half of MPC.update (what init_matrices() allocates: H, g, cone rows).  HOST
- * buffers, for parity tests of linearise/condense/H/g/bounds.  Scaled variables u_hat.
- *   P_out [B][12N][12N]   Hessian H = Bs' Q Bs + R s^2        q_out [B][12N]   gradient
+/* ~ the QP-assembly half of MPC.update (what init_matrices() allocates: H, g, cone rows), produced by the SHIPPED kernel:
+ * the kernel a srbdqp_solve_batch_f64 of the same batch would run (compact / one-wave, by srbdqp_config.kernel, batch size
+ * and contact bound) is started in dump mode and stops right before its factorisation.  HOST buffers, for parity tests of
+ * rows a5-a8 (tests/test_gpu_parity.py).  Scaled variables u_hat.
+ *   P_out [B][12N][12N]   Hessian H = Bs' Q Bs + R s^2 of the PRESOLVED QP in the original variable order: rows / columns of
+ *                         swing-contact variables (eliminated before anything is built) are 0
+ *   q_out [B][12N]        gradient (0 for swing-contact variables)
  *   l_out, ub_out [B][20N] constraint bounds (rows 20k+5i+j; +-1e30 = unbounded)
+ * Configurations that solve on the general kernel (SRBDQP_KERNEL_WRENCH, or what AUTO routes to it) return
+ * SRBDQP_E_INVALID: their assembly is srbdqp_assemble_wrench_f64's.
  */
 int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B,
                         const double* x0, const double* x_ref, const double* foot,

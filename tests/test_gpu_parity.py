@@ -31,37 +31,46 @@ def _engine(N, **kw):
     return BatchMPC(horizon=N, **kw)
 
 
-@pytest.mark.parametrize("N,schedule", [(10, "single"), (10, "double"), (10, "mixed"), (8, "single"), (4, "double")])
-def test_assembly_matches_oracle(torch_first, built_lib, N, schedule):
+@pytest.mark.parametrize("kernel", ["compact", "wave"])
+@pytest.mark.parametrize("N,schedule", [(10, "single"), (10, "double"), (10, "mixed"), (8, "single"), (8, "mixed"), (4, "double"), (4, "single"),
+                                        (12, "single"), (16, "single"), (20, "single")])
+def test_assembly_matches_oracle(torch_first, built_lib, N, schedule, kernel):
+    """Rows a5-a8 on the kernels that SHIP: srbdqp_assemble_f64 starts the kernel a solve of the batch would run (4-wave
+    compact, or the one-wave batch kernel) in dump mode, right before its factorisation.  The closed-form Hessian and
+    gradient of the presolved QP against the oracle's dense products B'QB + R, q = B'Q(A x0 - x_ref), entry by entry."""
+    from g1_locomotion_amd import _lib
     B = 6
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=100 + N, schedule=schedule)
-    with _engine(N) as eng:
+    one_wave = kernel == "wave" and (schedule == "single" and N <= 10 or N == 4)     # <= 64 presolved variables, <= 4 x 4 tiles
+    with _engine(N, kernel=_lib.KERNEL_WAVE if kernel == "wave" else _lib.KERNEL_COMPACT) as eng:
         got = eng.assemble(x0, xr, ft, ct)
-    p = orc.SrbdParams()
+        assert eng.kernel_name().startswith("wave_" if one_wave else "compact_"), eng.kernel_name()
+    p = orc.params_for(N)
     for b in range(B):
         qp = orc.build_qp(p, x0[b], xr[b], ft[b], ct[b])
-        sP = np.abs(qp["P"]).max()
-        assert np.abs(got["P"][b] - qp["P"]).max() <= 1e-11 * sP
-        assert np.abs(got["q"][b] - qp["q"]).max() <= 1e-11 * max(1.0, np.abs(qp["q"]).max())
+        red, vi, ri = orc.presolve(qp, ct[b])
+        sP = np.abs(red["P"]).max()
+        assert np.abs(got["P"][b][np.ix_(vi, vi)] - red["P"]).max() <= 1e-11 * sP
+        assert np.abs(got["q"][b][vi] - red["q"]).max() <= 1e-11 * max(1.0, np.abs(red["q"]).max())
+        off = np.setdiff1d(np.arange(12 * N), vi)
+        assert np.all(got["P"][b][off, :] == 0.0) and np.all(got["P"][b][:, off] == 0.0) and np.all(got["q"][b][off] == 0.0)
         np.testing.assert_array_equal(got["l"][b], qp["l"])
         np.testing.assert_array_equal(got["u"][b], qp["u"])
 
 
-# kernel variants: gj / mfma keep all 12N variables (swing contacts clamped by their rows); compact (= auto) solves the
-# presolved QP.  The oracle twin runs the matching algorithm (SrbdParams.eliminate_swing).
-@pytest.mark.parametrize("kernel", ["gj", "mfma", "auto", "split", "wave"])
+# kernel variants of the presolved family; the general kernel has its own file (test_gpu_wrench.py)
+@pytest.mark.parametrize("kernel", ["auto", "split", "wave"])
 @pytest.mark.parametrize("N,schedule,B", [(10, "single", 24), (10, "double", 8), (10, "mixed", 16), (8, "mixed", 8), (8, "single", 8), (4, "single", 6), (4, "double", 6)])
 def test_solve_matches_oracle_and_exact_optimum(torch_first, built_lib, kernel, N, schedule, B):
     from g1_locomotion_amd import _lib
-    kid = {"gj": _lib.KERNEL_GJ, "mfma": _lib.KERNEL_MFMA, "auto": _lib.KERNEL_AUTO, "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE}[kernel]
-    presolved = kernel in ("auto", "split", "wave")
+    kid = {"auto": _lib.KERNEL_AUTO, "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE}[kernel]
+    presolved = True
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=200 + N, schedule=schedule)
     with _engine(N, kernel=kid) as eng:
         out = eng.solve(x0, xr, ft, ct, want_y=True)
         # wave = the whole solve on one wave per QP, split = the same as two kernels with a hand-over through HBM; both
         # exist for <= 64 presolved variables, else fall back to compact
-        assert eng.kernel_name().startswith({"gj": ("gj_",), "mfma": ("mfma_",), "auto": ("compact_",), "split": ("split_", "compact_"),
-                                             "wave": ("wave_", "compact_")}[kernel]), eng.kernel_name()
+        assert eng.kernel_name().startswith({"auto": ("compact_",), "split": ("split_", "compact_"), "wave": ("wave_", "compact_")}[kernel]), eng.kernel_name()
         if kernel in ("split", "wave") and (schedule == "single" or N == 4):     # <= 64 presolved variables
             assert eng.kernel_name().startswith(kernel + "_")
     p = orc.SrbdParams(eliminate_swing=presolved)
@@ -212,7 +221,8 @@ def test_large_batch_against_c_oracle(torch_first, built_lib, N, pattern, B):
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     with _engine(N) as eng:
         out = eng.solve(x0, xr, ft, ct)
-        assert eng.kernel_name().startswith(("compact_", "split_", "wave_"))
+        # AUTO: the one-wave kernel (<= 2 stance contacts per step), the general kernel (more, batches >= 256) or compact
+        assert eng.kernel_name().startswith(("compact_", "wave_", "wrench_"))
     np.testing.assert_array_equal(out["status"], ref["status"])
     assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
     same = out["iters"] == ref["iters"]

@@ -13,7 +13,7 @@ n = 12 * N
 o = {}
 o["x0"] = 0; o["tm"] = 14; o["J"] = o["tm"] + up2(9 * N); o["red"] = o["J"] + 36 * N; o["ct"] = o["red"] + 32
 o["misc"] = o["ct"] + up2((4 * N + 7) // 8); o["sq"] = o["misc"] + 4; o["int"] = o["sq"] + 12
-o["R"] = o["int"] + up2((2 * N + 6) // 2 + 1)
+o["R"] = o["int"] + up2((3 * N + 6) // 2 + 1)
 o["xref"] = o["R"]; o["foot"] = o["xref"] + up2(13 * N); o["pcom"] = o["foot"] + 12 * N; o["cp"] = o["pcom"] + up2(3 * N)
 o["eh"] = o["cp"] + up2(9 * N); o["t1"] = o["eh"] + n; o["t2"] = o["t1"] + up2(9 * N); o["mt"] = o["t2"] + up2(9 * N)
 o["gv"] = o["mt"] + up2(9 * N * (N + 1) // 2)
