@@ -971,6 +971,191 @@ int srbdqp_assemble_wrench_f64(srbdqp_handle* h, int32_t B, const double* x0, co
     return SRBDQP_OK;
 }
 
+// ---- ragged batches (BASELINE.json configs[4]): mixed horizons, one launch per horizon bucket, all in flight together ----
+struct srbdqp_ragged {
+    std::vector<srbdqp_handle*> hs;          // one engine (own stream) per horizon bucket
+    std::vector<int> horizons;
+    std::vector<hipEvent_t> ev_out;
+    hipEvent_t ev_in = nullptr;
+    bool ev_in_pending = false;
+    int device = 0;
+    int32_t *d_perm = nullptr, *d_off = nullptr, *h_perm = nullptr, *h_off = nullptr;   // device arrays + pinned mirrors
+    size_t cap = 0;
+    char* ws = nullptr; size_t ws_bytes = 0;  // host-buffer entry point: device copies of the caller's arrays
+    hipStream_t stream = nullptr;             // ... and the stream its copies run on
+    std::string err;
+};
+
+namespace {
+std::string g_ragged_err;
+#define RAG_TRY(r, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (r)->err = std::string(#call) + ": " + hipGetErrorString(e_); return SRBDQP_E_HIP; } } while (0)
+
+int ragged_launch_bucket(srbdqp_handle* bh, const KArgs& a, hipStream_t st) {
+    bh->io_f32 = false;
+    switch (bh->cfg.horizon) {
+        case 4: return launch_wrench<4>(bh, a, st);
+        case 8: return launch_wrench<8>(bh, a, st);
+        case 10: return launch_wrench<10>(bh, a, st);
+        case 12: return launch_wrench<12>(bh, a, st);
+        case 16: return launch_wrench<16>(bh, a, st);
+        case 20: return launch_wrench<20>(bh, a, st);
+        case 24: return launch_wrench<24>(bh, a, st);
+        default: bh->err = "unsupported horizon"; return SRBDQP_E_INVALID;
+    }
+}
+}  // namespace
+
+int srbdqp_ragged_create(const srbdqp_config* cfg, const int32_t* horizons, int32_t n_horizons, srbdqp_ragged** out) {
+    if (!cfg || !horizons || !out || n_horizons < 1 || n_horizons > 16) { g_ragged_err = "bad argument"; return SRBDQP_E_INVALID; }
+    *out = nullptr;
+    srbdqp_ragged* r = new (std::nothrow) srbdqp_ragged();
+    if (!r) { g_ragged_err = "out of host memory"; return SRBDQP_E_NOMEM; }
+    r->device = cfg->device;
+    auto fail = [&](int rc, const std::string& what) { g_ragged_err = what; srbdqp_ragged_destroy(r); return rc; };
+    for (int i = 0; i < n_horizons; ++i) {
+        for (int j = 0; j < i; ++j) if (horizons[j] == horizons[i]) return fail(SRBDQP_E_INVALID, "duplicate horizon");
+        srbdqp_config c = *cfg;
+        c.horizon = horizons[i];
+        c.kernel = SRBDQP_KERNEL_WRENCH;       // per-QP contact schedules are free: the general kernel at every horizon
+        srbdqp_handle* h = nullptr;
+        const int rc = srbdqp_create(&c, &h);
+        if (rc != SRBDQP_OK) return fail(rc, std::string("bucket engine: ") + srbdqp_last_error(nullptr));
+        r->hs.push_back(h);
+        r->horizons.push_back(horizons[i]);
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(SRBDQP_E_HIP, "hipEventCreate");
+        r->ev_out.push_back(ev);
+    }
+    if (hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming) != hipSuccess) return fail(SRBDQP_E_HIP, "hipEventCreate");
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return fail(SRBDQP_E_HIP, "hipStreamCreate");
+    *out = r;
+    return SRBDQP_OK;
+}
+
+int srbdqp_ragged_destroy(srbdqp_ragged* r) {
+    if (!r) return SRBDQP_OK;
+    (void)hipSetDevice(r->device);
+    for (auto* h : r->hs) srbdqp_destroy(h);
+    for (auto ev : r->ev_out) if (ev) (void)hipEventDestroy(ev);
+    if (r->ev_in) (void)hipEventDestroy(r->ev_in);
+    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    if (r->d_perm) (void)hipFree(r->d_perm);
+    if (r->d_off) (void)hipFree(r->d_off);
+    if (r->h_perm) (void)hipHostFree(r->h_perm);
+    if (r->h_off) (void)hipHostFree(r->h_off);
+    if (r->ws) (void)hipFree(r->ws);
+    delete r;
+    return SRBDQP_OK;
+}
+
+const char* srbdqp_ragged_last_error(const srbdqp_ragged* r) { return r ? r->err.c_str() : g_ragged_err.c_str(); }
+
+int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const double* x0, const double* x_ref,
+                                   const double* foot, const uint8_t* contact, double* u_out, double* x_out, int32_t* status,
+                                   int32_t* iters, void* stream) {
+    if (!r) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!N_per_qp || !x0 || !x_ref || !foot || !contact || !u_out))) { r->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    RAG_TRY(r, hipSetDevice(r->device));
+    hipStream_t sin = stream ? reinterpret_cast<hipStream_t>(stream) : r->stream;
+    const size_t nb = r->hs.size();
+    if ((size_t)B > r->cap) {   // (re)allocate the index arrays: the only point that waits, and only for earlier solves of this object
+        for (auto* h : r->hs) RAG_TRY(r, hipStreamSynchronize(h->stream));
+        RAG_TRY(r, hipStreamSynchronize(sin));
+        if (r->d_perm) (void)hipFree(r->d_perm);
+        if (r->d_off) (void)hipFree(r->d_off);
+        if (r->h_perm) (void)hipHostFree(r->h_perm);
+        if (r->h_off) (void)hipHostFree(r->h_off);
+        r->d_perm = r->d_off = r->h_perm = r->h_off = nullptr; r->cap = 0;
+        const size_t want = (size_t)B + (size_t)B / 4 + 64;
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_perm), want * 4));
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_off), want * 4));
+        RAG_TRY(r, hipHostMalloc(reinterpret_cast<void**>(&r->h_perm), want * 4, hipHostMallocDefault));
+        RAG_TRY(r, hipHostMalloc(reinterpret_cast<void**>(&r->h_off), want * 4, hipHostMallocDefault));
+        r->cap = want;
+        r->ev_in_pending = false;
+    }
+    if (r->ev_in_pending) RAG_TRY(r, hipEventSynchronize(r->ev_in));   // the previous call's index upload has left the pinned mirrors
+    // bucket permutation (counting sort by horizon) and the packed row offsets
+    std::vector<int> cnt(nb, 0), start(nb + 1, 0), which((size_t)B);
+    long long rows = 0;
+    for (int32_t b = 0; b < B; ++b) {
+        int k = -1;
+        for (size_t i = 0; i < nb; ++i) if (r->horizons[i] == N_per_qp[b]) { k = (int)i; break; }
+        if (k < 0) { r->err = "N_per_qp holds a horizon this object was not created for"; return SRBDQP_E_INVALID; }
+        which[(size_t)b] = k; ++cnt[(size_t)k];
+        if (rows > 2000000000LL) { r->err = "more than 2^31 horizon rows in one call"; return SRBDQP_E_INVALID; }
+        r->h_off[b] = (int32_t)rows;
+        rows += N_per_qp[b];
+    }
+    for (size_t i = 0; i < nb; ++i) start[i + 1] = start[i] + cnt[i];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int32_t b = 0; b < B; ++b) r->h_perm[fill[(size_t)which[(size_t)b]]++] = b;
+    RAG_TRY(r, hipMemcpyAsync(r->d_off, r->h_off, (size_t)B * 4, hipMemcpyHostToDevice, sin));
+    RAG_TRY(r, hipMemcpyAsync(r->d_perm, r->h_perm, (size_t)B * 4, hipMemcpyHostToDevice, sin));
+    RAG_TRY(r, hipEventRecord(r->ev_in, sin));
+    r->ev_in_pending = true;
+    // one launch per non-empty bucket, each on its engine's own stream behind the upload; the caller's stream then waits for all
+    for (size_t i = 0; i < nb; ++i) {
+        if (cnt[i] == 0) continue;
+        srbdqp_handle* bh = r->hs[i];
+        hipStream_t bs = bh->stream;
+        RAG_TRY(r, hipStreamWaitEvent(bs, r->ev_in, 0));
+        KArgs a;
+        std::memset(&a, 0, sizeof(a));
+        fill_args(bh->cfg, a);
+        a.x0 = x0; a.xref = x_ref; a.foot = foot; a.contact = contact;
+        a.u_out = u_out; a.x_out = x_out; a.status = status; a.iters = iters;
+        a.perm = r->d_perm + start[i]; a.row_off = r->d_off;
+        a.B = cnt[i]; a.mode = 0;
+        const int rc = ragged_launch_bucket(bh, a, bs);
+        if (rc != SRBDQP_OK) { r->err = std::string("bucket N=") + std::to_string(r->horizons[i]) + ": " + bh->err; return rc; }
+        RAG_TRY(r, hipEventRecord(r->ev_out[i], bs));
+        RAG_TRY(r, hipStreamWaitEvent(sin, r->ev_out[i], 0));
+    }
+    return SRBDQP_OK;
+}
+
+int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const double* x0, const double* x_ref,
+                            const double* foot, const uint8_t* contact, double* u_out, double* x_out, int32_t* status, int32_t* iters) {
+    if (!r) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!N_per_qp || !x0 || !x_ref || !foot || !contact || !u_out))) { r->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    RAG_TRY(r, hipSetDevice(r->device));
+    size_t rows = 0;
+    for (int32_t b = 0; b < B; ++b) { if (N_per_qp[b] < 1 || N_per_qp[b] > SRBDQP_MAX_HORIZON) { r->err = "bad horizon in N_per_qp"; return SRBDQP_E_INVALID; } rows += (size_t)N_per_qp[b]; }
+    const size_t b = (size_t)B;
+    Carver sz(nullptr);
+    double *dx0, *dxr, *dft, *du, *dx; uint8_t* dct; int32_t *dst, *dit;
+    auto carve = [&](Carver& c) {
+        dx0 = c.take<double>(b * 13); dxr = c.take<double>(rows * 13); dft = c.take<double>(rows * 12); dct = c.take<uint8_t>(rows * 4);
+        du = c.take<double>(rows * 12); dx = x_out ? c.take<double>((rows + b) * 13) : nullptr;
+        dst = c.take<int32_t>(b); dit = c.take<int32_t>(b);
+    };
+    carve(sz);
+    if (sz.off > r->ws_bytes) {
+        RAG_TRY(r, hipStreamSynchronize(r->stream));
+        if (r->ws) { (void)hipFree(r->ws); r->ws = nullptr; r->ws_bytes = 0; }
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->ws), sz.off + sz.off / 4));
+        r->ws_bytes = sz.off + sz.off / 4;
+    }
+    Carver cv(r->ws);
+    carve(cv);
+    hipStream_t st = r->stream;
+    RAG_TRY(r, hipMemcpyAsync(dx0, x0, b * 13 * 8, hipMemcpyHostToDevice, st));
+    RAG_TRY(r, hipMemcpyAsync(dxr, x_ref, rows * 13 * 8, hipMemcpyHostToDevice, st));
+    RAG_TRY(r, hipMemcpyAsync(dft, foot, rows * 12 * 8, hipMemcpyHostToDevice, st));
+    RAG_TRY(r, hipMemcpyAsync(dct, contact, rows * 4, hipMemcpyHostToDevice, st));
+    const int rc = srbdqp_solve_ragged_device_f64(r, B, N_per_qp, dx0, dxr, dft, dct, du, dx, dst, dit, st);
+    if (rc != SRBDQP_OK) return rc;
+    RAG_TRY(r, hipMemcpyAsync(u_out, du, rows * 12 * 8, hipMemcpyDeviceToHost, st));
+    if (x_out) RAG_TRY(r, hipMemcpyAsync(x_out, dx, (rows + b) * 13 * 8, hipMemcpyDeviceToHost, st));
+    if (status) RAG_TRY(r, hipMemcpyAsync(status, dst, b * 4, hipMemcpyDeviceToHost, st));
+    if (iters) RAG_TRY(r, hipMemcpyAsync(iters, dit, b * 4, hipMemcpyDeviceToHost, st));
+    RAG_TRY(r, hipStreamSynchronize(st));
+    return SRBDQP_OK;
+}
+
 // ---- the steps either side of the QP (include/srbdqp_cascade.h) --------------------------------------------------
 namespace {
 inline unsigned elementwise_grid(long long B) {

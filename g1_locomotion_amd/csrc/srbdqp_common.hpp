@@ -34,6 +34,8 @@ struct KArgs {
     double* l_out;           // [B][m]
     double* ub_out;          // [B][m]
     const int32_t* perm;     // optional dispatch order: workgroup i solves QP perm[i] (longest-first scheduling), or null
+    const int32_t* row_off;  // ragged batches (general kernel): first horizon row of QP b in the packed [sum N][.] arrays, or
+                             //   null (= b N); x_out of QP b then starts at row row_off[b] + b
     long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null
     double* ws;              // split mode: per-QP workspace between the set-up kernel and the ADMM kernel, or null
     // rho re-balancing (one OSQP-style restart of the QPs that reach the cap of the first pass, see srbdqp.hip)

@@ -239,16 +239,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     uint8_t* gstep = reinterpret_cast<uint8_t*>(sm + S::o_gs);
     const double* SQ = sm + S::o_sq;
     const double* CP = sm + S::o_cp;
-    const TIO* gwu = reinterpret_cast<const TIO*>(a.warm_u);
-    const TIO* gwy = reinterpret_cast<const TIO*>(a.warm_y);
+    const size_t row0 = a.row_off ? (size_t)a.row_off[b] : (size_t)b * N;   // first horizon row of this QP in the step-major arrays
+    const TIO* gwu = reinterpret_cast<const TIO*>(a.warm_u) + row0 * 12;
+    const TIO* gwy = reinterpret_cast<const TIO*>(a.warm_y) + row0 * 20;
 
     // ================= load (coalesced, one batch of loads) + linearise (a5) =================
     SRBDQP_STAMP(a, b, 0);
     {
         const TIO* gx0 = reinterpret_cast<const TIO*>(a.x0) + (size_t)b * 13;
-        const TIO* gxr = reinterpret_cast<const TIO*>(a.xref) + (size_t)b * N * 13;
-        const TIO* gft = reinterpret_cast<const TIO*>(a.foot) + (size_t)b * N * 12;
-        const uint8_t* gct = a.contact + (size_t)b * N * 4;
+        const TIO* gxr = reinterpret_cast<const TIO*>(a.xref) + row0 * 13;
+        const TIO* gft = reinterpret_cast<const TIO*>(a.foot) + row0 * 12;
+        const uint8_t* gct = a.contact + row0 * 4;
         constexpr int RX = (N * 13 + BT - 1) / BT, RF = (N * 12 + BT - 1) / BT;
         static_assert(N * 4 <= BT && N * 3 <= BT, "one thread per contact flag / pcom entry");
         const TIO* gpc = a.pcom ? reinterpret_cast<const TIO*>(a.pcom) + (size_t)b * N * 3 : gx0;
@@ -341,7 +342,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     if constexpr (MODE == 1) { if (na == 0) return; }   // assembly dump of an empty problem: all zeros (the host cleared the buffers)
     if (na == 0) {   // nothing to solve: all forces 0
         for (int c = t; c < n; c += BT) sm[S::o_xs + c] = 0.0;
-        if (a.y_out) for (int i = t; i < m; i += BT) reinterpret_cast<TIO*>(a.y_out)[(size_t)b * m + i] = TIO(0);
+        if (a.y_out) for (int i = t; i < m; i += BT) reinterpret_cast<TIO*>(a.y_out)[row0 * 20 + i] = TIO(0);
         if (t == 0) { if (a.status) a.status[b] = 1; if (a.iters) a.iters[b] = 0; }
         __syncthreads();
     } else {
@@ -436,7 +437,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     double px0 = 0.0, x_init = 0.0;
     if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0 (u space, swing variables 0)
         double* TF = sm + S::o_tf;
-        x_init = active_u ? (double)gwu[(size_t)b * n + uvar] / a.s : 0.0;
+        x_init = active_u ? (double)gwu[uvar] / a.s : 0.0;
         if (stepok) sm[S::o_x0c + uvar] = x_init;
         __syncthreads();
         for (int idx = t; idx < 6 * N; idx += BT) {   // per step: tau_j = J_j x_j (3), f_j = sum of contact forces (3)
@@ -627,7 +628,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     if constexpr (MODE == 1) { if (sm[S::o_misc] != 0.0) { if (t == 0) a.ub_out[(size_t)b * (N + 1) + N] = -1.0; return; } }
     if (sm[S::o_misc] != 0.0) {   // degenerate contact geometry: report, return zero forces
         for (int c = t; c < n; c += BT) sm[S::o_xs + c] = 0.0;
-        if (a.y_out) for (int i = t; i < m; i += BT) reinterpret_cast<TIO*>(a.y_out)[(size_t)b * m + i] = TIO(0);
+        if (a.y_out) for (int i = t; i < m; i += BT) reinterpret_cast<TIO*>(a.y_out)[row0 * 20 + i] = TIO(0);
         if (t == 0) { if (a.status) a.status[b] = -1; if (a.iters) a.iters[b] = 0; }
         __syncthreads();
     } else {
@@ -922,8 +923,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         };
         x = (R)x_init;
         R cpx = (R)(px0 + qv), spxA = R(0), spxB = R(0);             // c = P x + q = cpx - A' spx
-        yA = (rowA && a.warm_y) ? (R)gwy[(size_t)b * m + irowA] : R(0);
-        yB = (rowB && a.warm_y) ? (R)gwy[(size_t)b * m + irowB] : R(0);
+        yA = (rowA && a.warm_y) ? (R)gwy[irowA] : R(0);
+        yB = (rowB && a.warm_y) ? (R)gwy[irowB] : R(0);
         const R fz0 = bperm(x, cbase + 2);
         R axA = rowA ? fma(-mucA, fz0, x) : R(0), axB = rowB ? fma(-mu, fz0, -x) : R(0);
         R zA = rmin(rmax(axA, loA), hiA), zB = rmin(rmax(axB, loB), hiB);
@@ -1010,7 +1011,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     __syncthreads();
     if (stepok) sm[S::o_xs + uvar] = (double)x;
     if (a.y_out) {
-        TIO* yo = reinterpret_cast<TIO*>(a.y_out) + (size_t)b * m;
+        TIO* yo = reinterpret_cast<TIO*>(a.y_out) + row0 * 20;
         if (stepok) {
             const bool on = active_u;
             yo[irowA] = on ? (TIO)yA : TIO(0);
@@ -1030,7 +1031,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     {
         const double* uh = sm + S::o_xs;
         double* scratch = sm + S::o_scr;
-        TIO* uo = reinterpret_cast<TIO*>(a.u_out) + (size_t)b * n;
+        const size_t row0 = a.row_off ? (size_t)a.row_off[b] : (size_t)b * N;
+        TIO* uo = reinterpret_cast<TIO*>(a.u_out) + row0 * 12;
         for (int c = t; c < n; c += BT) uo[c] = (TIO)(a.s * uh[c]);
         if (a.x_out) {
             const double* x0 = sm + S::o_x0;
@@ -1059,7 +1061,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 scratch[idx] = v;
             }
             __syncthreads();
-            TIO* xo = reinterpret_cast<TIO*>(a.x_out) + (size_t)b * (N + 1) * 13;
+            TIO* xo = reinterpret_cast<TIO*>(a.x_out) + (row0 + (size_t)b) * 13;      // N + 1 rows per QP
             for (int idx = t; idx < 13 * (N + 1); idx += BT) {
                 const int k = idx / 13, comp = idx % 13;
                 double v;

@@ -253,34 +253,81 @@ class BatchMPC:
 
 
 class RaggedMPC:
-    """Mixed-horizon batches (BASELINE.json configs[4]): QPs are bucketed by horizon and every bucket is one kernel
-    launch on its own engine / HIP stream, so the buckets run concurrently.  Per-QP contact schedules are free."""
+    """Mixed-horizon batches (BASELINE.json configs[4]) over srbdqp_solve_ragged_*: QPs in any order, each with its own
+    horizon and contact schedule; the library sorts them into horizon buckets and launches every bucket on its own HIP
+    stream, all in flight together."""
 
-    def __init__(self, horizons=(8, 12, 16, 20), dt: float = 0.04, device: int = 0, **overrides):
-        self.engines = {int(N): BatchMPC(horizon=int(N), dt=dt, device=device, **overrides) for N in horizons}
+    def __init__(self, horizons=(8, 12, 16, 24), dt: float = 0.04, device: int = 0, **overrides):
+        lib = _lib.load()
+        cfg = _lib.default_config()
+        cfg.dt = float(dt)
+        cfg.device = int(device)
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown srbdqp_config field {k!r}")
+            setattr(cfg, k, type(getattr(cfg, k))(v))
+        self.horizons = tuple(int(h) for h in horizons)
+        hz = np.ascontiguousarray(self.horizons, dtype=np.int32)
+        self._lib = lib
+        self._h = C.c_void_p()
+        rc = lib.srbdqp_ragged_create(C.byref(cfg), _ptr(hz), len(hz), C.byref(self._h))
+        if rc != _lib.OK:
+            msg = lib.srbdqp_ragged_last_error(None)
+            self._h = C.c_void_p()
+            raise SrbdqpError(f"srbdqp_ragged_create failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            msg = self._lib.srbdqp_ragged_last_error(self._h)
+            raise SrbdqpError(f"srbdqp error {rc}: {msg.decode() if msg else '?'}")
+
+    def solve_packed(self, N_per_qp, x0, x_ref, foot, contact, want_x=True):
+        """Step-major packed host arrays (include/srbdqp.h): x0 (B,13), x_ref (sum N,13), foot (sum N,12), contact (sum N,4).
+        Returns dict(u (sum N,12), x (sum N + B,13), status (B,), iters (B,), off (B+1,) row offsets)."""
+        Nq = np.ascontiguousarray(N_per_qp, dtype=np.int32)
+        B, rows = Nq.size, int(Nq.sum())
+        x0 = _as(x0, np.float64, (B, NX), "x0")
+        x_ref = _as(x_ref, np.float64, (rows, NX), "x_ref")
+        foot = _as(foot, np.float64, (rows, NU), "foot")
+        contact = _as(np.asarray(contact) != 0, np.uint8, (rows, NC), "contact")
+        u = np.empty((rows, NU)); x = np.empty((rows + B, NX)) if want_x else None
+        status = np.empty(B, np.int32); iters = np.empty(B, np.int32)
+        self._check(self._lib.srbdqp_solve_ragged_f64(self._h, B, _ptr(Nq), _ptr(x0), _ptr(x_ref), _ptr(foot), _ptr(contact),
+                                                      _ptr(u), _ptr(x), _ptr(status), _ptr(iters)))
+        return dict(u=u, x=x, status=status, iters=iters, off=np.concatenate([[0], np.cumsum(Nq)]))
+
+    def solve_device(self, B, N_per_qp, x0, x_ref, foot, contact, u_out, x_out=0, status=0, iters=0, stream=0):
+        """Packed arrays resident in HBM (raw device addresses); N_per_qp is a HOST int32 array.  Does not synchronise."""
+        Nq = np.ascontiguousarray(N_per_qp, dtype=np.int32)
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        self._check(self._lib.srbdqp_solve_ragged_device_f64(self._h, int(B), _ptr(Nq), v(x0), v(x_ref), v(foot), v(contact), v(u_out),
+                                                             v(x_out), v(status), v(iters), v(stream)))
 
     def solve(self, problems):
-        """problems: sequence of dicts(x0 (13,), x_ref (N,13), foot (N,12), contact (N,4)[, pcom (N,3)]) with per-QP N.
+        """problems: sequence of dicts(x0 (13,), x_ref (N,13), foot (N,12), contact (N,4)) with per-QP N.
         Returns a list of dicts(u (N,12), x (N+1,13), status, iters) in the input order."""
-        buckets = {}
-        for i, pr in enumerate(problems):
-            N = int(np.asarray(pr["x_ref"]).shape[0])
-            if N not in self.engines:
-                raise ValueError(f"no engine for horizon {N} (have {sorted(self.engines)})")
-            buckets.setdefault(N, []).append(i)
-        out = [None] * len(problems)
-        for N, idx in buckets.items():
-            has_pcom = all("pcom" in problems[i] for i in idx)
-            res = self.engines[N].solve(np.stack([problems[i]["x0"] for i in idx]), np.stack([problems[i]["x_ref"] for i in idx]),
-                                        np.stack([problems[i]["foot"] for i in idx]), np.stack([problems[i]["contact"] for i in idx]),
-                                        pcom=np.stack([problems[i]["pcom"] for i in idx]) if has_pcom else None)
-            for j, i in enumerate(idx):
-                out[i] = dict(u=res["u"][j], x=res["x"][j], status=int(res["status"][j]), iters=int(res["iters"][j]))
-        return out
+        Nq = [int(np.asarray(pr["x_ref"]).shape[0]) for pr in problems]
+        for N in Nq:
+            if N not in self.horizons:
+                raise ValueError(f"no engine for horizon {N} (have {sorted(self.horizons)})")
+        if any("pcom" in pr for pr in problems):
+            raise ValueError("the ragged path takes the CoM horizon from x_ref (no separate pcom)")
+        res = self.solve_packed(Nq, np.stack([pr["x0"] for pr in problems]), np.concatenate([pr["x_ref"] for pr in problems]),
+                                np.concatenate([pr["foot"] for pr in problems]), np.concatenate([pr["contact"] for pr in problems]))
+        off = res["off"]
+        return [dict(u=res["u"][off[i]:off[i + 1]], x=res["x"][off[i] + i:off[i + 1] + i + 1], status=int(res["status"][i]),
+                     iters=int(res["iters"][i])) for i in range(len(problems))]
 
     def close(self):
-        for e in self.engines.values():
-            e.close()
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.srbdqp_ragged_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MPC:

@@ -187,6 +187,28 @@ int srbdqp_assemble_wrench_f64(srbdqp_handle* h, int32_t B,
                                const uint8_t* contact, const double* pcom,
                                double* T_out, double* q_out, double* blocks_out, double* goff_out);
 
+/* Ragged batches (BASELINE.json configs[4]: "Mixed horizon N in {8,12,16,24} with per-QP contact schedule (ragged batch,
+ * bucketed kernel launch)").  One object holds an engine per horizon; a call takes the QPs in ANY order with their horizon
+ * in N_per_qp[] (HOST array), sorts them into horizon buckets and launches every non-empty bucket on its own HIP stream --
+ * all buckets in flight together, no host blocking (the caller's stream is made to wait for them with events).  Step-major
+ * PACKED arrays: QP b owns rows [off_b, off_b + N_b) with off_b = sum of the horizons before it:
+ *   x0 [B][13]   x_ref [sum N][13]   foot [sum N][12]   contact [sum N][4]   u_out [sum N][12]   x_out [sum N + B][13]
+ *   (x_out of QP b starts at row off_b + b: N_b + 1 rows), status / iters [B] in the caller's QP order.
+ * Every bucket runs the general kernel (any per-QP contact schedule); cfg is the template of the per-horizon engines
+ * (horizon ignored, rho = 0 picks each horizon's own penalty).  No warm start and no rho restart on this path. */
+typedef struct srbdqp_ragged srbdqp_ragged;
+int srbdqp_ragged_create(const srbdqp_config* cfg, const int32_t* horizons, int32_t n_horizons, srbdqp_ragged** out);
+int srbdqp_ragged_destroy(srbdqp_ragged* r);
+const char* srbdqp_ragged_last_error(const srbdqp_ragged* r);   /* r may be NULL: last create() error */
+/* DEVICE buffers; enqueued behind `stream` (NULL = the object's own), returns without synchronising. */
+int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,
+                                   const double* x0, const double* x_ref, const double* foot, const uint8_t* contact,
+                                   double* u_out, double* x_out, int32_t* status, int32_t* iters, void* stream);
+/* HOST buffers (copies inside; returns with the results in place). */
+int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,
+                            const double* x0, const double* x_ref, const double* foot, const uint8_t* contact,
+                            double* u_out, double* x_out, int32_t* status, int32_t* iters);
+
 /* Longest-first scheduling hint for the DEVICE-buffer API only (the host-buffer and the staged calls ignore it):
  * `device_iters_prev` = the iters[] array (device memory, `length` entries) of the previous control step of the same
  * batch, or NULL to switch the hint off.  A solve of more than `length` QPs is dispatched in natural order.  Subsequent device

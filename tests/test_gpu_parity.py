@@ -157,27 +157,66 @@ def test_mpc_update_drop_in_path(torch_first, built_lib):
 
 
 def test_ragged_horizons_bucketed_launch(torch_first, built_lib):
-    """BASELINE.json configs[4] (fp64 subset): mixed horizons N in {8, 12, 16, 20}, per-QP random-phase single-support
-    schedule, one launch per horizon bucket; every QP against the oracle twin and the exact optimum."""
+    """BASELINE.json configs[4]: mixed horizons N in {8, 12, 16, 24}, per-QP contact schedules of every kind, one C-ABI call
+    (srbdqp_solve_ragged_f64: bucket permutation + one launch per horizon bucket, all in flight together); every QP against
+    the oracle twin and the exact optimum, in the caller's order."""
     from g1_locomotion_amd import RaggedMPC
     rng = np.random.default_rng(5)
     problems = []
-    for i in range(24):
-        N = int(rng.choice([8, 12, 16, 20]))
-        x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=900 + i, schedule="single"))
+    for i in range(40):
+        N = int(rng.choice([8, 12, 16, 24]))
+        x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=900 + i, schedule=str(rng.choice(["single", "mixed", "double"]))))
         problems.append(dict(x0=x0, x_ref=xr, foot=ft, contact=ct))
-    eng = RaggedMPC(horizons=(8, 12, 16, 20))
+    eng = RaggedMPC(horizons=(8, 12, 16, 24), rho_restart_iter=-1)
     res = eng.solve(problems)
+    res2 = eng.solve(problems[::-1])[::-1]            # another order, other buckets sizes per position: same answers
     eng.close()
-    for pr, r in zip(problems, res):
+    for pr, r, r2 in zip(problems, res, res2):
         p = orc.params_for(pr["x_ref"].shape[0])
         ref = orc.update(p, pr["x0"], pr["x_ref"], pr["foot"], pr["contact"])
         assert r["status"] == ref["status"] and abs(r["iters"] - ref["iters"]) <= p.check_every
         assert r["u"].shape == pr["foot"].shape and np.abs(r["u"] - ref["u"]).max() <= TOL_TWIN_N
-        assert np.abs(r["x"] - ref["x"]).max() <= 1e-5
+        assert r["x"].shape == (pr["foot"].shape[0] + 1, 13) and np.abs(r["x"] - ref["x"]).max() <= 1e-5
+        np.testing.assert_array_equal(r["u"], r2["u"])
         if ref["status"] == orc.STATUS_SOLVED:
             xs, _ = orc.solve_reference(p, ref["qp"])
             assert np.abs(r["u"].reshape(-1) - xs * p.force_scale).max() <= TOL_EXACT_N
+
+
+def test_ragged_device_call_does_not_block_and_buckets_overlap(torch_first, built_lib):
+    """The device-buffer ragged entry returns before the work is done (the caller's stream waits through events) and a
+    second call may follow at once; results equal the per-horizon engines' on the same QPs."""
+    torch = torch_first
+    from g1_locomotion_amd import RaggedMPC, BatchMPC, _lib
+    rng = np.random.default_rng(11)
+    hz = (8, 12, 16, 24)
+    Bq = 600
+    Nq = rng.choice(hz, Bq).astype(np.int32)
+    parts = [[a[0] for a in orc.synthetic_batch(1, int(N), seed=7000 + i, schedule="mixed")] for i, N in enumerate(Nq)]
+    x0 = np.stack([p[0] for p in parts]); xr = np.concatenate([p[1] for p in parts]); ft = np.concatenate([p[2] for p in parts]); ct = np.concatenate([p[3] for p in parts])
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(v).to(dev) for v in (x0, xr, ft, ct)]
+    rows = int(Nq.sum())
+    u = torch.zeros((rows, 12), dtype=torch.float64, device=dev); st = torch.zeros(Bq, dtype=torch.int32, device=dev); it = torch.zeros(Bq, dtype=torch.int32, device=dev)
+    eng = RaggedMPC(horizons=hz, rho_restart_iter=-1)
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        for _ in range(2):                              # back to back, nothing waited for in between
+            eng.solve_device(Bq, Nq, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(), status=st.data_ptr(),
+                             iters=it.data_ptr(), stream=s.cuda_stream)
+    s.synchronize()
+    eng.close()
+    u, st, it = u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(Nq)])
+    for N in hz:
+        idx = np.where(Nq == N)[0]
+        with BatchMPC(horizon=int(N), kernel=_lib.KERNEL_WRENCH, rho_restart_iter=-1) as one:
+            ref = one.solve(x0[idx], np.stack([xr[off[i]:off[i + 1]] for i in idx]), np.stack([ft[off[i]:off[i + 1]] for i in idx]),
+                            np.stack([ct[off[i]:off[i + 1]] for i in idx]))
+        np.testing.assert_array_equal(st[idx], ref["status"])
+        np.testing.assert_array_equal(it[idx], ref["iters"])
+        for j, i in enumerate(idx):
+            np.testing.assert_array_equal(u[off[i]:off[i + 1]], ref["u"][j])
 
 
 def test_schedule_hint_only_reorders_work(torch_first, built_lib):
