@@ -14,6 +14,8 @@ device pointers of HBM-resident buffers).  All compute happens in libsrbdqp.so o
 from __future__ import annotations
 
 import ctypes as C
+import time
+import warnings
 from typing import Optional, Sequence
 
 import numpy as np
@@ -333,10 +335,15 @@ class RaggedMPC:
 class MPC:
     """Drop-in for ``srbd_mpc.mpc.MPC`` on the hot path (run_simulation.py:169-170,73-82,96,103,106)."""
 
-    def __init__(self, dt: float = 0.04, horizon: int = 10, device: int = 0, warm_start: bool = False, **overrides):
+    def __init__(self, dt: float = 0.04, horizon: int = 10, device: int = 0, warm_start: bool = False, strict: bool = True,
+                 **overrides):
         """warm_start=True starts every solve from the previous plan and duals shifted by one step.  Off by default: on
         this problem it does not shorten the solve (the dual residual, not the starting point, sets the iteration
-        count -- DESIGN.md section 2) and the extra staging traffic costs ~13 us per call."""
+        count -- DESIGN.md section 2) and the extra staging traffic costs ~13 us per call.
+        strict=True (default): a solve that ends with a negative status (SRBDQP_NUMERICAL, SRBDQP_CONTACT_BOUND: the kernel
+        returned all-zero forces) raises SrbdqpError instead of handing zeros to the WBID step; a solve that stops at the
+        iteration cap (SRBDQP_MAX_ITER) returns its best iterate with a RuntimeWarning.  strict=False returns whatever came
+        back; ``status`` / ``iters`` / ``solve_time`` always hold the outcome of the last call."""
         self.dt = float(dt)
         self.HORIZON_LENGTH = int(horizon)
         self.g = -9.80665                       # ros_run_simulation.py:58
@@ -345,6 +352,8 @@ class MPC:
         self.x_ref_hor = np.zeros((self.HORIZON_LENGTH, NX))
         self.x_ref_hor[:, 12] = self.g
         self.warm_start = bool(warm_start)
+        self.strict = bool(strict)
+        self.solve_time = 0.0                   # seconds spent in the last solve() (the node's solve-time statistic)
         self._device = device
         self._overrides = overrides
         self._engine: Optional[BatchMPC] = None
@@ -381,9 +390,18 @@ class MPC:
         if use_pcom:
             st["pcom"][0] = np.asarray(p_com_horizon, dtype=np.float64).reshape(N, 3)
         use_warm = self.warm_start and self._warm
+        t0 = time.perf_counter()
         eng.solve_staged(1, use_pcom=use_pcom, use_warm=use_warm, want_x=True, want_y=self.warm_start)
+        self.solve_time = time.perf_counter() - t0
         self.status = int(st["status"][0])
         self.iters = int(st["iters"][0])
+        if self.strict and self.status < 0:
+            self._warm = False
+            raise SrbdqpError(f"MPC solve failed with status {self.status} "
+                              f"({'non-finite inputs or a singular contact geometry' if self.status == _lib.NUMERICAL else 'more stance contacts in a step than max_contacts_per_step'}); "
+                              "the kernel returned zero forces")
+        if self.strict and self.status == _lib.MAX_ITER:
+            warnings.warn(f"MPC solve stopped at the iteration cap ({self.iters} iterations): best iterate returned", RuntimeWarning, stacklevel=3)
         self.u_opt = st["u"][0].copy()
         self.x_opt = st["x"][0].copy()
         if self.warm_start and self.status in (_lib.SOLVED, _lib.MAX_ITER):

@@ -16,6 +16,7 @@ own minimal stand-in (fixed-period alternating single support, Raibert-style lan
 """
 from __future__ import annotations
 
+import time
 from dataclasses import dataclass, field
 from typing import List
 
@@ -128,6 +129,9 @@ class MpcNode:
 
     def __init__(self, mpc, gait: AlternatingGait, com_target, v_ref=(0.0, 0.0), hip_offset_y=0.0645):
         self.mpc, self.gait = mpc, gait
+        # what the reference node publishes on /mpc_statistics (index 4 is plotted as the solve time,
+        # g1_mujoco_sim/config/MPC_QP_layout.xml:258-259): outcome and wall time of the last step()
+        self.statistics = {"solve_time": 0.0, "status": 0, "iters": 0}
         self.com_target = np.asarray(com_target, dtype=np.float64)
         self.v_ref = np.asarray(v_ref, dtype=np.float64)
         self.hip_offset_y = hip_offset_y
@@ -151,7 +155,10 @@ class MpcNode:
         # lever arms r_i = c_i - p_com: linearise about the MEASURED CoM (plus the commanded drift), not about the target --
         # with the torso-only inertia of wbid.py:261-266 a 1 cm CoM offset is a 40 rad/s^2 modelling error otherwise
         p_com_horizon = x0[3:6][None, :] + np.concatenate([self.v_ref, [0.0]])[None, :] * (k[:, None] - 1) * mpc.dt
+        t0 = time.perf_counter()
         u_opt0, x_opt1 = mpc.update(list(contact_horizon), c_horizon, p_com_horizon, x_current=mpc.x0, one_rollout=True)
+        self.statistics = {"solve_time": float(getattr(mpc, "solve_time", 0.0)) or (time.perf_counter() - t0),
+                           "status": int(getattr(mpc, "status", 0)), "iters": int(getattr(mpc, "iters", 0))}
         out = SRBDState(stamp=msg.stamp)
         out.states_horizon = [vec_to_state(x_opt1[i], i) for i in range(x_opt1.shape[0])]
         u = np.asarray(u_opt0, dtype=np.float64).reshape(-1)

@@ -73,3 +73,24 @@ def test_wbid_reference_first_principles():
     assert np.abs(a_w - (np.array([u[0:4].sum(), u[4:8].sum(), u[8:12].sum()]) / mass + [0, 0, -9.80665])).max() < 1e-12
     assert np.abs(a_c - (u.reshape(4, 3).sum(0) / mass + [0, 0, -9.80665])).max() < 1e-12
     assert abs((a_w - a_c).sum()) < 1e-10 and np.abs(a_w - a_c).max() > 1e-3
+
+
+def test_swing_drop_in_scalar_getters_run_on_the_host_from_cached_coefficients(gold):
+    """The class the simulator calls ~3 x per 1 ms step (ros_run_simulation.py:246-256): its scalar getters are host
+    arithmetic on the coefficients cached by calculate_coeff() -- no GPU, no engine -- and reproduce the reference's outputs."""
+    from g1_locomotion_amd import swing_trajectory
+    s = swing_trajectory.SwingTrajectory(engine=None)
+    idx = np.linspace(0, gold["progress"].shape[0] - 1, 60).astype(int)
+    for i in idx:
+        ps, pf, zm, t = gold["p_start"][i], gold["p_final"][i], float(gold["z_middle"][i]), float(gold["progress"][i])
+        s.reset()
+        s.set_positions_xy(ps[0], pf[0], ps[1], pf[1]); s.set_positions_z(ps[2], zm, pf[2]); s.calculate_coeff()
+        assert np.abs(s.coeff - gold["coeff"][i]).max() < 1e-11
+        x, y = s.calculate_position_xy(t)
+        assert abs(x - gold["pos"][i, 0]) < TOL_SWING and abs(y - gold["pos"][i, 1]) < TOL_SWING
+        assert abs(s.calculate_position_z(t) - gold["pos"][i, 2]) < TOL_SWING
+        assert abs(s.calculate_velocity_z(t) - gold["vel_z"][i]) < TOL_SWING and abs(s.calculate_acceleration_z(t) - gold["acc_z"][i]) < 1e-11
+    # stale coefficients are used until calculate_coeff() is called again, as in the reference
+    z_before = s.calculate_position_z(0.3)
+    s.set_positions_z(0.5, 0.9, 0.5)
+    assert s.calculate_position_z(0.3) == z_before

@@ -70,4 +70,9 @@ def test_closed_loop_gpu_engine_stands_and_steps():
     assert np.abs(log[-1, 3:6] - COM).max() < 0.03 and np.abs(log[-1, 0:3]).max() < 0.05
     log2 = _run(MPC, steps=25, standing=False)                 # alternating single support in place: must not fall
     assert log2[:, 5].min() > 0.45 and np.abs(log2[:, 0:2]).max() < 0.5
+    # the same two closed loops with the CPU oracle behind the same adapter: the trajectories agree step for step (forces
+    # agree to 2e-3 N per solve; the plant integrates 40 ms of them between solves)
+    ref = _run(OracleMPC(), steps=50, standing=True, push=(5, np.array([0.15, 0.1, 0.0])))
+    ref2 = _run(OracleMPC(), steps=25, standing=False)
+    assert np.abs(log - ref).max() < 1e-4 and np.abs(log2 - ref2).max() < 1e-4, (np.abs(log - ref).max(), np.abs(log2 - ref2).max())
     MPC.close()
