@@ -1,12 +1,12 @@
 """Diagnostic: per-phase time of the v1 kernel from in-kernel s_memtime stamps (100 MHz), batch-1 and full batch."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
 import ctypes as C
 import numpy as np
 import torch
 from g1_locomotion_amd import BatchMPC
-import srbd_oracle as orc
+from g1_locomotion_amd import synth as orc
 
 names = ["linearise", "tables", "gradient", "K assembly", "barrier", "F(chol)", "W", "I", "frag", "ADMM", "rollout"]
 for B in (1, 4096):
