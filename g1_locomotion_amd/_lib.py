@@ -21,6 +21,8 @@ SOLVED, MAX_ITER, NUMERICAL, CONTACT_BOUND = 1, 2, -1, -2
 FLAG_TIMING = 1
 FLAG_NO_SPIN = 2
 FLAG_SETUP4 = 4
+FLAG_F64_TILES = 8     # _f32 calls: fp64 tiles for every QP
+FLAG_F32_TILES = 16    # _f32 calls: fp32 tiles for the eligible QPs of small batches too
 KERNEL_AUTO, KERNEL_COMPACT, KERNEL_SPLIT, KERNEL_WAVE, KERNEL_WRENCH = 0, 3, 4, 5, 6   # 1, 2: the retired round-1 baselines
 
 EXPORTS = (

@@ -165,6 +165,10 @@ constexpr int kSplitMinBatch = 512;
 // gait 10.4 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
 constexpr int kWrenchMinBatch = 256;
 
+// fp32 calls of at least this many QPs are split by tile precision (two launches + the classification kernel); smaller
+// ones run on fp64 tiles, where the third workgroup per CU would stay empty anyway.
+constexpr int kTileClassMinBatch = 512;
+
 // does a solve of B QPs on this handle go to the general kernel (srbdqp_wrench.hpp)?  launch() / launch_long() ask this.
 inline bool uses_wrench(const srbdqp_handle* h, int maxs, int B) {
     const int N = h->cfg.horizon;
@@ -256,11 +260,15 @@ int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
 }
 
 // The general kernel (srbdqp_wrench.hpp): any contact pattern, fp64 or fp32 iterations / buffers.
-template <int N, typename R>
+template <int N, typename R, int TB = 8>
 struct WrenchTraits {
-    using S = srbdqp::WrenchSmem<N>;
+    using S = srbdqp::WrenchSmem<N, TB>;
     static constexpr int by_lds = (S::lds_wgs * S::NW) / 4 > 0 ? (S::lds_wgs * S::NW) / 4 : 1;   // waves per SIMD LDS admits
+#ifdef SRBDQP_F32TILE_WPS   // experiments: waves per SIMD the fp32-tile instantiation is compiled for
+    static constexpr int want = (TB == 4) ? SRBDQP_F32TILE_WPS : ((sizeof(R) == 4) ? 3 : (S::CHMAX <= 36 ? 2 : 1));
+#else
     static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 36 ? 2 : 1);                  // register budget
+#endif
     static constexpr int wps = by_lds < want ? by_lds : want;
 };
 
@@ -282,6 +290,26 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
         int rc = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>, lds);
         if (rc != SRBDQP_OK) return rc;
         h->kname = nm.c_str();
+        if constexpr (sizeof(R) == 4) {
+            // fp32 iterations: QPs whose steps all have 0 or >= 3 stance contacts (every g coordinate a wrench coordinate,
+            // cond(T) ~ 5e4) factor T in fp32 tiles -- half the LDS, one more workgroup per CU; a step kept in force
+            // variables carries the conditioning of K (1e8) into T and needs fp64 tiles.  Two launches over the same grid,
+            // each workgroup looks at its QP's contact flags and leaves at once if the QP belongs to the other launch.
+            // Not on the staged path (its workgroups are counted), not in the restart pass (few QPs), not for ragged batches.
+            if (!a.done_flag && !a.count_ptr && !a.row_off && !a.stamps && !(h->cfg.flags & SRBDQP_FLAG_F64_TILES) && (a.B >= kTileClassMinBatch || (h->cfg.flags & SRBDQP_FLAG_F32_TILES))) {
+                using S4 = srbdqp::WrenchSmem<N, 4>;
+                constexpr int WPS4 = WrenchTraits<N, R, 4>::wps;
+                constexpr size_t lds4 = S4::bytes;
+                rc = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS4, float>, lds4);
+                if (rc != SRBDQP_OK) return rc;
+                KArgs a4 = a, a8 = a;
+                a4.tile_sel = 1; a8.tile_sel = 2;
+                hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS4, float>), dim3((unsigned)a.B), dim3(S::BT), lds4, st, a4);
+                hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>), dim3((unsigned)a.B), dim3(S::BT), lds, st, a8);
+                HIP_TRY(h, hipGetLastError());
+                return SRBDQP_OK;
+            }
+        }
         hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>), dim3((unsigned)a.B), dim3(S::BT), lds, st, a);
     }
     HIP_TRY(h, hipGetLastError());

@@ -34,6 +34,8 @@ struct KArgs {
     double* l_out;           // [B][m]
     double* ub_out;          // [B][m]
     const int32_t* perm;     // optional dispatch order: workgroup i solves QP perm[i] (longest-first scheduling), or null
+    int tile_sel;            // general kernel, fp32 calls: 0 = every QP; 1 = only QPs whose steps all have 0 or >= 3 stance
+                             //   contacts (the fp32-tile launch); 2 = only the others (the fp64-tile launch)
     const int32_t* row_off;  // ragged batches (general kernel): first horizon row of QP b in the packed [sum N][.] arrays, or
                              //   null (= b N); x_out of QP b then starts at row row_off[b] + b
     long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null

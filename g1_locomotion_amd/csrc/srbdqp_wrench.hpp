@@ -39,7 +39,7 @@ namespace srbdqp {
 #define SRBDQP_PHASE_LOCAL(...) asm volatile("" : __VA_ARGS__)
 #endif
 
-template <int N>
+template <int N, int TB = 8>   // TB = bytes per tile element: 8 (fp64 tiles) or 4 (fp32 tiles, double-support QPs of the fp32 path)
 struct WrenchSmem {
     static constexpr int n = 12 * N, m = 20 * N;
     static constexpr int NW = (N + 4) / 5;                // waves per QP: 5 steps of 12 lanes per wave
@@ -82,7 +82,8 @@ struct WrenchSmem {
     static constexpr int endA = o_gs + up2((NG + 7) / 8);
     // ---- phase B (tiles)
     static constexpr int o_T = o_R;
-    static constexpr int endB = o_T + NTT * 256;
+    static constexpr int o_ws = o_T + NTT * 256 * TB / 8;   // fp32 tiles: one 16 x 16 scratch tile per wave (operand re-layout)
+    static constexpr int endB = o_ws + (TB == 4 ? NW * 128 : 0);
     // ---- phase C (ADMM vectors; element type R <= 8 bytes, offsets in doubles)
     static constexpr int VB = 2 * CHMAX + 8;              // one v buffer (elements)
     static constexpr int o_wb = o_R;                      // NW x 64   right-hand sides, wave private
@@ -109,6 +110,28 @@ __device__ __forceinline__ double rmax(double a, double b) { return fmax(a, b); 
 __device__ __forceinline__ float rabs(float a) { return fabsf(a); }
 __device__ __forceinline__ double rabs(double a) { return fabs(a); }
 
+// a wave-uniform value, moved to scalar registers (the float constants of the iteration are converted from doubles by the
+// vector ALU and would otherwise each hold a vector register for the whole loop)
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uni(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4d mma16(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ v4f mma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// row of accumulator register q in the MFMA C/D layout: fp64 16x16x4: (lane >> 4) + 4 q; fp32 16x16x4: 4 (lane >> 4) + q
+template <typename TT> __device__ __forceinline__ int crow(int kq, int q) { return (sizeof(TT) == 8) ? kq + 4 * q : 4 * kq + q; }
+template <typename TT, bool SWZ, typename V4>
+__device__ __forceinline__ void store_tile_t(TT* tile, const V4& v, int lane) {
+    const int col = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = crow<TT>(g, q);
+        tile[row * 16 + (SWZ ? (col ^ row) : col)] = v[q];
+    }
+}
+
 // workgroup-wide max of one non-negative value (NW waves); two barriers
 template <int NW>
 __device__ __forceinline__ double wg_max1(double v, double* red) {
@@ -129,9 +152,9 @@ __device__ __forceinline__ double wg_max1(double v, double* red) {
 // Used once in fp64 for x_q and every iteration in R.  `vb` is the v buffer to publish into; a workgroup barrier sits
 // between the publication of v and its use.  hook() runs right after that barrier (the ADMM loop reads the convergence
 // decision there).
-template <typename R, int CHMAX, class Hook>
+template <typename R, int CHMAX, typename KT, class Hook>
 __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, int sg, int ul, bool active_g, int Rrow, int CH,
-                                        const R (&kin)[CHMAX], const R (&vrow)[6], const R (&vcol)[6], const R (&bdrow)[12], Hook&& hook) {
+                                        const KT (&kin)[CHMAX], const R (&vrow)[6], const R (&vcol)[6], const R (&bdrow)[12], Hook&& hook) {
     typedef R R4 __attribute__((ext_vector_type(4)));
     typedef R R2 __attribute__((ext_vector_type(2)));
     const int h = ul & 1;
@@ -171,16 +194,16 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
 #pragma unroll
                 for (int c = 0; c < CHMAX / 4; ++c) {
                     const R4 vv = s4[c];
-                    acc0 = fma(kin[4 * c], vv[0], acc0); acc1 = fma(kin[4 * c + 1], vv[1], acc1);
-                    acc2 = fma(kin[4 * c + 2], vv[2], acc2); acc3 = fma(kin[4 * c + 3], vv[3], acc3);
+                    acc0 = fma((R)kin[4 * c], vv[0], acc0); acc1 = fma((R)kin[4 * c + 1], vv[1], acc1);
+                    acc2 = fma((R)kin[4 * c + 2], vv[2], acc2); acc3 = fma((R)kin[4 * c + 3], vv[3], acc3);
                 }
             } else {
                 const R2* s2 = reinterpret_cast<const R2*>(src);
 #pragma unroll
                 for (int c = 0; c < CHMAX / 2; ++c) {
                     const R2 vv = s2[c];
-                    if (c & 1) { acc2 = fma(kin[2 * c], vv[0], acc2); acc3 = fma(kin[2 * c + 1], vv[1], acc3); }
-                    else { acc0 = fma(kin[2 * c], vv[0], acc0); acc1 = fma(kin[2 * c + 1], vv[1], acc1); }
+                    if (c & 1) { acc2 = fma((R)kin[2 * c], vv[0], acc2); acc3 = fma((R)kin[2 * c + 1], vv[1], acc3); }
+                    else { acc0 = fma((R)kin[2 * c], vv[0], acc0); acc1 = fma((R)kin[2 * c + 1], vv[1], acc1); }
                 }
             }
         } else {
@@ -196,8 +219,8 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
                     for (int i = 0; i < BL; ++i) {
                         const int c0 = 2 * (blk * BL + i);
                         if (c0 + 1 < CHMAX) {
-                            if (i & 1) { acc2 = fma(kin[c0], vv[i][0], acc2); acc3 = fma(kin[c0 + 1], vv[i][1], acc3); }
-                            else { acc0 = fma(kin[c0], vv[i][0], acc0); acc1 = fma(kin[c0 + 1], vv[i][1], acc1); }
+                            if (i & 1) { acc2 = fma((R)kin[c0], vv[i][0], acc2); acc3 = fma((R)kin[c0 + 1], vv[i][1], acc3); }
+                            else { acc0 = fma((R)kin[c0], vv[i][0], acc0); acc1 = fma((R)kin[c0 + 1], vv[i][1], acc1); }
                         }
                     }
                 }
@@ -220,9 +243,11 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
 }
 
 // One QP (index b) on one workgroup of NW waves.  TIO = element type of the caller's buffers, R = iteration type.
-template <int N, typename R, typename TIO, int MODE>
+template <int N, typename R, typename TIO, int MODE, typename TT = double>
 __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* sm) {
-    using S = WrenchSmem<N>;
+    using S = WrenchSmem<N, (int)sizeof(TT)>;
+    typedef TT v4t __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(TT) == 8 || (sizeof(R) == 4 && MODE == 0), "fp32 tiles belong to the fp32 path");
     constexpr int n = S::n, m = S::m, NW = S::NW, BT = S::BT, TS = S::TS, CHMAX = S::CHMAX;
     static_assert((S::o_R % 2) == 0 && (S::o_wb % 2) == 0 && (S::o_tb % 2) == 0 && (S::o_vb % 2) == 0, "16-byte alignment");
     static_assert(S::NT <= 2 * NW || S::WQ >= 1, "");
@@ -230,7 +255,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     int mcol = lane & 15, kq = lane >> 4;
-    double* T = sm + S::o_T;
+    TT* T = reinterpret_cast<TT*>(sm + S::o_T);
     int* igsz = reinterpret_cast<int*>(sm + S::o_int);            // gsz[N]
     int* igoff = igsz + N;                                        // goff[N + 1]
     int* imisc = igoff + N + 1;                                   // [0] n_g, [1] na
@@ -434,12 +459,9 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         return;
     }
 #endif
-    double px0 = 0.0, x_init = 0.0;
-    if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0 (u space, swing variables 0)
+    // G'(G x) for the vector x at o_x0c (u space, swing variables 0; visible to the workgroup on entry): this lane's entry
+    auto gtg_of_x0c = [&]() -> double {
         double* TF = sm + S::o_tf;
-        x_init = active_u ? (double)gwu[uvar] / a.s : 0.0;
-        if (stepok) sm[S::o_x0c + uvar] = x_init;
-        __syncthreads();
         for (int idx = t; idx < 6 * N; idx += BT) {   // per step: tau_j = J_j x_j (3), f_j = sum of contact forces (3)
             const int j = idx / 6, comp = idx - 6 * j;
             const double* x = sm + S::o_x0c + 12 * j;
@@ -479,7 +501,15 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         __syncthreads();
         gt_tables(sm + S::o_gx);
         __syncthreads();
-        px0 = active_u ? gt_eval_u() + a.rs2 * x_init : 0.0;
+        return active_u ? gt_eval_u() : 0.0;
+    };
+    double px0 = 0.0, x_init = 0.0;
+    if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0
+        x_init = active_u ? (double)gwu[uvar] / a.s : 0.0;
+        if (stepok) sm[S::o_x0c + uvar] = x_init;
+        __syncthreads();
+        const double gtg = gtg_of_x0c();
+        px0 = active_u ? gtg + a.rs2 * x_init : 0.0;
     }
 
     // ================= per-step wrench blocks: E^-1, V, Bd (registers of the step's lanes) =================
@@ -646,18 +676,18 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         tb[s] = (id < NTT) ? bb : -1;
         ta[s] = (id < NTT) ? id - (bb * (bb + 1)) / 2 : -1;
     }
-    v4d acc[TS];
+    v4t acc[TS];
     {
         const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
         const double* ZT = sm + S::o_zt;
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
-            acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
             if (ta[s] >= 0) {
                 const int c = 16 * tb[s] + mcol;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int r = 16 * ta[s] + kq + 4 * q;
+                    const int r = 16 * ta[s] + crow<TT>(kq, q);
                     const bool in = (r < n_g) && (c < n_g);
                     const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;
                     const int j = gstep[lo], mm = gstep[hi];
@@ -683,7 +713,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                     }
                     double val = s2 * v;
                     if (j == mm) val += sm[S::o_ei + 36 * j + 6 * l1 + l2];
-                    acc[s][q] = in ? val : ((r == c) ? 1.0 : 0.0);               // padding -> identity
+                    acc[s][q] = (TT)(in ? val : ((r == c) ? 1.0 : 0.0));         // padding -> identity
                 }
             }
         }
@@ -722,19 +752,34 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // ================= phase F: tiled right-looking Cholesky T = U'U, trailing tiles in registers =================
     SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
     for (int j = 0; j < NT; ++j) {
-        double* Djj = T + tile_id(j, j) * 256;
+        TT* Djj = T + tile_id(j, j) * 256;
         {
             bool mine = false;
-            v4d d = acc[0];
+            v4t d = acc[0];
 #pragma unroll
             for (int s = 0; s < TS; ++s)
                 if (ta[s] == j && tb[s] == j) { mine = true; d = acc[s]; }
             if (mine) {
                 int lane_j = lane;
                 SRBDQP_PHASE_LOCAL("+v"(lane_j));
+                v4d dd;
+                if constexpr (sizeof(TT) == 8) {
+                    dd = d;
+                } else {   // fp32 accumulator layout -> the fp64 one, through the wave's scratch tile; the 16 x 16 inverse is fp64
+                    float* wsx = reinterpret_cast<float*>(sm + S::o_ws) + 256 * w;
+                    store_tile_t<float, false>(wsx, d, lane_j);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: its LDS operations complete in order
+                    const int cj = lane_j & 15, gj = lane_j >> 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dd[q] = (double)wsx[(gj + 4 * q) * 16 + cj];
+                }
                 bool ok;
-                const v4d winv = diag16_invert_mfma(d, lane_j, ok);
-                store_tile<true>(Djj, winv, lane_j);
+                const v4d winv = diag16_invert_mfma(dd, lane_j, ok);
+                {
+                    const int cj = lane_j & 15, gj = lane_j >> 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int row = gj + 4 * q; Djj[row * 16 + (cj ^ row)] = (TT)winv[q]; }
+                }
                 if (!ok && lane == 0) sm[S::o_misc] = 1.0;
             }
         }
@@ -742,28 +787,28 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             if (ta[s] == j && tb[s] > j) {
-                v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
+                v4t o = (v4t){TT(0), TT(0), TT(0), TT(0)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int k = 4 * r + kq;
-                    double av = Djj[mcol * 16 + (k ^ mcol)];
-                    av = (k <= mcol) ? av : 0.0;
-                    o = mfma_f64(av, acc[s][r], o);
+                    const int k = crow<TT>(kq, r);           // accumulator register r = the B operand of this k index
+                    TT av = Djj[mcol * 16 + (k ^ mcol)];
+                    av = (k <= mcol) ? av : TT(0);
+                    o = mma16(av, acc[s][r], o);
                 }
                 acc[s] = o;
-                store_tile<false>(T + tile_id(j, tb[s]) * 256, o, lane);
+                store_tile_t<TT, false>(T + tile_id(j, tb[s]) * 256, o, lane);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             if (ta[s] > j) {
-                const double* Ua = T + tile_id(j, ta[s]) * 256;
-                const double* Ub = T + tile_id(j, tb[s]) * 256;
+                const TT* Ua = T + tile_id(j, ta[s]) * 256;
+                const TT* Ub = T + tile_id(j, tb[s]) * 256;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = 4 * r + kq;
-                    acc[s] = mfma_f64(-Ua[k * 16 + mcol], Ub[k * 16 + mcol], acc[s]);
+                    acc[s] = mma16(-Ua[k * 16 + mcol], Ub[k * 16 + mcol], acc[s]);
                 }
             }
         }
@@ -774,41 +819,41 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // ================= phase W: W = L^-1 block row by block row, in place over U =================
     SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
     for (int i = 1; i < NT; ++i) {
-        v4d res[S::WQ];
-        const double* Dii = T + tile_id(i, i) * 256;
+        v4t res[S::WQ];
+        const TT* Dii = T + tile_id(i, i) * 256;
 #pragma unroll
         for (int q = 0; q < S::WQ; ++q) {
             const int j = w + NW * q;
-            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+            res[q] = (v4t){TT(0), TT(0), TT(0), TT(0)};
             if (j < i) {
-                v4d o = (v4d){0.0, 0.0, 0.0, 0.0};
+                v4t o = (v4t){TT(0), TT(0), TT(0), TT(0)};
                 {
-                    const double* Uji = T + tile_id(j, i) * 256;
-                    const double* Djj = T + tile_id(j, j) * 256;
+                    const TT* Uji = T + tile_id(j, i) * 256;
+                    const TT* Djj = T + tile_id(j, j) * 256;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int k = 4 * r + kq;
-                        double bv = Djj[k * 16 + (mcol ^ k)];
-                        bv = (mcol <= k) ? bv : 0.0;
-                        o = mfma_f64(Uji[k * 16 + mcol], bv, o);
+                        TT bv = Djj[k * 16 + (mcol ^ k)];
+                        bv = (mcol <= k) ? bv : TT(0);
+                        o = mma16(Uji[k * 16 + mcol], bv, o);
                     }
                 }
                 for (int k2 = j + 1; k2 < i; ++k2) {
-                    const double* Uki = T + tile_id(k2, i) * 256;
-                    const double* Wkj = T + tile_id(j, k2) * 256;
+                    const TT* Uki = T + tile_id(k2, i) * 256;
+                    const TT* Wkj = T + tile_id(j, k2) * 256;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int k = 4 * r + kq;
-                        o = mfma_f64(Uki[k * 16 + mcol], Wkj[k * 16 + mcol], o);
+                        o = mma16(Uki[k * 16 + mcol], Wkj[k * 16 + mcol], o);
                     }
                 }
-                v4d o2 = (v4d){0.0, 0.0, 0.0, 0.0};
+                v4t o2 = (v4t){TT(0), TT(0), TT(0), TT(0)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int k = 4 * r + kq;
-                    double av = Dii[mcol * 16 + (k ^ mcol)];
-                    av = (k <= mcol) ? -av : 0.0;
-                    o2 = mfma_f64(av, o[r], o2);
+                    const int k = crow<TT>(kq, r);
+                    TT av = Dii[mcol * 16 + (k ^ mcol)];
+                    av = (k <= mcol) ? -av : TT(0);
+                    o2 = mma16(av, o[r], o2);
                 }
                 res[q] = o2;
             }
@@ -817,7 +862,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
         for (int q = 0; q < S::WQ; ++q) {
             const int j = w + NW * q;
-            if (j < i) store_tile<false>(T + tile_id(j, i) * 256, res[q], lane);
+            if (j < i) store_tile_t<TT, false>(T + tile_id(j, i) * 256, res[q], lane);
         }
         __syncthreads();
     }
@@ -827,28 +872,28 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
-        acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
         if (ta[s] >= 0) {
             const int ia = ta[s], ib = tb[s];
-            const double* Dbb = T + tile_id(ib, ib) * 256;
+            const TT* Dbb = T + tile_id(ib, ib) * 256;
             {
-                const double* Wba = T + tile_id(ia, ib) * 256;
+                const TT* Wba = T + tile_id(ia, ib) * 256;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = 4 * r + kq;
-                    double dv = Dbb[k * 16 + (mcol ^ k)];
-                    dv = (mcol <= k) ? dv : 0.0;
-                    const double av = (ia < ib) ? Wba[k * 16 + mcol] : dv;
-                    acc[s] = mfma_f64(av, dv, acc[s]);
+                    TT dv = Dbb[k * 16 + (mcol ^ k)];
+                    dv = (mcol <= k) ? dv : TT(0);
+                    const TT av = (ia < ib) ? Wba[k * 16 + mcol] : dv;
+                    acc[s] = mma16(av, dv, acc[s]);
                 }
             }
             for (int i = ib + 1; i < NT; ++i) {
-                const double* Wia = T + tile_id(ia, i) * 256;
-                const double* Wib = T + tile_id(ib, i) * 256;
+                const TT* Wia = T + tile_id(ia, i) * 256;
+                const TT* Wib = T + tile_id(ib, i) * 256;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = 4 * r + kq;
-                    acc[s] = mfma_f64(Wia[k * 16 + mcol], Wib[k * 16 + mcol], acc[s]);
+                    acc[s] = mma16(Wia[k * 16 + mcol], Wib[k * 16 + mcol], acc[s]);
                 }
             }
         }
@@ -856,13 +901,13 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < TS; ++s)
-        if (ta[s] >= 0) store_tile<true>(T + tile_id(ta[s], tb[s]) * 256, acc[s], lane);
+        if (ta[s] >= 0) store_tile_t<TT, true>(T + tile_id(ta[s], tb[s]) * 256, acc[s], lane);
     __syncthreads();
     SRBDQP_STAMP(a, b, 6);
 
-    // ================= half rows of T^-1 (fp64), then x_q = -K^-1 q in fp64 =================
+    // ================= half rows of T^-1 (in the tiles' type), then x_q = -K^-1 q accumulated in fp64 =================
     const int CH = 2 * ((n_g + 3) / 4);
-    double kin64[CHMAX];
+    TT kin64[CHMAX];
     {
         const int rr = active_g ? Rrow : 0;
 #pragma unroll
@@ -872,8 +917,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             const int cs = ok ? c : 0;
             const int lo = (rr <= cs) ? rr : cs, hi = (rr <= cs) ? cs : rr;
             const int row = lo & 15, col = hi & 15;
-            const double v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
-            kin64[cc] = ok ? v : 0.0;
+            const TT v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
+            kin64[cc] = ok ? v : TT(0);
         }
     }
     const bool failed = sm[S::o_misc] != 0.0;
@@ -891,6 +936,25 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, [] {});
             xq = active_u ? xq : 0.0;
             __syncthreads();
+            if constexpr (sizeof(TT) == 4) {
+                // fp32 tiles: T^-1 is good to ~1e-4 only.  One step of iterative refinement with the fp64 residual
+                // r = K x_q + q = G'(G x_q) + D x_q + q (closed form, as the warm start's P x^0) takes the large gradient
+                // out of that error: what is left is 1e-4 of the iteration's own right-hand sides (oracle: admm_solve_split).
+                if (t < 9) {   // the prefix sums of Rz' lay under the tiles
+                    double accp = 0.0;
+                    for (int k = 0; k < N; ++k) { accp += sm[S::o_tm + k * 9 + t]; sm[S::o_cp + k * 9 + t] = accp; }
+                }
+                if (stepok) sm[S::o_x0c + uvar] = xq;
+                __syncthreads();
+                const double gtg = gtg_of_x0c();
+                const double dl = (ax < 2) ? dxy : dz;
+                const double rres = active_u ? fma(dl, xq, gtg + qv) : 0.0;
+                for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
+                __syncthreads();
+                const double dxq = apply_kinv<double, CHMAX>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, [] {});
+                xq = active_u ? xq + dxq : 0.0;
+                __syncthreads();
+            }
         }
         SRBDQP_STAMP(a, b, 7);
 
@@ -911,7 +975,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         for (int i = 0; i < 12; ++i) bd[i] = (R)bdrow[i];
         const R xqr = (R)xq;
         const bool rowA = active_u, rowB = active_u && ax < 2;
-        const R sigma = (R)a.sigma, alpha = (R)a.alpha, oma = (R)(1.0 - a.alpha), mu = (R)a.mu, irho = (R)(1.0 / rho_b);
+        const R sigma = uni((R)a.sigma), alpha = uni((R)a.alpha), oma = uni((R)(1.0 - a.alpha)), mu = uni((R)a.mu), irho = uni((R)(1.0 / rho_b));
         const R rhoA = rowA ? (R)rho_b : R(0), rhoB = rowB ? (R)rho_b : R(0);
         const R loA = !rowA ? R(0) : (ax < 2 ? (R)-kInf : (R)a.fzmin_s), hiA = !rowA ? R(0) : (ax < 2 ? R(0) : (R)a.fzmax_s);
         const R loB = rowB ? (R)-kInf : R(0), hiB = R(0);
@@ -928,11 +992,11 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const R fz0 = bperm(x, cbase + 2);
         R axA = rowA ? fma(-mucA, fz0, x) : R(0), axB = rowB ? fma(-mu, fz0, -x) : R(0);
         R zA = rmin(rmax(axA, loA), hiA), zB = rmin(rmax(axB, loB), hiB);
-        const float qnf = (float)wg_max1<NW>(fabs(qv), sm + S::o_red + 24);
+        const float qnf = uni((float)wg_max1<NW>(fabs(qv), sm + S::o_red + 24));
         R wv = fma(sigma, x, At(fma(rhoA, zA, -yA), fma(rhoB, zB, -yB)));
         __syncthreads();
         // fp32 iterations cannot certify residuals below ~2e-6 (1 + norm): the maxima themselves carry a few ulp of noise
-        const double eps_a = (sizeof(R) == 4) ? fmax(a.eps_abs, 2.0e-6) : a.eps_abs, eps_r = (sizeof(R) == 4) ? fmax(a.eps_rel, 2.0e-6) : a.eps_rel;
+        const double eps_a = uni((sizeof(R) == 4) ? fmax(a.eps_abs, 2.0e-6) : a.eps_abs), eps_r = uni((sizeof(R) == 4) ? fmax(a.eps_rel, 2.0e-6) : a.eps_rel);
         status = 2; iters = a.max_iter;
         int nchk = 0, ph = 0;
         bool pending = false, vote_ok = true, done = false;
@@ -946,7 +1010,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                     float v0 = buf[0], v1 = buf[1], v2 = buf[2], v3 = buf[3];
 #pragma unroll
                     for (int q = 1; q < NW; ++q) { v0 = fmaxf(v0, buf[4 * q]); v1 = fmaxf(v1, buf[4 * q + 1]); v2 = fmaxf(v2, buf[4 * q + 2]); v3 = fmaxf(v3, buf[4 * q + 3]); }
-                    const double e_prim = eps_a + eps_r * (double)v1;
+                    v0 = uni(v0); v1 = uni(v1); v2 = uni(v2); v3 = uni(v3);
+                    const double e_prim = uni(eps_a + eps_r * (double)v1);
                     const double e_dual = eps_a + eps_r * fmax((double)v3, (double)qnf);
                     e_prim_last = e_prim;
                     lastv0 = v0; lastv1 = v1; lastv2 = v2; lastv3 = fmaxf(v3, qnf);
@@ -1088,13 +1153,21 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     SRBDQP_STAMP(a, b, 9);
 }
 
-template <int N, typename R, typename TIO, int MODE, int WPS>
+template <int N, typename R, typename TIO, int MODE, int WPS, typename TT = double>
 __global__ __launch_bounds__(WrenchSmem<N>::BT, WPS) void srbdqp_wrench_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if ((int)blockIdx.x >= a.B) return;
+    if (a.tile_sel) {   // fp32 calls: this launch takes the QPs with (1) / without (2) wrench coordinates only
+        const uint32_t* cf = reinterpret_cast<const uint32_t*>(a.contact + (size_t)SRBDQP_QP_INDEX(a) * (N * 4));   // 4 flags per step
+        const int lane = threadIdx.x & 63;
+        const uint32_t v = cf[lane < N ? lane : 0];
+        const int nc = ((v & 0xffu) ? 1 : 0) + ((v & 0xff00u) ? 1 : 0) + ((v & 0xff0000u) ? 1 : 0) + ((v & 0xff000000u) ? 1 : 0);
+        const bool wrench_only = __ballot(lane < N && (nc == 1 || nc == 2)) == 0ull;
+        if (wrench_only != (a.tile_sel == 1)) return;
+    }
     // restart pass: workgroup i takes the i-th listed QP; no loop over QPs here -- any loop around the body makes hipcc
     // hoist the body's lane-index expressions out of it and spill them (750 bytes of scratch per lane at N = 20)
-    if (!a.count_ptr || (int)blockIdx.x < *a.count_ptr) wrench_qp<N, R, TIO, MODE>(a, SRBDQP_QP_INDEX(a), sm);
+    if (!a.count_ptr || (int)blockIdx.x < *a.count_ptr) wrench_qp<N, R, TIO, MODE, TT>(a, SRBDQP_QP_INDEX(a), sm);
     signal_done(a);   // staged path: every workgroup of the launch reports once, with or without work
 }
 

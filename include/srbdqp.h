@@ -49,6 +49,9 @@ extern "C" {
 /* srbdqp_config.flags */
 #define SRBDQP_FLAG_TIMING 1      /* bracket every kernel launch with HIP events (srbdqp_last_kernel_ms) */
 #define SRBDQP_FLAG_SETUP4 4      /* split pipeline: set-up kernel with 4 waves per QP instead of one wave per QP (A/B) */
+#define SRBDQP_FLAG_F64_TILES 8   /* _f32 calls: factor every QP's T in fp64 tiles (default: fp32 tiles for the QPs whose steps all
+                                     have 0 or >= 3 stance contacts; A/B and accuracy studies) */
+#define SRBDQP_FLAG_F32_TILES 16  /* _f32 calls: fp32 tiles for the eligible QPs of batches below 512 too (tests) */
 #define SRBDQP_FLAG_NO_SPIN 2     /* srbdqp_solve_staged_f64: wait with hipStreamSynchronize instead of spinning on the
                                      completion word the kernel writes to host memory */
 

@@ -439,7 +439,7 @@ def admm_solve(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, dtype=np.
     return x, z, y, iters, status
 
 
-def admm_solve_split(p: SrbdParams, P, q, A, l, u, wr, x_init=None, y_init=None, dtype=np.float32, info=None):
+def admm_solve_split(p: SrbdParams, P, q, A, l, u, wr, x_init=None, y_init=None, dtype=np.float32, info=None, tile_dtype=np.float64):
     """The recursions of the general HIP kernel (srbdqp_wrench.hpp), in `dtype` (float32 = its fp32 instantiation).
 
     Same algorithm as admm_solve(), rearranged so that the large gradient q never enters the iteration:
@@ -450,11 +450,19 @@ def admm_solve_split(p: SrbdParams, P, q, A, l, u, wr, x_init=None, y_init=None,
     n, m = P.shape[0], A.shape[0]
     rho64 = rho_vector(p, l, u)
     T = wr["T"]
-    Lc = np.linalg.cholesky(T)
-    Linv = _tri_inv(Lc)
-    Tinv64 = Linv.T @ Linv
+    if tile_dtype == np.float32:   # the fp32-tile instantiation: T rounded to float32, factored and inverted in float32
+        Linv = _tri_inv(_chol(T.astype(np.float32)))
+        Tinv64 = (Linv.T @ Linv).astype(np.float64)
+    else:
+        Linv = _tri_inv(np.linalg.cholesky(T))
+        Tinv64 = Linv.T @ Linv
     V64, Bd64 = wr["V"], wr["Bd"]
-    xq = (-(Bd64 @ q + V64.T @ (Tinv64 @ (V64 @ q)))).astype(dtype)
+    kinv64 = lambda r: Bd64 @ r + V64.T @ (Tinv64 @ (V64 @ r))
+    xq = -kinv64(q)
+    if tile_dtype == np.float32:   # one step of iterative refinement with the float64 residual K x_q + q
+        K = P + p.sigma * np.eye(n) + (A.T * rho64) @ A
+        xq = xq - kinv64(K @ xq + q)
+    xq = xq.astype(dtype)
     Tinv, V, Bd = Tinv64.astype(dtype), V64.astype(dtype), Bd64.astype(dtype)
     A = A.astype(dtype); rho = rho64.astype(dtype)
     lo = np.maximum(l, -INF).astype(dtype); hi = np.minimum(u, INF).astype(dtype)
@@ -505,9 +513,21 @@ def admm_solve_split(p: SrbdParams, P, q, A, l, u, wr, x_init=None, y_init=None,
     return x.astype(np.float64), z.astype(np.float64), y.astype(np.float64), iters, status
 
 
-def update_split(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None, warm=None, dtype=np.float32):
+def fp32_tiles_ok(contact_hor) -> bool:
+    """The general kernel's rule for factoring T in float32 tiles (fp32 calls, batches >= 512): every step has 0 or >= 3
+    stance contacts, i.e. every g coordinate is a wrench coordinate (cond(T) ~ 5e4; a step kept in force variables
+    carries the conditioning of K, 1e8, into T)."""
+    c = (np.asarray(contact_hor).reshape(-1, NC) != 0).sum(axis=1)
+    return bool(np.all((c == 0) | (c >= 3)))
+
+
+def update_split(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None, warm=None, dtype=np.float32, tile_dtype=np.float64):
     """Oracle twin of the general kernel's fp32 (or fp64) path: like update(), through wrench_reduce() +
-    admm_solve_split().  With dtype=float32 the inputs are first rounded to float32, as the _f32 entry points see them."""
+    admm_solve_split().  With dtype=float32 the inputs are first rounded to float32, as the _f32 entry points see them.
+    tile_dtype: np.float64, np.float32 or "auto" (float32 where fp32_tiles_ok(), as the engine does for batches >= 512);
+    the pass after a rho restart always factors in float64 tiles."""
+    if isinstance(tile_dtype, str):
+        tile_dtype = np.float32 if (dtype == np.float32 and fp32_tiles_ok(contact_hor)) else np.float64
     if dtype == np.float32:
         x0, x_ref, foot_hor = (np.asarray(v, np.float32).astype(np.float64) for v in (x0, x_ref, foot_hor))
         pcom_hor = None if pcom_hor is None else np.asarray(pcom_hor, np.float32).astype(np.float64)
@@ -523,14 +543,14 @@ def update_split(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None,
         args = (red["P"], red["q"], red["A"], red["l"], red["u"])
         if 0 < p.rho_restart_iter < p.max_iter:   # the general kernel's in-kernel rho restart (same rule as solve_with_restart)
             info = {}
-            xr_, _, yr_, iters, status = admm_solve_split(replace(p, max_iter=p.rho_restart_iter), *args, wr, xi, yi, dtype=dtype, info=info)
+            xr_, _, yr_, iters, status = admm_solve_split(replace(p, max_iter=p.rho_restart_iter), *args, wr, xi, yi, dtype=dtype, info=info, tile_dtype=tile_dtype)
             if status == STATUS_MAX_ITER:
                 p2 = replace(p, rho=restart_rho(p, info), max_iter=p.max_iter - p.rho_restart_iter)
                 wr2 = wrench_reduce(p2, x_ref, foot_hor, contact_hor, pcom_hor)
                 xr_, _, yr_, it2, status = admm_solve_split(p2, *args, wr2, xr_, yr_, dtype=dtype)
                 iters = p.rho_restart_iter + it2
         else:
-            xr_, _, yr_, iters, status = admm_solve_split(p, *args, wr, xi, yi, dtype=dtype)
+            xr_, _, yr_, iters, status = admm_solve_split(p, *args, wr, xi, yi, dtype=dtype, tile_dtype=tile_dtype)
         uh[vi] = xr_
         y[ri] = yr_
     N = np.asarray(x_ref).shape[0]

@@ -5,7 +5,8 @@ Tolerances, stated once:
   fp64 (srbdqp_solve_batch_f64, kernel = SRBDQP_KERNEL_WRENCH)
     * forces vs the oracle's ADMM twin (orc.update, dense presolved K):  <= 2e-3 N, iteration counts within one check interval
     * forces vs the independent exact QP optimum:                        <= 5e-2 N
-  fp32 (srbdqp_solve_batch_f32; fp32 buffers and iterations, fp64 set-up)
+  fp32 (srbdqp_solve_batch_f32; fp32 buffers and iterations, fp64 set-up; batches >= 512: T of the QPs without
+        force-variable steps factored in fp32 tiles + one fp64 refinement step of x_q -- same tolerances)
     * forces vs the fp32 twin (orc.update_split, float32):               <= 2e-2 N, iteration counts within two check intervals
       (the twin's NumPy mat-vecs sum in another order than the kernel's; in fp32 that moves an iterate near the stopping
       threshold more often than in fp64)
@@ -143,6 +144,62 @@ def test_wrench_f32_matches_twin_and_exact_optimum(torch_first, built_lib, N, sc
         kr = orc.kkt_residuals(kq["P"], kq["q"], kq["A"], kq["l"], kq["u"], out["u"][b].reshape(-1).astype(np.float64)[vi] / p.force_scale,
                                out["y"][b].astype(np.float64)[ri])
         assert kr["primal"] <= 1e-4 and kr["stationarity"] <= 1e-3 * max(1.0, np.abs(ref["qp"]["q"]).max()), kr
+
+
+@pytest.mark.parametrize("N,schedule,B", [(20, "double", 12), (24, "double", 4), (16, "three", 6), (10, "double", 8), (4, "double", 6), (20, "mixed", 8)])
+def test_wrench_f32_tiles_match_twin_and_exact_optimum(torch_first, built_lib, N, schedule, B):
+    """The fp32-tile instantiation (what an _f32 call of >= 512 QPs runs for the QPs whose steps all have 0 or >= 3 stance
+    contacts; SRBDQP_FLAG_F32_TILES forces it at test sizes): T factored and inverted in fp32 MFMA tiles, x_q refined
+    once with the fp64 residual.  Against the twin with the same rule (tile_dtype="auto": float32 Cholesky of T + the
+    refinement step) and the exact optimum; the "mixed" batch sends its QPs through both launches of the call."""
+    from g1_locomotion_amd import _lib
+    x0, xr, ft, ct = _batch(B, N, 500 + N, "double" if schedule == "three" else schedule)
+    if schedule == "three":                          # 3 or 4 stance contacts on every step
+        rng = np.random.default_rng(N)
+        for b in range(B):
+            for k in range(N):
+                if rng.random() < 0.5:
+                    ct[b, k, rng.integers(0, 4)] = 0
+    if schedule == "mixed":
+        ct[::2] = 1                                  # every other QP in full double support: eligible for fp32 tiles
+        ct[0, 3:5] = 0                               # ... one of them with a flight phase (0 contacts: still eligible)
+    with _engine(N, flags=_lib.FLAG_F32_TILES) as eng:
+        out = eng.solve(x0, xr, ft, ct, want_y=True, dtype=np.float32)
+        assert eng.kernel_name() == f"wrench_f32_n{N}", eng.kernel_name()
+    p = orc.params_for(N, eps_abs=2e-6, eps_rel=2e-6)
+    n32 = 0
+    for b in range(B):
+        n32 += orc.fp32_tiles_ok(ct[b])
+        ref = orc.update_split(p, x0[b], xr[b], ft[b], ct[b], dtype=np.float32, tile_dtype="auto")
+        assert out["status"][b] == ref["status"] == orc.STATUS_SOLVED, (b, out["status"][b], ref["status"], out["iters"][b], ref["iters"])
+        assert abs(int(out["iters"][b]) - ref["iters"]) <= 2 * p.check_every, (b, out["iters"][b], ref["iters"])
+        assert np.abs(out["u"][b] - ref["u"]).max() <= TOL32_TWIN_N, (b, np.abs(out["u"][b] - ref["u"]).max())
+        assert np.abs(out["x"][b] - ref["x"]).max() <= 1e-3
+        xs, ys = orc.solve_reference(p, ref["qp"])
+        assert np.abs(out["u"][b].reshape(-1).astype(np.float64) - xs * p.force_scale).max() <= TOL32_EXACT_N
+        kq, vi, ri = orc.presolve(ref["qp"], ct[b])
+        kr = orc.kkt_residuals(kq["P"], kq["q"], kq["A"], kq["l"], kq["u"], out["u"][b].reshape(-1).astype(np.float64)[vi] / p.force_scale,
+                               out["y"][b].astype(np.float64)[ri])
+        assert kr["primal"] <= 1e-4 and kr["stationarity"] <= 1e-3 * max(1.0, np.abs(ref["qp"]["q"]).max()), kr
+        off = np.setdiff1d(np.arange(12 * N), vi)
+        assert np.all(out["u"][b].reshape(-1)[off] == 0.0)
+    assert n32 == (B if schedule != "mixed" else B // 2), n32          # the case exercises what its name says
+
+
+def test_f32_tile_flags_select_the_factorisation(torch_first, built_lib):
+    """SRBDQP_FLAG_F64_TILES / _F32_TILES and the batch threshold: same QPs, forces within the fp32 path's twin tolerance of
+    each other, and not bit-identical between the two factorisations (so the flag really switches the kernel)."""
+    from g1_locomotion_amd import _lib
+    N, B = 20, 16
+    x0, xr, ft, ct = _batch(B, N, 61, "double")
+    res = {}
+    for name, flags in (("default", 0), ("f32", _lib.FLAG_F32_TILES), ("f64", _lib.FLAG_F64_TILES)):
+        with _engine(N, flags=flags) as eng:
+            res[name] = eng.solve(x0, xr, ft, ct, dtype=np.float32)
+    assert np.array_equal(res["default"]["u"], res["f64"]["u"])        # below 512 QPs a call stays on fp64 tiles
+    assert not np.array_equal(res["f32"]["u"], res["f64"]["u"])
+    assert np.abs(res["f32"]["u"].astype(np.float64) - res["f64"]["u"]).max() <= TOL32_TWIN_N
+    assert (res["f32"]["status"] == orc.STATUS_SOLVED).all()
 
 
 def test_wrench_warm_start_and_edge_cases(torch_first, built_lib):
