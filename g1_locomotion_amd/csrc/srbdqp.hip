@@ -45,10 +45,10 @@ struct srbdqp_handle {
         hipStream_t st = nullptr; bool used = false;
         int32_t* perm = nullptr; size_t perm_cap = 0;
         double* ws = nullptr; size_t ws_doubles = 0;
-        // rho restart: fp32 maxima of the capped QPs, their list + count, their new rho, and y / status when the caller
-        // passes none (the second pass warm-starts from the first pass's outputs)
+        // rho restart: fp32 maxima of the last check of the QPs that end at the cap of the first pass, and y / status when
+        // the caller passes none (the second pass warm-starts from the first pass's outputs)
         char* rs = nullptr; size_t rs_items = 0, rs_rows = 0;
-        float* resid = nullptr; int32_t* list = nullptr; int32_t* count = nullptr; double* rho = nullptr; double* ybuf = nullptr;
+        float* resid = nullptr; double* ybuf = nullptr;
         int32_t* stbuf = nullptr;
     };
     static constexpr int kMaxSlots = 8;
@@ -296,7 +296,7 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
             // variables carries the conditioning of K (1e8) into T and needs fp64 tiles.  Two launches over the same grid,
             // each workgroup looks at its QP's contact flags and leaves at once if the QP belongs to the other launch.
             // Not on the staged path (its workgroups are counted), not in the restart pass (few QPs), not for ragged batches.
-            if (!a.done_flag && !a.count_ptr && !a.row_off && !a.stamps && !(h->cfg.flags & SRBDQP_FLAG_F64_TILES) && (a.B >= kTileClassMinBatch || (h->cfg.flags & SRBDQP_FLAG_F32_TILES))) {
+            if (!a.done_flag && !a.count_ptr && !a.resid_in && !a.row_off && !a.stamps && !(h->cfg.flags & SRBDQP_FLAG_F64_TILES) && (a.B >= kTileClassMinBatch || (h->cfg.flags & SRBDQP_FLAG_F32_TILES))) {
                 using S4 = srbdqp::WrenchSmem<N, 4>;
                 constexpr int WPS4 = WrenchTraits<N, R, 4>::wps;
                 constexpr size_t lds4 = S4::bytes;
@@ -378,28 +378,6 @@ struct Carver {
     }
 };
 
-// Restart selection: the QPs whose first pass ended at its cap (status 2), their new rho from the fp32 maxima of their
-// last check (OSQP's rule, oracle restart_rho()).  One workgroup; the order of the list is arbitrary, every QP's
-// result is independent of it.
-__global__ __launch_bounds__(1024) void srbdqp_restart_select_kernel(const int32_t* status, const float* resid, int B, double rho0,
-                                                                     int32_t* list, int32_t* count, double* rho_qp) {
-    __shared__ int cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < B; i += 1024) {
-        if (status[i] != SRBDQP_MAX_ITER) continue;
-        const int pos = atomicAdd(&cnt, 1);
-        list[pos] = i;
-        const float* r = resid + (size_t)i * 4;
-        const double num = (double)r[0] / fmax((double)r[1], 1e-30), den = (double)r[2] / fmax((double)r[3], 1e-30);
-        double r1 = rho0;
-        if (num > 0.0 && den > 0.0 && num <= 1.0e30 && den <= 1.0e30) r1 = fmin(fmax(rho0 * sqrt(num / den), rho0 * 0.1), rho0 * 5.0);
-        rho_qp[i] = r1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *count = cnt;
-}
-
 // Iteration at which a solve of this handle re-balances rho (0 = never).  srbdqp_config.rho_restart_iter: > 0 that
 // iteration, < 0 off, 0 = automatic: 100 (125 above N = 16) on the general kernel (its long horizons have a 1 - 10 % tail
 // of slow QPs, and at its batch sizes the second launch costs 3 - 5 %), off elsewhere (the N = 10 batch kernels run
@@ -419,8 +397,7 @@ int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hi
     HIP_TRY(h, hipStreamSynchronize(st));
     if (slot->rs) { HIP_TRY(h, hipFree(slot->rs)); slot->rs = nullptr; }
     auto carve = [&](Carver& c) {
-        slot->resid = c.take<float>(B * 4); slot->list = c.take<int32_t>(B); slot->count = c.take<int32_t>(16);
-        slot->rho = c.take<double>(B); slot->ybuf = c.take<double>(B * m); slot->stbuf = c.take<int32_t>(B);
+        slot->resid = c.take<float>(B * 4); slot->ybuf = c.take<double>(B * m); slot->stbuf = c.take<int32_t>(B);
     };
     Carver sz(nullptr);
     carve(sz);
@@ -432,30 +409,19 @@ int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hi
     return SRBDQP_OK;
 }
 
-// second pass of a two-pass solve: select the capped QPs, then re-run them with their own rho from their own (x, y).
+// second pass of a two-pass solve: the same grid again; the workgroup of a QP that ended at the cap re-balances its rho from
+// the maxima of its last check and continues from its own (x, y), every other workgroup leaves at once.  No selection
+// kernel and no list between the passes: a one-workgroup kernel queued behind a chip-filling launch of another stream
+// waits ~150 us for its turn at the dispatcher (rocprofv3 timeline, round 2), which cost more than the second pass itself.
 // a1 = the arguments of the first pass (status / y_out / resid_out set).
 int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int maxs, bool signal) {
-    auto* slot = stream_slot(h, st);
-    if (!slot) return SRBDQP_E_INVALID;
-    const int B = a1.B;
-    // every capped QP is listed and re-run, one per workgroup; the grid covers the worst case (all of them) and the
-    // workgroups beyond the count exit at once (an empty workgroup costs a few ns of dispatch)
-    const int grid2 = B;
-    (void)maxs;
-    hipLaunchKernelGGL(srbdqp_restart_select_kernel, dim3(1), dim3(1024), 0, st, a1.status, slot->resid, B, h->cfg.rho,
-                       slot->list, slot->count, slot->rho);
-    HIP_TRY(h, hipGetLastError());
     KArgs a2 = a1;
-    a2.perm = slot->list;
-    a2.count_ptr = slot->count;
-    a2.rho_qp = slot->rho;
+    a2.resid_in = a1.resid_out;
     a2.warm_u = a1.u_out;                                   // newtons, as a caller's warm start would be
     a2.warm_y = a1.y_out;
     a2.max_iter = h->cfg.max_iter - a1.max_iter;            // the cap is on the total
     a2.iters_base = a1.max_iter;
     a2.resid_out = nullptr;
-    a2.qp_span = B;
-    a2.B = grid2;
     if (signal) { a2.done_flag = h->done_dev; a2.done_count = h->done_count; a2.done_value = h->done_seq; }
     else { a2.done_flag = nullptr; a2.done_count = nullptr; }
     return launch(h, a2, st, maxs, 2);

@@ -41,7 +41,10 @@ struct KArgs {
     long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null
     double* ws;              // split mode: per-QP workspace between the set-up kernel and the ADMM kernel, or null
     // rho re-balancing (one OSQP-style restart of the QPs that reach the cap of the first pass, see srbdqp.hip)
-    const double* rho_qp;    // second pass: rho of QP b, or null (= rho)
+    const double* rho_qp;    // rho of QP b, or null (= rho)
+    const float* resid_in;   // second pass: the first pass's resid_out.  Workgroup of QP b leaves at once unless status[b] is
+                             //   SRBDQP_MAX_ITER, and re-balances its rho from resid_in[b] (restart_rho_of) -- no list, no
+                             //   selection kernel between the passes
     float* resid_out;        // first pass: [B][4] fp32 maxima (r_prim, n_prim, r_dual, n_dual) of the last check of a QP
                              //   that ends at the cap, or null
     const int32_t* count_ptr;   // second pass: number of valid entries of perm[]; workgroups beyond it exit at once
@@ -61,6 +64,18 @@ struct KArgs {
 
 // QP index of this workgroup
 #define SRBDQP_QP_INDEX(a) ((a).perm ? (a).perm[blockIdx.x] : (int)blockIdx.x)
+
+// rho of the second pass from the fp32 maxima of the first pass's last check (OSQP's rule, oracle restart_rho()):
+// rho sqrt((r_prim / n_prim) / (r_dual / n_dual)), clipped to [rho / 10, 5 rho]
+__device__ __forceinline__ double restart_rho_of(double rho0, const float* r) {
+    const double num = (double)r[0] / fmax((double)r[1], 1e-30), den = (double)r[2] / fmax((double)r[3], 1e-30);
+    double r1 = rho0;
+    if (num > 0.0 && den > 0.0 && num <= 1.0e30 && den <= 1.0e30) r1 = fmin(fmax(rho0 * sqrt(num / den), rho0 * 0.1), rho0 * 5.0);
+    return r1;
+}
+// is QP b this workgroup's to solve in a second pass (resid_in set)?  Uniform over the workgroup.
+#define SRBDQP_RESTART_SKIP(a, b) ((a).resid_in && (a).status[(b)] != 2)
+#define SRBDQP_RHO_OF(a, b) ((a).resid_in ? restart_rho_of((a).rho, (a).resid_in + (size_t)(b) * 4) : ((a).rho_qp ? (a).rho_qp[(b)] : (a).rho))
 
 // diagnostic phase stamp (thread 0 only; leaves the kernel through a buffer nothing else reads)
 #define SRBDQP_STAMP(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)

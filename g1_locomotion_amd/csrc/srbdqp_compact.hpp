@@ -333,7 +333,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
     static_assert(2 * S::nmax <= kThreads, "two threads per compact column / row");
     static_assert(4 * N <= 128, "the presolve compacts the 4N contact flags with at most two wave-wide ballots");
     static_assert((S::o_R % 2) == 0 && (S::o_rhs % 2) == 0, "16-byte alignment");
-    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+    const double rho_b = SRBDQP_RHO_OF(a, b);
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     int mcol = lane & 15, kq = lane >> 4;                   // re-laundered per phase, see SRBDQP_PHASE_LOCAL
@@ -884,11 +884,12 @@ template <int N, int MAXS, bool SPLIT = false, bool DUMP = false>
 __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) void srbdqp_compact_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if ((int)blockIdx.x >= a.B) return;
-    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) {   // restart pass: nothing listed for this workgroup
+    const int b = SRBDQP_QP_INDEX(a);
+    if ((a.count_ptr && (int)blockIdx.x >= *a.count_ptr) || SRBDQP_RESTART_SKIP(a, b)) {   // restart pass: not this workgroup's
         signal_done(a);
         return;
     }
-    compact_qp<N, MAXS, SPLIT, DUMP>(a, SRBDQP_QP_INDEX(a), sm);
+    compact_qp<N, MAXS, SPLIT, DUMP>(a, b, sm);
 }
 
 template <int N, int MAXS>

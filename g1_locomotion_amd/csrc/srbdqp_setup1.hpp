@@ -75,7 +75,8 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     if ((int)blockIdx.x >= a.B) return;
     if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) return;
     const int b = SRBDQP_QP_INDEX(a);
-    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+    if (SRBDQP_RESTART_SKIP(a, b)) return;
+    const double rho_b = SRBDQP_RHO_OF(a, b);
     const int lane = threadIdx.x;
     int mcol = lane & 15, kq = lane >> 4;
     double* ws = FUSED ? nullptr : a.ws + (size_t)b * W::doubles;

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
     if ((int)blockIdx.x >= a.B) return;
     if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) return;   // restart pass: nothing listed for this workgroup
     const int b = SRBDQP_QP_INDEX(a);
-    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+    if (SRBDQP_RESTART_SKIP(a, b)) return;
+    const double rho_b = SRBDQP_RHO_OF(a, b);
     const int lane = threadIdx.x;
     const double* ws = a.ws + (size_t)b * W::doubles;
     if (ws[S::o_misc + 1] != 0.0) return;                  // finished by the set-up kernel (no stance contact / bound)

@@ -251,7 +251,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     constexpr int n = S::n, m = S::m, NW = S::NW, BT = S::BT, TS = S::TS, CHMAX = S::CHMAX;
     static_assert((S::o_R % 2) == 0 && (S::o_wb % 2) == 0 && (S::o_tb % 2) == 0 && (S::o_vb % 2) == 0, "16-byte alignment");
     static_assert(S::NT <= 2 * NW || S::WQ >= 1, "");
-    const double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+    const double rho_b = SRBDQP_RHO_OF(a, b);
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     int mcol = lane & 15, kq = lane >> 4;
@@ -1165,9 +1165,10 @@ __global__ __launch_bounds__(WrenchSmem<N>::BT, WPS) void srbdqp_wrench_kernel(K
         const bool wrench_only = __ballot(lane < N && (nc == 1 || nc == 2)) == 0ull;
         if (wrench_only != (a.tile_sel == 1)) return;
     }
-    // restart pass: workgroup i takes the i-th listed QP; no loop over QPs here -- any loop around the body makes hipcc
+    // restart pass: the workgroup of a QP that did not end at the cap leaves at once; no loop over QPs here -- any loop around the body makes hipcc
     // hoist the body's lane-index expressions out of it and spill them (750 bytes of scratch per lane at N = 20)
-    if (!a.count_ptr || (int)blockIdx.x < *a.count_ptr) wrench_qp<N, R, TIO, MODE, TT>(a, SRBDQP_QP_INDEX(a), sm);
+    if ((!a.count_ptr || (int)blockIdx.x < *a.count_ptr) && !SRBDQP_RESTART_SKIP(a, SRBDQP_QP_INDEX(a)))
+        wrench_qp<N, R, TIO, MODE, TT>(a, SRBDQP_QP_INDEX(a), sm);
     signal_done(a);   // staged path: every workgroup of the launch reports once, with or without work
 }
 
