@@ -267,7 +267,10 @@ struct WrenchTraits {
 #ifdef SRBDQP_F32TILE_WPS   // experiments: waves per SIMD the fp32-tile instantiation is compiled for
     static constexpr int want = (TB == 4) ? SRBDQP_F32TILE_WPS : ((sizeof(R) == 4) ? 3 : (S::CHMAX <= 36 ? 2 : 1));
 #else
-    static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 36 ? 2 : 1);                  // register budget
+#ifndef SRBDQP_F64_SMALL_WPS
+#define SRBDQP_F64_SMALL_WPS 3
+#endif
+    static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 24 ? SRBDQP_F64_SMALL_WPS : (S::CHMAX <= 36 ? 2 : 1));   // register budget
 #endif
     static constexpr int wps = by_lds < want ? by_lds : want;
 };

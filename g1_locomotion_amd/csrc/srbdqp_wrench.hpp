@@ -152,35 +152,65 @@ __device__ __forceinline__ double wg_max1(double v, double* red) {
 // Used once in fp64 for x_q and every iteration in R.  `vb` is the v buffer to publish into; a workgroup barrier sits
 // between the publication of v and its use.  hook() runs right after that barrier (the ADMM loop reads the convergence
 // decision there).
-template <typename R, int CHMAX, typename KT, class Hook>
+// bj: the block-diagonal part Bd of K^-1, in one of two forms.
+//   BDN = 12: the lane's row of Bd over its step's 12 variables, explicit (formed in fp64 at set-up) -- the fp32 iterations:
+//             the implicit form below subtracts two nearly equal fp32 numbers every iteration and left 0.3 % of configs[2]
+//             short of the 2e-6 tolerance (0.06 % with the explicit rows);
+//   BDN = 4:  {J[0..2][u], 1 / D_u}: Bd w = D^-1 (w - Y' v) from the step's own v = V w -- the fp64 iterations: 8 registers
+//             instead of 24, 6 multiply-adds instead of 12, and only the lane's half of the step's right-hand sides is read.
+template <typename R, int CHMAX, typename KT, int BDN, class Hook>
 __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, int sg, int ul, bool active_g, int Rrow, int CH,
-                                        const KT (&kin)[CHMAX], const R (&vrow)[6], const R (&vcol)[6], const R (&bdrow)[12], Hook&& hook) {
+                                        const KT (&kin)[CHMAX], const R (&vrow)[6], const R (&vcol)[6], const R (&bj)[BDN], int vsoff, int vssel,
+                                        Hook&& hook) {
+    static_assert(BDN == 4 || BDN == 12, "Bd: implicit (4) or explicit row (12)");
     typedef R R4 __attribute__((ext_vector_type(4)));
     typedef R R2 __attribute__((ext_vector_type(2)));
     const int h = ul & 1;
     wbw[lane] = wv;
     asm volatile("" ::: "memory");
-    R wg[12];
-    {
-        const R* src = wbw + 12 * sg;                       // 12 sg elements: 16-byte aligned for float (48 B) and double (96 B)
-        if constexpr (sizeof(R) == 4) {
-            const R4* s4 = reinterpret_cast<const R4*>(src);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { const R4 v = s4[i]; wg[4 * i] = v[0]; wg[4 * i + 1] = v[1]; wg[4 * i + 2] = v[2]; wg[4 * i + 3] = v[3]; }
-        } else {
+    R xb;
+    if constexpr (BDN == 4) {
+        R wg[6];                                            // the lane's half (h) of its step's 12 right-hand sides
+        {
+            const R* src = wbw + 12 * sg + 6 * h;           // 8-byte aligned for float (24 B), 16-byte for double (48 B)
             const R2* s2 = reinterpret_cast<const R2*>(src);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { const R2 v = s2[i]; wg[2 * i] = v[0]; wg[2 * i + 1] = v[1]; }
+            for (int i = 0; i < 3; ++i) { const R2 v = s2[i]; wg[2 * i] = v[0]; wg[2 * i + 1] = v[1]; }
         }
+        R vp = R(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vp = fma(vrow[i], wg[i], vp);
+        const R v = vp + dpp_swap1(vp);
+        if (active_g && h == 0) vb[Rrow] = v;
+        asm volatile("" ::: "memory");
+        // the g rows of the lane's own step were written by this wave just above (LDS operations of one wave complete in
+        // order): no barrier needed.  Y' column of the variable: [J[:, u]; e_ax] on a wrench step, the unit vector of its g
+        // row on a force-variable step (where the whole term is w - w = 0).
+        const R* vs = vb + vsoff;
+        xb = bj[3] * (wv - fma(bj[0], vs[0], fma(bj[1], vs[1], fma(bj[2], vs[2], vb[vssel]))));
+    } else {
+        R wg[12];
+        {
+            const R* src = wbw + 12 * sg;                   // 12 sg elements: 16-byte aligned for float (48 B) and double (96 B)
+            if constexpr (sizeof(R) == 4) {
+                const R4* s4 = reinterpret_cast<const R4*>(src);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const R4 v = s4[i]; wg[4 * i] = v[0]; wg[4 * i + 1] = v[1]; wg[4 * i + 2] = v[2]; wg[4 * i + 3] = v[3]; }
+            } else {
+                const R2* s2 = reinterpret_cast<const R2*>(src);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { const R2 v = s2[i]; wg[2 * i] = v[0]; wg[2 * i + 1] = v[1]; }
+            }
+        }
+        R vp = R(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vp = fma(vrow[i], h ? wg[6 + i] : wg[i], vp);
+        const R v = vp + dpp_swap1(vp);
+        if (active_g && h == 0) vb[Rrow] = v;
+        xb = R(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) xb = fma(bj[i], wg[i], xb);
     }
-    R vp = R(0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) vp = fma(vrow[i], h ? wg[6 + i] : wg[i], vp);
-    const R v = vp + dpp_swap1(vp);
-    if (active_g && h == 0) vb[Rrow] = v;
-    R xb = R(0);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) xb = fma(bdrow[i], wg[i], xb);
     __syncthreads();
     hook();
     R tp;
@@ -208,7 +238,7 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
             }
         } else {
             const R2* s2 = reinterpret_cast<const R2*>(src);
-            constexpr int NV = CHMAX / 2, BL = (NV <= 8) ? NV : 8, NB = (NV + BL - 1) / BL;
+            constexpr int NV = CHMAX / 2, BL = (NV <= 4) ? NV : 4, NB = (NV + BL - 1) / BL;
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
                 if (blk == 0 || blk * 2 * BL < CH) {
@@ -515,7 +545,10 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // ================= per-step wrench blocks: E^-1, V, Bd (registers of the step's lanes) =================
     const double dxy = a.rs2 + a.sigma + 2.0 * rho_b, dz = a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b;
     const double idxy = 1.0 / dxy, idz = 1.0 / dz;
-    double vrow[6], vcol[6], bdrow[12];
+    double vrow[6], vcol[6], bjv[4];                                 // bjv: J[:, u] of the lane's variable and 1 / D_u (apply_kinv)
+    constexpr bool BD_EXPLICIT = (sizeof(R) == 4) || (MODE == 1);     // fp32 iterations and the assembly dump: Bd rows (apply_kinv)
+    [[maybe_unused]] double bdrow[12];
+    int bsel = 0;                                                    // g row (within the step) of the unit part of Y'[:, u]
     {
         const double* Jj = sm + S::o_J + js * 36;
         const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
@@ -617,15 +650,18 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 yv[r] = Ei[r][0] * j0 + Ei[r][1] * j1 + Ei[r][2] * j2 + ea;
                 vcol[r] = wu * yv[r];
             }
+            bjv[0] = j0; bjv[1] = j1; bjv[2] = j2; bjv[3] = wu; bsel = 3 + ax;
+            if constexpr (BD_EXPLICIT) {
 #pragma unroll
-            for (int u2 = 0; u2 < 12; ++u2) {
-                const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
-                const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
-                bdrow[u2] = -wu * wgt2 * dotv;
+                for (int u2 = 0; u2 < 12; ++u2) {
+                    const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
+                    const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
+                    bdrow[u2] = -wu * wgt2 * dotv;
+                }
+                // the diagonal term of D^-1 (static index: select chain over the unrolled loop)
+#pragma unroll
+                for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] += (u2 == ul) ? wu : 0.0;
             }
-            // the diagonal term of D^-1 (static index: select chain over the unrolled loop)
-#pragma unroll
-            for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] += (u2 == ul) ? wu : 0.0;
         } else {
             // identity coordinates: g row r <-> the r-th stance force variable of the step
             const int before = (ci > 0 ? f0 : 0) + (ci > 1 ? f1 : 0) + (ci > 2 ? f2 : 0);   // stance contacts before ci
@@ -642,8 +678,11 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             for (int i = 0; i < 6; ++i) vrow[i] = (active_g && (6 * h + i == ug)) ? 1.0 : 0.0;
 #pragma unroll
             for (int r = 0; r < 6; ++r) vcol[r] = (active_u && r == rank) ? 1.0 : 0.0;
+            bjv[0] = 0.0; bjv[1] = 0.0; bjv[2] = 0.0; bjv[3] = 0.0; bsel = active_u ? rank : 0;
+            if constexpr (BD_EXPLICIT) {
 #pragma unroll
-            for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] = 0.0;
+                for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] = 0.0;
+            }
             if (stepok && active_g) {
                 const double dd = ((rl % 3) < 2) ? dxy : dz;
 #pragma unroll
@@ -922,6 +961,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
     }
     const bool failed = sm[S::o_misc] != 0.0;
+    const int vsoff = stepok ? igoff[js] : 0, vssel = vsoff + bsel;   // the step's own v = V w inside the v buffer
     __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
     int status = -1, iters = 0;
     R x = R(0), yA = R(0), yB = R(0);
@@ -933,7 +973,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             double* vb = sm + S::o_vb;
             for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
             __syncthreads();
-            xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, [] {});
+            if constexpr (BD_EXPLICIT) xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, vsoff, vssel, [] {});
+            else xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bjv, vsoff, vssel, [] {});
             xq = active_u ? xq : 0.0;
             __syncthreads();
             if constexpr (sizeof(TT) == 4) {
@@ -951,7 +992,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const double rres = active_u ? fma(dl, xq, gtg + qv) : 0.0;
                 for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
                 __syncthreads();
-                const double dxq = apply_kinv<double, CHMAX>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, [] {});
+                const double dxq = apply_kinv<double, CHMAX>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, vsoff, vssel, [] {});
                 xq = active_u ? xq + dxq : 0.0;
                 __syncthreads();
             }
@@ -966,13 +1007,14 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         int* vflag = reinterpret_cast<int*>(redf + 8 * NW);             // [NW] pre-test votes
         for (int i = t; i < 2 * S::VB; i += BT) vbuf[i] = R(0);
         if (t < NW) vflag[t] = 0;
-        R kin[CHMAX], vr[6], vc[6], bd[12];
+        constexpr int BDN = BD_EXPLICIT ? 12 : 4;
+        R kin[CHMAX], vr[6], vc[6], bd[BDN];
 #pragma unroll
         for (int cc = 0; cc < CHMAX; ++cc) kin[cc] = (R)kin64[cc];
 #pragma unroll
         for (int i = 0; i < 6; ++i) { vr[i] = (R)vrow[i]; vc[i] = (R)vcol[i]; }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) bd[i] = (R)bdrow[i];
+        for (int i = 0; i < BDN; ++i) bd[i] = BD_EXPLICIT ? (R)bdrow[i] : (R)bjv[i < 4 ? i : 0];
         const R xqr = (R)xq;
         const bool rowA = active_u, rowB = active_u && ax < 2;
         const R sigma = uni((R)a.sigma), alpha = uni((R)a.alpha), oma = uni((R)(1.0 - a.alpha)), mu = uni((R)a.mu), irho = uni((R)(1.0 / rho_b));
@@ -1004,7 +1046,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         float lastv0 = 0.0f, lastv1 = 0.0f, lastv2 = 0.0f, lastv3 = 0.0f;   // maxima of the last full check (restart rule)
         for (int k = 1; k <= a.max_iter + 1 && !done; ++k) {
             R* vb = vbuf + (k & 1) * S::VB;
-            const R kw = apply_kinv<R, CHMAX>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, [&] {
+            const R kw = apply_kinv<R, CHMAX>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
                 if (pending) {   // decision of the check made at iteration k - 1 (its maxima were published by this barrier)
                     const float* buf = redf + ((nchk - 1) & 1) * 4 * NW;
                     float v0 = buf[0], v1 = buf[1], v2 = buf[2], v3 = buf[3];
