@@ -299,7 +299,7 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
             // variables carries the conditioning of K (1e8) into T and needs fp64 tiles.  Two launches over the same grid,
             // each workgroup looks at its QP's contact flags and leaves at once if the QP belongs to the other launch.
             // Not on the staged path (its workgroups are counted), not in the restart pass (few QPs), not for ragged batches.
-            if (!a.done_flag && !a.count_ptr && !a.resid_in && !a.row_off && !a.stamps && !(h->cfg.flags & SRBDQP_FLAG_F64_TILES) && (a.B >= kTileClassMinBatch || (h->cfg.flags & SRBDQP_FLAG_F32_TILES))) {
+            if (!a.done_flag && !a.count_ptr && !a.resid_in && !a.row_off && !(h->cfg.flags & SRBDQP_FLAG_F64_TILES) && (a.B >= kTileClassMinBatch || (h->cfg.flags & SRBDQP_FLAG_F32_TILES))) {
                 using S4 = srbdqp::WrenchSmem<N, 4>;
                 constexpr int WPS4 = WrenchTraits<N, R, 4>::wps;
                 constexpr size_t lds4 = S4::bytes;
