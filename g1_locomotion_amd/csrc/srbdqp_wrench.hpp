@@ -29,6 +29,7 @@
 // The reference for all of this is the absent submodule g1_mpc; conventions from
 // g1_mujoco_sim/src/run_simulation.py:73-111.
 #pragma once
+#include <type_traits>
 #include "srbdqp_common.hpp"
 #include "srbdqp_admm.hpp"
 #include "srbdqp_mfma.hpp"
@@ -75,15 +76,19 @@ struct WrenchSmem {
     static constexpr int o_gv = o_mt + up2(9 * NPAIR);    // 9N   G'v tables
     static constexpr int o_gx = o_gv + up2(9 * N);        // 12N  G x^0 (warm start)
     static constexpr int o_tf = o_gx + n;                 // 6N
-    static constexpr int o_x0c = o_tf + 6 * N;            // 12N  warm start in the scaled variables
-    static constexpr int o_zt = o_x0c + n;                // 6 NG: wrench-space 6-vector of every g coordinate
+    static constexpr int o_x0c = o_eh;                    // 12N  warm start in the scaled variables (the gradient is done with o_eh by then)
+    static constexpr int o_zt = o_tf + 6 * N;             // 6 NG: wrench-space 6-vector of every g coordinate
     static constexpr int o_ei = o_zt + 6 * NG;            // 36N  E^-1 per step
     static constexpr int o_gs = o_ei + 36 * N;            // NG bytes: step of every g coordinate
     static constexpr int endA = o_gs + up2((NG + 7) / 8);
     // ---- phase B (tiles)
     static constexpr int o_T = o_R;
     static constexpr int o_ws = o_T + NTT * 256 * TB / 8;   // fp32 tiles: one 16 x 16 scratch tile per wave (operand re-layout)
-    static constexpr int endB = o_ws + (TB == 4 ? NW * 128 : 0);
+    // fp32 tiles: the lower triangle of E^-1 per step (21 N doubles: the very values that went into T -- V and Bd formed from a
+    // rounded copy break the Woodbury identity 100 times worse than rounding V and Bd themselves), written in phase E and kept
+    // through phases F / W / I behind the tiles AND behind the phase-A arrays; the rows of V and Bd are formed from it afterwards
+    static constexpr int o_e4 = cmax(o_ws + (TB == 4 ? NW * 128 : 0), TB == 4 ? endA : 0);
+    static constexpr int endB = o_e4 + (TB == 4 ? 21 * N : 0);
     // ---- phase C (ADMM vectors; element type R <= 8 bytes, offsets in doubles)
     static constexpr int VB = 2 * CHMAX + 8;              // one v buffer (elements)
     static constexpr int o_wb = o_R;                      // NW x 64   right-hand sides, wave private
@@ -553,10 +558,79 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // ================= per-step wrench blocks: E^-1, V, Bd (registers of the step's lanes) =================
     const double dxy = a.rs2 + a.sigma + 2.0 * rho_b, dz = a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b;
     const double idxy = 1.0 / dxy, idz = 1.0 / dz;
-    double vrow[6], vcol[6], bjv[4];                                 // bjv: J[:, u] of the lane's variable and 1 / D_u (apply_kinv)
+    // fp32 tiles (3 workgroups per CU, 168 registers): the rows / columns of V and Bd are formed AFTER the factorisation, from
+    // the triangle of E^-1 kept in LDS behind the tiles, and held in fp32 from then on.  Formed here they waited in scratch
+    // memory across phases F / W / I: 10 GB of HBM traffic per 65,536-QP launch against 0.29 GB of inputs and outputs
+    // (rocprofv3 FETCH_SIZE / WRITE_SIZE, round 2).
+    constexpr bool VBD_LATE = sizeof(TT) == 4;
+    typedef double VS;   // (x_q and its refinement need V and Bd in fp64: rounded to fp32 the refinement contracts 10 x slower)
+    VS vrow[6], vcol[6];
+    double bjv[4];                                                   // bjv: J[:, u] of the lane's variable and 1 / D_u (apply_kinv)
     constexpr bool BD_EXPLICIT = (sizeof(R) == 4) || (MODE == 1);     // fp32 iterations and the assembly dump: Bd rows (apply_kinv)
-    [[maybe_unused]] double bdrow[12];
+    // explicit Bd rows: fp32 from the start in the fp32-tile kernel (only the iterations use them there; x_q and its refinement
+    // run in fp64, where the implicit form is exact enough) -- 12 registers instead of 24 next to the T^-1 row
+    typedef typename std::conditional<sizeof(TT) == 4, float, double>::type BS;
+    [[maybe_unused]] BS bdrow[12];
     int bsel = 0;                                                    // g row (within the step) of the unit part of Y'[:, u]
+    const int before_ci = (ci > 0 ? f0 : 0) + (ci > 1 ? f1 : 0) + (ci > 2 ? f2 : 0);   // stance contacts of the step before ci
+    int ug_id = 0;                                                   // force-variable step: variable (0..11) of g row rl
+    {
+        const int want = rl / 3;
+        int cc = -1, seen = 0;
+        if (f0) { if (seen == want && cc < 0) cc = 0; ++seen; }
+        if (f1) { if (seen == want && cc < 0) cc = 1; ++seen; }
+        if (f2) { if (seen == want && cc < 0) cc = 2; ++seen; }
+        if (f3) { if (seen == want && cc < 0) cc = 3; ++seen; }
+        ug_id = (cc >= 0 ? 3 * cc : 0) + (rl % 3);
+    }
+    // registers of V and Bd of a wrench step from E^-1; E(r, c, dynamic row, dynamic column) reads an entry (register
+    // select chains in phase E, LDS for the late formation: no 36-double matrix in registers there)
+    auto form_vbd = [&](auto&& E) {
+        const double* Jj = sm + S::o_J + js * 36;
+        const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
+        double er[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) er[c] = E(rl, c);
+        // V[rl][6 h + i] = wgt (er[0..2] . J[:, u'] + er[3 + a'])
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int u2 = 6 * h + i;
+            const double flc = (u2 / 3 == 0) ? fl[0] : (u2 / 3 == 1) ? fl[1] : (u2 / 3 == 2) ? fl[2] : fl[3];
+            const double wgt = flc * (((i % 3) < 2) ? idxy : idz);
+            vrow[i] = (VS)(wgt * (er[0] * Jj[u2] + er[1] * Jj[12 + u2] + er[2] * Jj[24 + u2] + er[3 + (i % 3)]));
+        }
+        // y = E^-1 omega_u, omega_u = [J[:, ul]; e_ax]
+        const double wu = active_u ? ((ax < 2) ? idxy : idz) : 0.0;
+        const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
+        double yv[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            yv[r] = E(r, 0) * j0 + E(r, 1) * j1 + E(r, 2) * j2 + E(r, 3 + ax);
+            vcol[r] = (VS)(wu * yv[r]);
+        }
+        bjv[0] = j0; bjv[1] = j1; bjv[2] = j2; bjv[3] = wu; bsel = 3 + ax;
+        if constexpr (BD_EXPLICIT) {
+#pragma unroll
+            for (int u2 = 0; u2 < 12; ++u2) {
+                const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
+                const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
+                bdrow[u2] = (BS)(((u2 == ul) ? wu : 0.0) - wu * wgt2 * dotv);   // D^-1 - D^-1 Y' V (static index: select chain)
+            }
+        }
+    };
+    // ... of a force-variable step: V = the selection of the stance variables, Bd = 0
+    auto form_vbd_identity = [&]() {
+        const int rank = 3 * before_ci + ax;                         // g row of this lane's variable
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vrow[i] = (active_g && (6 * h + i == ug_id)) ? VS(1) : VS(0);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) vcol[r] = (active_u && r == rank) ? VS(1) : VS(0);
+        bjv[0] = 0.0; bjv[1] = 0.0; bjv[2] = 0.0; bjv[3] = 0.0; bsel = active_u ? rank : 0;
+        if constexpr (BD_EXPLICIT) {
+#pragma unroll
+            for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] = BS(0);
+        }
+    };
     {
         const double* Jj = sm + S::o_J + js * 36;
         const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
@@ -589,6 +663,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) Em[3 + q][p] = Em[p][3 + q];
+            // (the J entries are read again below rather than kept: 36 doubles per lane across this phase were spilled)
+            asm volatile("" ::: "memory");
             // Cholesky E = L L', Li = L^-1, E^-1 = Li' Li
             double Lm[6][6], Li[6][6];
             bool okE = true;
@@ -640,57 +716,27 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                     ZT[6 * Rrow + 3 * h + i] = (3 * h + i == rl) ? 1.0 : 0.0;
                 }
             }
-            // V[rl][6 h + i] = wgt (er[0..2] . J[:, u'] + er[3 + a'])
+            if constexpr (VBD_LATE) {
+                if (stepok) {
+                    double* E4 = sm + S::o_e4 + 21 * js;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int u2 = 6 * h + i;
-                const double flc = (u2 / 3 == 0) ? fl[0] : (u2 / 3 == 1) ? fl[1] : (u2 / 3 == 2) ? fl[2] : fl[3];
-                const double wgt = flc * (((i % 3) < 2) ? idxy : idz);
-                vrow[i] = wgt * (er[0] * Jj[u2] + er[1] * Jj[12 + u2] + er[2] * Jj[24 + u2] + er[3 + (i % 3)]);
-            }
-            // y = E^-1 omega_u, omega_u = [J[:, ul]; e_ax]
-            const double wu = active_u ? ((ax < 2) ? idxy : idz) : 0.0;
-            const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
-            double yv[6];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const double ea = (ax == 0) ? Ei[r][3] : (ax == 1) ? Ei[r][4] : Ei[r][5];
-                yv[r] = Ei[r][0] * j0 + Ei[r][1] * j1 + Ei[r][2] * j2 + ea;
-                vcol[r] = wu * yv[r];
-            }
-            bjv[0] = j0; bjv[1] = j1; bjv[2] = j2; bjv[3] = wu; bsel = 3 + ax;
-            if constexpr (BD_EXPLICIT) {
-#pragma unroll
-                for (int u2 = 0; u2 < 12; ++u2) {
-                    const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
-                    const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
-                    bdrow[u2] = -wu * wgt2 * dotv;
+                    for (int i = 0; i < 3; ++i)
+                        if (3 * h + i <= rl) E4[(rl * (rl + 1)) / 2 + 3 * h + i] = h ? er[3 + i] : er[i];
                 }
-                // the diagonal term of D^-1 (static index: select chain over the unrolled loop)
+            } else {
+                form_vbd([&](int r, int c) -> double {   // r or c may be a run-time index: select chains over the register matrix
+                    double v = Ei[0][0];
 #pragma unroll
-                for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] += (u2 == ul) ? wu : 0.0;
+                    for (int p = 0; p < 6; ++p)
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) v = (r == p && c == q) ? Ei[p][q] : v;
+                    return v;
+                });
             }
         } else {
             // identity coordinates: g row r <-> the r-th stance force variable of the step
-            const int before = (ci > 0 ? f0 : 0) + (ci > 1 ? f1 : 0) + (ci > 2 ? f2 : 0);   // stance contacts before ci
-            const int rank = 3 * before + ax;                                                // g row of this lane's variable
-            // variable of g row rl: contact = the (rl / 3)-th stance contact
-            const int want = rl / 3;
-            int cc = -1, seen = 0;
-            if (f0) { if (seen == want && cc < 0) cc = 0; ++seen; }
-            if (f1) { if (seen == want && cc < 0) cc = 1; ++seen; }
-            if (f2) { if (seen == want && cc < 0) cc = 2; ++seen; }
-            if (f3) { if (seen == want && cc < 0) cc = 3; ++seen; }
-            const int ug = (cc >= 0 ? 3 * cc : 0) + (rl % 3);        // variable (0..11) of g row rl
-#pragma unroll
-            for (int i = 0; i < 6; ++i) vrow[i] = (active_g && (6 * h + i == ug)) ? 1.0 : 0.0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) vcol[r] = (active_u && r == rank) ? 1.0 : 0.0;
-            bjv[0] = 0.0; bjv[1] = 0.0; bjv[2] = 0.0; bjv[3] = 0.0; bsel = active_u ? rank : 0;
-            if constexpr (BD_EXPLICIT) {
-#pragma unroll
-                for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] = 0.0;
-            }
+            const int ug = ug_id;
+            if constexpr (!VBD_LATE) form_vbd_identity();
             if (stepok && active_g) {
                 const double dd = ((rl % 3) < 2) ? dxy : dz;
 #pragma unroll
@@ -952,6 +998,15 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     __syncthreads();
     SRBDQP_STAMP(a, b, 6);
 
+    if constexpr (VBD_LATE) {   // rows / columns of V and Bd now that the accumulator tiles are gone (see phase E)
+        if (wrench) {
+            const double* E4 = sm + S::o_e4 + 21 * js;
+            form_vbd([&](int r, int c) -> double { const int hi = r > c ? r : c, lo = r > c ? c : r; return E4[(hi * (hi + 1)) / 2 + lo]; });
+        } else {
+            form_vbd_identity();
+        }
+        asm volatile("" ::: "memory");   // keep the reads of the T^-1 rows below this block (their 60 registers)
+    }
     // ================= half rows of T^-1 (in the tiles' type), then x_q = -K^-1 q accumulated in fp64 =================
     const int CH = 2 * ((n_g + 3) / 4);
     TT kin64[CHMAX];
@@ -981,8 +1036,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             double* vb = sm + S::o_vb;
             for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
             __syncthreads();
-            if constexpr (BD_EXPLICIT) xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, vsoff, vssel, [] {});
-            else xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bjv, vsoff, vssel, [] {});
+            double vrd[6], vcd[6];
+            [[maybe_unused]] double bdd[12];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { vrd[i] = (double)vrow[i]; vcd[i] = (double)vcol[i]; }
+            if constexpr (BD_EXPLICIT && !VBD_LATE) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) bdd[i] = (double)bdrow[i];
+                xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bdd, vsoff, vssel, [] {});
+            } else {
+                xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {});
+            }
             xq = active_u ? xq : 0.0;
             __syncthreads();
             if constexpr (sizeof(TT) == 4) {
@@ -1000,7 +1064,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const double rres = active_u ? fma(dl, xq, gtg + qv) : 0.0;
                 for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
                 __syncthreads();
-                const double dxq = apply_kinv<double, CHMAX>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrow, vcol, bdrow, vsoff, vssel, [] {});
+                const double dxq = apply_kinv<double, CHMAX>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {});
                 xq = active_u ? xq + dxq : 0.0;
                 __syncthreads();
             }

@@ -19,7 +19,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU" \
            "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_CVT" \
-           "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F64"; do
+           "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F64" \
+           "SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64"; do
     i=$((i+1))
     if ! timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 "$R/bench.py" "${BENCH_ARGS[@]}" --no-cpu-baseline --no-latency > "$OUT/g$i.log" 2>&1; then
         echo "group $i FAILED ($grp)"; tail -5 "$OUT/g$i.log"; exit 1
