@@ -41,6 +41,10 @@ def main():
         simd_quads = 1024 * xcd_cycles / 4.0
         fl64 = (2 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")) * 64
         fl32 = (2 * g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32")) * 64
+        # SQ_INSTS_VALU_FLOPS_FP32/64 (flops per lane, summed over wave instructions) count a packed v_pk_fma_f32 as 4: the
+        # instruction counters above see it once.  Checked on the fp64 one-wave kernel (no packed code): both agree to 1 %.
+        if g("SQ_INSTS_VALU_FLOPS_FP32") > 0: fl32 = g("SQ_INSTS_VALU_FLOPS_FP32") * 64
+        if g("SQ_INSTS_VALU_FLOPS_FP64") > 0: fl64 = g("SQ_INSTS_VALU_FLOPS_FP64") * 64
         flmf = g("SQ_INSTS_MFMA") * 2048
         kk = {"rocprof_kernel_trace": stats[k],
               "counters_mean_per_dispatch": {n: v for n, v in c.items() if not n.startswith("_")},
@@ -99,8 +103,8 @@ def main():
                       "bound": bound,
                       "utilisation": {"valu_busy": vu, "mfma_busy": mu, "lds_busy": lu, "hbm_frac_of_8TBps": hbm_frac, "wave_time_split": ws,
                                       "lds_bank_conflict_share": d0["lds_bank_conflict_share"], "clock_GHz": d0["clock_GHz"]},
-                      "note": "issued flops from the PMC counters: (FMA x 2 + ADD + MUL) x 64 lanes per wave instruction (fp64 + fp32, EXEC-masked lanes "
-                              "counted) + MFMA x 2048; the useful share is lower (masked lanes, padded tiles)"},
+                      "note": "issued flops from the PMC counters: SQ_INSTS_VALU_FLOPS_FP32/FP64 x 64 lanes (= (FMA x 2 + ADD + MUL) per wave instruction, "
+                              "packed fp32 instructions counted twice; EXEC-masked lanes counted) + MFMA x 2048; the useful share is lower (masked lanes, padded tiles)"},
          "kernels": kernels,
          "notes": "SQ_* are summed over the chip; SQ_ACTIVE_INST_*/SQ_WAVE_CYCLES/SQ_WAIT_* are in 4-cycle quads; GRBM_GUI_ACTIVE is summed over the 8 XCDs."}
     json.dump(d, open(out, "w"), indent=1)
