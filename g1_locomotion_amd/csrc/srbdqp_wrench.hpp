@@ -349,15 +349,16 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             Tm[6] = 0.0; Tm[7] = 0.0; Tm[8] = 1.0;
         }
         if (t == BT - 1) {   // presolve bookkeeping: g coordinates per step (serial over <= 24 steps)
-            int off = 0, na = 0;
+            int off = 0, na = 0, allw = 1;
             for (int k = 0; k < N; ++k) {
                 const int c = sct[4 * k] + sct[4 * k + 1] + sct[4 * k + 2] + sct[4 * k + 3];
                 const int g = (c >= 3) ? 6 : 3 * c;
+                allw &= (c >= 3) ? 1 : 0;
                 igsz[k] = g; igoff[k] = off; iwr[k] = (c >= 3) ? 1 : 0;
                 for (int r = 0; r < g; ++r) gstep[off + r] = (uint8_t)k;
                 off += g; na += c;
             }
-            igoff[N] = off; imisc[0] = off; imisc[1] = na;
+            igoff[N] = off; imisc[0] = off; imisc[1] = na; iwr[N] = allw;   // iwr[N]: every step in wrench coordinates
         }
         __syncthreads();
         if (t < 9) {
@@ -583,14 +584,12 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         if (f3) { if (seen == want && cc < 0) cc = 3; ++seen; }
         ug_id = (cc >= 0 ? 3 * cc : 0) + (rl % 3);
     }
-    // registers of V and Bd of a wrench step from E^-1; E(r, c, dynamic row, dynamic column) reads an entry (register
-    // select chains in phase E, LDS for the late formation: no 36-double matrix in registers there)
-    auto form_vbd = [&](auto&& E) {
+    // registers of V and Bd of a wrench step from er = row rl of E^-1 and yv = E^-1 omega_u, omega_u = [J[:, ul]; e_ax]
+    // (the callers form the two from the register matrix in phase E, from the LDS triangle for the late formation; E^-1
+    // itself must not be captured here: a by-reference capture turns its select chains into an indexed scratch array)
+    auto form_vbd = [&](const double (&er)[6], const double (&yv)[6]) __attribute__((always_inline)) {
         const double* Jj = sm + S::o_J + js * 36;
         const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
-        double er[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) er[c] = E(rl, c);
         // V[rl][6 h + i] = wgt (er[0..2] . J[:, u'] + er[3 + a'])
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -599,15 +598,10 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             const double wgt = flc * (((i % 3) < 2) ? idxy : idz);
             vrow[i] = (VS)(wgt * (er[0] * Jj[u2] + er[1] * Jj[12 + u2] + er[2] * Jj[24 + u2] + er[3 + (i % 3)]));
         }
-        // y = E^-1 omega_u, omega_u = [J[:, ul]; e_ax]
         const double wu = active_u ? ((ax < 2) ? idxy : idz) : 0.0;
         const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
-        double yv[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            yv[r] = E(r, 0) * j0 + E(r, 1) * j1 + E(r, 2) * j2 + E(r, 3 + ax);
-            vcol[r] = (VS)(wu * yv[r]);
-        }
+        for (int r = 0; r < 6; ++r) vcol[r] = (VS)(wu * yv[r]);
         bjv[0] = j0; bjv[1] = j1; bjv[2] = j2; bjv[3] = wu; bsel = 3 + ax;
         if constexpr (BD_EXPLICIT) {
 #pragma unroll
@@ -619,7 +613,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
     };
     // ... of a force-variable step: V = the selection of the stance variables, Bd = 0
-    auto form_vbd_identity = [&]() {
+    auto form_vbd_identity = [&]() __attribute__((always_inline)) {
         const int rank = 3 * before_ci + ax;                         // g row of this lane's variable
 #pragma unroll
         for (int i = 0; i < 6; ++i) vrow[i] = (active_g && (6 * h + i == ug_id)) ? VS(1) : VS(0);
@@ -724,14 +718,14 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                         if (3 * h + i <= rl) E4[(rl * (rl + 1)) / 2 + 3 * h + i] = h ? er[3 + i] : er[i];
                 }
             } else {
-                form_vbd([&](int r, int c) -> double {   // r or c may be a run-time index: select chains over the register matrix
-                    double v = Ei[0][0];
+                const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
+                double yv[6];
 #pragma unroll
-                    for (int p = 0; p < 6; ++p)
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) v = (r == p && c == q) ? Ei[p][q] : v;
-                    return v;
-                });
+                for (int r = 0; r < 6; ++r) {
+                    const double ea = (ax == 0) ? Ei[r][3] : (ax == 1) ? Ei[r][4] : Ei[r][5];
+                    yv[r] = Ei[r][0] * j0 + Ei[r][1] * j1 + Ei[r][2] * j2 + ea;
+                }
+                form_vbd(er, yv);
             }
         } else {
             // identity coordinates: g row r <-> the r-th stance force variable of the step
@@ -773,6 +767,34 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     {
         const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
         const double* ZT = sm + S::o_zt;
+        if (sizeof(TT) == 4 && iwr[N] != 0) {   // (fp32 tiles only: in the fp64 instantiations the second copy of the loop gained nothing)
+            // every step in wrench coordinates (full double support, configs[2]): step and coordinate of a g row are r / 6 and
+            // r % 6, every entry is a table look-up -- no index tables, no 6-vectors (the general loop below spends most of its
+            // 38 k cycles on three levels of dependent LDS index reads per entry)
+#pragma unroll
+            for (int s = 0; s < TS; ++s) {
+                acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
+                if (ta[s] >= 0) {
+                    const int c = 16 * tb[s] + mcol;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 16 * ta[s] + crow<TT>(kq, q);
+                        const bool in = (r < n_g) && (c < n_g);
+                        const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;
+                        const int j = lo / 6, mm = hi / 6, l1 = lo - 6 * j, l2 = hi - 6 * mm;
+                        const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
+                        const int Ls = N - mm, d = mm - j;
+                        const double sp = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2)), ls = (double)Ls;
+                        const int a1 = (l1 >= 3) ? l1 - 3 : 0;
+                        const double dg = SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls;
+                        const double v = (l1 < 3 && l2 < 3) ? M[3 * l1 + l2] : ((l1 >= 3 && l1 == l2) ? dg : 0.0);
+                        double val = s2 * v;
+                        if (j == mm) val += sm[S::o_ei + 36 * j + 6 * l1 + l2];
+                        acc[s][q] = (TT)(in ? val : ((r == c) ? 1.0 : 0.0));     // padding -> identity
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
@@ -1001,7 +1023,15 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     if constexpr (VBD_LATE) {   // rows / columns of V and Bd now that the accumulator tiles are gone (see phase E)
         if (wrench) {
             const double* E4 = sm + S::o_e4 + 21 * js;
-            form_vbd([&](int r, int c) -> double { const int hi = r > c ? r : c, lo = r > c ? c : r; return E4[(hi * (hi + 1)) / 2 + lo]; });
+            auto tri = [&](int r, int c) -> double { const int hi = r > c ? r : c, lo = r > c ? c : r; return E4[(hi * (hi + 1)) / 2 + lo]; };
+            const double* Jj = sm + S::o_J + js * 36;
+            const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
+            double er[6], yv[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) er[c] = tri(rl, c);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) yv[r] = tri(r, 0) * j0 + tri(r, 1) * j1 + tri(r, 2) * j2 + tri(r, 3 + ax);
+            form_vbd(er, yv);
         } else {
             form_vbd_identity();
         }
