@@ -207,17 +207,31 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
                 for (int i = 0; i < 6; ++i) { const R2 v = s2[i]; wg[2 * i] = v[0]; wg[2 * i + 1] = v[1]; }
             }
         }
-        R2 vp2 = (R2){R(0), R(0)};
+        // (2-vectors = packed fp32 instructions; in fp64 they only lengthen the dependency chains: N = 24 ran 12 % slower)
+        R vp;
+        if constexpr (sizeof(R) == 4) {
+            R2 vp2 = (R2){R(0), R(0)};
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            vp2 = __builtin_elementwise_fma((R2){vrow[2 * i], vrow[2 * i + 1]}, h ? (R2){wg[6 + 2 * i], wg[7 + 2 * i]} : (R2){wg[2 * i], wg[2 * i + 1]}, vp2);
-        const R vp = vp2[0] + vp2[1];
+            for (int i = 0; i < 3; ++i)
+                vp2 = __builtin_elementwise_fma((R2){vrow[2 * i], vrow[2 * i + 1]}, h ? (R2){wg[6 + 2 * i], wg[7 + 2 * i]} : (R2){wg[2 * i], wg[2 * i + 1]}, vp2);
+            vp = vp2[0] + vp2[1];
+        } else {
+            vp = R(0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) vp = fma(vrow[i], h ? wg[6 + i] : wg[i], vp);
+        }
         const R v = vp + dpp_swap1(vp);
         if (active_g && h == 0) vb[Rrow] = v;
-        R2 xb2 = (R2){R(0), R(0)};
+        if constexpr (sizeof(R) == 4) {
+            R2 xb2 = (R2){R(0), R(0)};
 #pragma unroll
-        for (int i = 0; i < 6; ++i) xb2 = __builtin_elementwise_fma((R2){bj[2 * i], bj[2 * i + 1]}, (R2){wg[2 * i], wg[2 * i + 1]}, xb2);
-        xb = xb2[0] + xb2[1];
+            for (int i = 0; i < 6; ++i) xb2 = __builtin_elementwise_fma((R2){bj[2 * i], bj[2 * i + 1]}, (R2){wg[2 * i], wg[2 * i + 1]}, xb2);
+            xb = xb2[0] + xb2[1];
+        } else {
+            xb = R(0);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) xb = fma(bj[i], wg[i], xb);
+        }
     }
     __syncthreads();
     hook();
@@ -276,10 +290,16 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
     {
         const R* src = tbw + 6 * sg;                        // 6 sg elements: 8-byte aligned (float), 16-byte (double)
         const R2* s2 = reinterpret_cast<const R2*>(src);
-        R2 x2 = (R2){xb, R(0)};
+        if constexpr (sizeof(R) == 4) {
+            R2 x2 = (R2){xb, R(0)};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) x2 = __builtin_elementwise_fma((R2){vcol[2 * i], vcol[2 * i + 1]}, s2[i], x2);
-        xt = x2[0] + x2[1];
+            for (int i = 0; i < 3; ++i) x2 = __builtin_elementwise_fma((R2){vcol[2 * i], vcol[2 * i + 1]}, s2[i], x2);
+            xt = x2[0] + x2[1];
+        } else {
+            xt = xb;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const R2 vv = s2[i]; xt = fma(vcol[2 * i], vv[0], xt); xt = fma(vcol[2 * i + 1], vv[1], xt); }
+        }
     }
     asm volatile("" ::: "memory");
     return xt;
@@ -1176,25 +1196,38 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             const bool pretest = (ph == a.check_every - 1);
             const R xt = active_u ? xqr + kw : R(0);
             const R fzt = bperm(xt, cbase + 2);
-            // rows A and B of the contact's cone block as one 2-vector: packed fp32 instructions in the fp32 kernels
-            typedef R R2v __attribute__((ext_vector_type(2)));
-            const R2v alpha2 = (R2v){alpha, alpha}, oma2 = (R2v){oma, oma}, rho2 = (R2v){rhoA, rhoB};
-            const R2v z2 = (R2v){zA, zB}, y2 = (R2v){yA, yB};
-            const R2v zt2 = __builtin_elementwise_fma((R2v){-mucA, -mu}, (R2v){fzt, fzt}, (R2v){xt, -xt});
-            const R2v nu2 = __builtin_elementwise_fma(rho2, zt2 - z2, y2);
-            const R2v zh2 = __builtin_elementwise_fma(alpha2, zt2, oma2 * z2);
-            const R2v zc2 = __builtin_elementwise_fma(y2, (R2v){irho, irho}, zh2);
-            const R znA = rmin(rmax(zc2[0], loA), hiA), znB = rmin(rmax(zc2[1], loB), hiB);
-            const R2v zn2 = (R2v){znA, znB};
-            const R2v yn2 = __builtin_elementwise_fma(rho2, zh2 - zn2, y2);
-            yA = yn2[0]; yB = yn2[1];
-            zA = znA; zB = znB;
-            const R2v ax2 = __builtin_elementwise_fma(alpha2, zt2, oma2 * (R2v){axA, axB});
-            axA = ax2[0]; axB = ax2[1];
-            const R2v spx2 = __builtin_elementwise_fma(alpha2, nu2, oma2 * (R2v){spxA, spxB});
-            spxA = spx2[0]; spxB = spx2[1];
-            const R2v aw2 = __builtin_elementwise_fma(rho2, zn2, -yn2);
-            const R atw = At(aw2[0], aw2[1]);
+            R atw;
+            if constexpr (sizeof(R) == 4) {
+                // rows A and B of the contact's cone block as one 2-vector: packed fp32 instructions in the fp32 kernels
+                typedef R R2v __attribute__((ext_vector_type(2)));
+                const R2v alpha2 = (R2v){alpha, alpha}, oma2 = (R2v){oma, oma}, rho2 = (R2v){rhoA, rhoB};
+                const R2v z2 = (R2v){zA, zB}, y2 = (R2v){yA, yB};
+                const R2v zt2 = __builtin_elementwise_fma((R2v){-mucA, -mu}, (R2v){fzt, fzt}, (R2v){xt, -xt});
+                const R2v nu2 = __builtin_elementwise_fma(rho2, zt2 - z2, y2);
+                const R2v zh2 = __builtin_elementwise_fma(alpha2, zt2, oma2 * z2);
+                const R2v zc2 = __builtin_elementwise_fma(y2, (R2v){irho, irho}, zh2);
+                const R znA = rmin(rmax(zc2[0], loA), hiA), znB = rmin(rmax(zc2[1], loB), hiB);
+                const R2v zn2 = (R2v){znA, znB};
+                const R2v yn2 = __builtin_elementwise_fma(rho2, zh2 - zn2, y2);
+                yA = yn2[0]; yB = yn2[1];
+                zA = znA; zB = znB;
+                const R2v ax2 = __builtin_elementwise_fma(alpha2, zt2, oma2 * (R2v){axA, axB});
+                axA = ax2[0]; axB = ax2[1];
+                const R2v spx2 = __builtin_elementwise_fma(alpha2, nu2, oma2 * (R2v){spxA, spxB});
+                spxA = spx2[0]; spxB = spx2[1];
+                const R2v aw2 = __builtin_elementwise_fma(rho2, zn2, -yn2);
+                atw = At(aw2[0], aw2[1]);
+            } else {
+                const R ztA = fma(-mucA, fzt, xt), ztB = fma(-mu, fzt, -xt);
+                const R nuA = fma(rhoA, ztA - zA, yA), nuB = fma(rhoB, ztB - zB, yB);
+                const R zhA = fma(alpha, ztA, oma * zA), zhB = fma(alpha, ztB, oma * zB);
+                const R znA = rmin(rmax(fma(yA, irho, zhA), loA), hiA), znB = rmin(rmax(fma(yB, irho, zhB), loB), hiB);
+                yA = fma(rhoA, zhA - znA, yA); yB = fma(rhoB, zhB - znB, yB);
+                zA = znA; zB = znB;
+                axA = fma(alpha, ztA, oma * axA); axB = fma(alpha, ztB, oma * axB);
+                spxA = fma(alpha, nuA, oma * spxA); spxB = fma(alpha, nuB, oma * spxB);
+                atw = At(fma(rhoA, zA, -yA), fma(rhoB, zB, -yB));
+            }
             cpx = fma(alpha, sigma * (x - xt), oma * cpx);
             x = fma(alpha, xt, oma * x);
             wv = fma(sigma, x, atw);
