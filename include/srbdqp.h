@@ -86,8 +86,8 @@ typedef struct srbdqp_config {
                                    * (clipped to [rho/10, 5 rho]) and continues from its own (x, y) until max_iter
                                    * iterations in total; iters[] counts both passes.  < 0 or >= max_iter = off; 0 (default) =
                                    * automatic: 100 (125 above N = 16) on the general kernel, off on the others.  Runs as
-                                   * a second launch over the QPs the first pass left at its cap (device-side selection,
-                                   * every one of them is continued). */
+                                   * a second launch over the same grid: the workgroup of a QP the first pass left at its
+                                   * cap continues it, every other one leaves at once (every capped QP is continued). */
     int32_t reserved0;
     double dt;                    /* run_simulation.py:169 */
     double mass;                  /* wbid.py:291 model.getMass() */
@@ -144,9 +144,11 @@ int srbdqp_solve_batch_device_f64(srbdqp_handle* h, int32_t B,
                                   int32_t* status, int32_t* iters, void* stream);
 
 /* The same two calls with fp32 buffers (BASELINE.json configs[2]: "Batch=65536, N=20, 4-contact double-support, fp32").
- * Every array above becomes float; contact stays uint8.  The set-up (closed-form assembly, Cholesky factor, inverse) is
- * computed in fp64 on chip; the ADMM iterations run in fp32 on the general kernel (SRBDQP_KERNEL_WRENCH), whatever
- * srbdqp_config.kernel says.  Tolerances reachable in fp32: see DESIGN.md section 3. */
+ * Every array above becomes float; contact stays uint8.  The closed-form assembly is computed in fp64 on chip; the ADMM
+ * iterations run in fp32 on the general kernel (SRBDQP_KERNEL_WRENCH), whatever srbdqp_config.kernel says.  The wrench-space
+ * matrix T is factored and inverted in fp64 tiles, or -- calls of >= 512 QPs, for the QPs whose steps all have 0 or >= 3 stance
+ * contacts -- in fp32 tiles with one fp64 refinement step of x_q (SRBDQP_FLAG_F64_TILES / _F32_TILES force either): such a call
+ * is two launches over the same grid.  Tolerances reachable in fp32: see DESIGN.md sections 2 and 3. */
 int srbdqp_solve_batch_f32(srbdqp_handle* h, int32_t B,
                            const float* x0, const float* x_ref, const float* foot,
                            const uint8_t* contact, const float* pcom,
