@@ -146,7 +146,7 @@ def test_wrench_f32_matches_twin_and_exact_optimum(torch_first, built_lib, N, sc
         assert kr["primal"] <= 1e-4 and kr["stationarity"] <= 1e-3 * max(1.0, np.abs(ref["qp"]["q"]).max()), kr
 
 
-@pytest.mark.parametrize("N,schedule,B", [(20, "double", 12), (24, "double", 4), (16, "three", 6), (10, "double", 8), (4, "double", 6), (20, "mixed", 8)])
+@pytest.mark.parametrize("N,schedule,B", [(20, "double", 12), (24, "double", 4), (16, "three", 6), (12, "double", 6), (10, "double", 8), (8, "three", 6), (4, "double", 6), (20, "mixed", 8)])
 def test_wrench_f32_tiles_match_twin_and_exact_optimum(torch_first, built_lib, N, schedule, B):
     """The fp32-tile instantiation (what an _f32 call of >= 512 QPs runs for the QPs whose steps all have 0 or >= 3 stance
     contacts; SRBDQP_FLAG_F32_TILES forces it at test sizes): T factored and inverted in fp32 MFMA tiles, x_q refined
