@@ -382,15 +382,15 @@ struct Carver {
 };
 
 // Iteration at which a solve of this handle re-balances rho (0 = never).  srbdqp_config.rho_restart_iter: > 0 that
-// iteration, < 0 off, 0 = automatic: 100 (125 above N = 16) on the general kernel (its long horizons have a 1 - 10 % tail
-// of slow QPs, and at its batch sizes the second launch costs 3 - 5 %), off elsewhere (the N = 10 batch kernels run
-// 0.2 ms steps, where a second launch costs a quarter of the throughput: DESIGN.md).
+// iteration, < 0 off, 0 = automatic: 100 (125 above N = 16) at N > 10 on every kernel -- the long horizons have a 1 - 2 % tail
+// of slow QPs (N = 20 single support: 98.4 % solved without, 99.3 % with) and at their 3 - 20 ms steps the second launch costs
+// 3 - 5 % -- off at N <= 10 (the batch kernels run 0.16 ms steps, where a second launch costs 15 %: DESIGN.md).
 inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B) {
     const srbdqp_config& c = h->cfg;
     const int rk = resolve_kernel(c);
     if (rk != SRBDQP_KERNEL_COMPACT && rk != SRBDQP_KERNEL_WRENCH) return 0;   // v0 / v1 have no restart
     int r = c.rho_restart_iter;
-    if (r == 0) r = (uses_wrench(h, maxs, B) && c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : 0;
+    if (r == 0) r = (c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : 0;
     return (r > 0 && r < c.max_iter) ? r : 0;
 }
 

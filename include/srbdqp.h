@@ -85,7 +85,7 @@ typedef struct srbdqp_config {
                                    * iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual))
                                    * (clipped to [rho/10, 5 rho]) and continues from its own (x, y) until max_iter
                                    * iterations in total; iters[] counts both passes.  < 0 or >= max_iter = off; 0 (default) =
-                                   * automatic: 100 (125 above N = 16) on the general kernel, off on the others.  Runs as
+                                   * automatic: 100 (125 above N = 16) at N > 10, off at N <= 10.  Runs as
                                    * a second launch over the same grid: the workgroup of a QP the first pass left at its
                                    * cap continues it, every other one leaves at once (every capped QP is continued). */
     int32_t reserved0;

@@ -28,6 +28,7 @@ def torch_first():
 
 def _engine(N, **kw):
     from g1_locomotion_amd import BatchMPC
+    kw.setdefault("rho_restart_iter", -1)       # off unless the test is about it (the default at N > 10 is 100 / 125)
     return BatchMPC(horizon=N, **kw)
 
 

@@ -1,5 +1,5 @@
 """Throughput of one engine on device-resident batches for other contact schedules / horizons than the headline config.
-    python tools/schedule_bench.py [schedule=double] [N=10] [B=4096] [kernel=auto|compact|wave|wrench] [f32=0]
+    python tools/schedule_bench.py [schedule=double] [N=10] [B=4096] [kernel=auto|compact|wave|wrench] [f32=0] [rho_restart_iter=0 (library default)]
 Steps rotate over 4 distinct batches on 2 streams with the longest-first hint, as bench.py does."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,13 +11,14 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 kern = sys.argv[4] if len(sys.argv) > 4 else "auto"
 f32 = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
+restart = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 dev = torch.device("cuda", 0)
 tdt = torch.float32 if f32 else torch.float64
 NB, S = 4, 2
 d = [[torch.from_numpy(v).to(dev).to(tdt) if v.dtype == np.float64 else torch.from_numpy(v).to(dev) for v in synth.synthetic_batch(B, N, seed=77 + j, schedule=sched)] for j in range(NB)]
 maxs = 2 if sched == "single" else 4
 kid = {"auto": _lib.KERNEL_AUTO, "compact": _lib.KERNEL_COMPACT, "wave": _lib.KERNEL_WAVE, "wrench": _lib.KERNEL_WRENCH, "split": _lib.KERNEL_SPLIT}[kern]
-eng = BatchMPC(horizon=N, max_contacts_per_step=maxs, kernel=kid)
+eng = BatchMPC(horizon=N, max_contacts_per_step=maxs, kernel=kid, rho_restart_iter=restart)
 streams = [torch.cuda.Stream() for _ in range(S)]
 u = [torch.empty((B, N, 12), dtype=tdt, device=dev) for _ in range(NB)]
 it = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NB)]
