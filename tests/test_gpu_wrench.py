@@ -202,6 +202,27 @@ def test_f32_tile_flags_select_the_factorisation(torch_first, built_lib):
     assert (res["f32"]["status"] == orc.STATUS_SOLVED).all()
 
 
+def test_f32_host_call_above_the_tile_threshold_takes_both_launches(torch_first, built_lib):
+    """A host-buffer _f32 call of >= 512 QPs with mixed patterns: the eligible QPs go through the fp32-tile launch, the others
+    through the fp64-tile one (no flag set).  Every QP is solved by exactly one of them: statuses / iteration counts are
+    written once, the eligible QPs differ from an all-fp64-tile solve only within the twin tolerance and the others not at all."""
+    from g1_locomotion_amd import _lib
+    N, B = 12, 640
+    x0, xr, ft, ct = _batch(B, N, 71, "mixed")
+    ct[::2] = 1                                      # every other QP in full double support
+    with _engine(N) as eng:
+        auto = eng.solve(x0, xr, ft, ct, dtype=np.float32)
+    with _engine(N, flags=_lib.FLAG_F64_TILES) as eng:
+        ref = eng.solve(x0, xr, ft, ct, dtype=np.float32)
+    elig = np.array([orc.fp32_tiles_ok(ct[b]) for b in range(B)])
+    assert elig.sum() == B // 2
+    assert (auto["status"] == orc.STATUS_SOLVED).mean() >= 0.99 and (auto["iters"] > 0).all()
+    assert np.array_equal(auto["u"][~elig], ref["u"][~elig]) and np.array_equal(auto["iters"][~elig], ref["iters"][~elig])
+    both = elig & (auto["status"] == orc.STATUS_SOLVED) & (ref["status"] == orc.STATUS_SOLVED)
+    assert not np.array_equal(auto["u"][elig], ref["u"][elig])
+    assert np.abs(auto["u"][both].astype(np.float64) - ref["u"][both]).max() <= TOL32_TWIN_N
+
+
 def test_wrench_warm_start_and_edge_cases(torch_first, built_lib):
     N, B = 20, 6
     x0, xr, ft, ct = _batch(B, N, 77, "double")
