@@ -234,7 +234,8 @@ def main(argv=None):
     kernel_ms = None
     if not stub:
         iso = []
-        for i in range(5):
+        n_iso = 50 if args.config == 1 else 5       # ~12 ms / ~80 ms of isolated solves: a stable average, and the GPU is at its
+        for i in range(n_iso):                       # sustained clocks when the timed region starts (disclosed in kernel_ms_note)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             k = base + S * NO * (i + 1)                                # a multiple of S and NO: stream 0, output set 0
             e0.record(streams[0]); step(k); e1.record(streams[0])
@@ -309,9 +310,11 @@ def roofline(kname, N, B, mean_iters, kernel_ms, peak, esz, ms_per_step, S):
          "frac_executed": None, "traffic": None,
          "traffic_unit": "bytes per solve = per launch of this step's kernels (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*_pmc_summary.json)",
          "algorithmic_bytes_per_launch": abytes, "kernel": kname, "kernel_ms": kernel_ms,
-         "kernel_ms_note": "one solve at a time (5 isolated solves after warm-up, HIP events on the launch stream; with the rho "
-                           "restart on, a solve = the first pass + the selection kernel + the pass over the capped QPs); the timed "
-                           "region overlaps consecutive steps on %d streams" % S,
+         "kernel_ms_note": "one solve at a time (50 isolated solves at configs[1], 5 at configs[2], after the W warm-up steps and "
+                           "before the timed region -- so the GPU is also at its sustained clocks when the K timed steps start; "
+                           "HIP events on the launch stream; with the rho restart on, a solve = the first pass + the pass in which "
+                           "the capped QPs continue; an _f32 solve of >= 512 QPs = the fp32-tile and the fp64-tile launch); the "
+                           "timed region overlaps consecutive steps on %d streams" % S,
          "algorithmic_flops_per_qp": algorithmic_flops(N, mean_iters),
          "hbm_algorithmic_GBps": hbm_gbs, "hbm_frac_of_8TBps": hbm_gbs / 8000.0,
          # the same count over the DRIVER-visible step time (the streams overlap steps): a value > 1 here would say that the
