@@ -33,11 +33,18 @@ EXPORTS = (
     "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
+    "srbdqp_mpc_inputs_f64", "srbdqp_mpc_inputs_device_f64",
 )
 
 
 class SrbdqpError(RuntimeError):
     pass
+
+
+class Gait(C.Structure):
+    """srbdqp_gait (include/srbdqp_cascade.h)."""
+    _fields_ = [("struct_size", C.c_int32), ("period_steps", C.c_int32), ("double_support_steps", C.c_int32), ("reserved0", C.c_int32),
+                ("com_target", C.c_double * 3), ("hip_offset_y", C.c_double)]
 
 
 class Config(C.Structure):
@@ -154,6 +161,10 @@ def load():
     lib.srbdqp_wbid_reference_f64.restype = C.c_int
     lib.srbdqp_wbid_reference_device_f64.argtypes = [H, C.c_int64, dp, dp, dp, C.c_int32, dp, dp, dp, dp, C.c_void_p]
     lib.srbdqp_wbid_reference_device_f64.restype = C.c_int
+    lib.srbdqp_mpc_inputs_f64.argtypes = [H, C.c_int64, dp, dp, dp, dp, C.c_void_p, C.POINTER(Gait), dp, dp, C.c_void_p, dp, dp]
+    lib.srbdqp_mpc_inputs_f64.restype = C.c_int
+    lib.srbdqp_mpc_inputs_device_f64.argtypes = [H, C.c_int64, dp, dp, dp, dp, C.c_void_p, C.POINTER(Gait), dp, dp, C.c_void_p, dp, dp, C.c_void_p]
+    lib.srbdqp_mpc_inputs_device_f64.restype = C.c_int
     lib.srbdqp_version.argtypes = []
     lib.srbdqp_version.restype = C.c_char_p
     _lib = lib

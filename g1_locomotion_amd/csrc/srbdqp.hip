@@ -1268,4 +1268,78 @@ int srbdqp_wbid_reference_f64(srbdqp_handle* h, int64_t B, const double* x_next,
     return SRBDQP_OK;
 }
 
+int srbdqp_mpc_inputs_device_f64(srbdqp_handle* h, int64_t B, const double* x0, const double* feet, const double* stamp,
+                                 const double* v_ref, const uint8_t* standing, const srbdqp_gait* gait,
+                                 double* x_ref, double* foot, uint8_t* contact, double* pcom, double* landing, void* stream) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!x0 || !feet || !stamp || !v_ref || !x_ref || !foot || !contact || !pcom))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (!gait || gait->struct_size != (int32_t)sizeof(srbdqp_gait) || gait->period_steps < 1 || gait->double_support_steps < 0 ||
+        gait->double_support_steps > gait->period_steps) { h->err = "invalid srbdqp_gait (struct_size, 1 <= period_steps, 0 <= double_support_steps <= period_steps)"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    srbdqp::MpcInputsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x0 = x0; a.feet = feet; a.stamp = stamp; a.v_ref = v_ref; a.standing = standing;
+    a.x_ref = x_ref; a.foot = foot; a.contact = contact; a.pcom = pcom; a.landing = landing;
+    for (int i = 0; i < 3; ++i) a.com_target[i] = gait->com_target[i];
+    a.hip_offset_y = gait->hip_offset_y; a.dt = h->cfg.dt;
+    a.N = h->cfg.horizon; a.period = gait->period_steps; a.ds = gait->double_support_steps;
+    a.B = (long long)B;
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+    const long long tiles = ((long long)B + 31) / 32;                   // one tile of 32 robots per workgroup pass
+    const dim3 grid((unsigned)(tiles < 1 ? 1 : (tiles > 256 * 32 ? 256 * 32 : tiles)));
+    switch (h->cfg.horizon) {
+        case 4: hipLaunchKernelGGL(srbdqp::srbdqp_mpc_inputs_kernel<4>, grid, dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL(srbdqp::srbdqp_mpc_inputs_kernel<8>, grid, dim3(256), 0, st, a); break;
+        case 10: hipLaunchKernelGGL(srbdqp::srbdqp_mpc_inputs_kernel<10>, grid, dim3(256), 0, st, a); break;
+        case 12: hipLaunchKernelGGL(srbdqp::srbdqp_mpc_inputs_kernel<12>, grid, dim3(256), 0, st, a); break;
+        case 16: hipLaunchKernelGGL(srbdqp::srbdqp_mpc_inputs_kernel<16>, grid, dim3(256), 0, st, a); break;
+        case 20: hipLaunchKernelGGL(srbdqp::srbdqp_mpc_inputs_kernel<20>, grid, dim3(256), 0, st, a); break;
+        case 24: hipLaunchKernelGGL(srbdqp::srbdqp_mpc_inputs_kernel<24>, grid, dim3(256), 0, st, a); break;
+        default: h->err = "unsupported horizon"; return SRBDQP_E_INVALID;
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->kname = "mpc_inputs_f64";
+    return SRBDQP_OK;
+}
+
+int srbdqp_mpc_inputs_f64(srbdqp_handle* h, int64_t B, const double* x0, const double* feet, const double* stamp,
+                          const double* v_ref, const uint8_t* standing, const srbdqp_gait* gait,
+                          double* x_ref, double* foot, uint8_t* contact, double* pcom, double* landing) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || (B > 0 && (!x0 || !feet || !stamp || !v_ref || !x_ref || !foot || !contact || !pcom))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t b = (size_t)B, N = (size_t)h->cfg.horizon;
+    double *dx0, *dfe, *dst, *dv, *dxr, *dft, *dpc, *dlp;
+    uint8_t *dsd, *dct;
+    auto carve = [&](Carver& c) {
+        dx0 = c.take<double>(b * 13); dfe = c.take<double>(b * 12); dst = c.take<double>(b); dv = c.take<double>(b * 2);
+        dsd = standing ? c.take<uint8_t>(b) : nullptr;
+        dxr = c.take<double>(b * N * 13); dft = c.take<double>(b * N * 12); dct = c.take<uint8_t>(b * N * 4);
+        dpc = c.take<double>(b * N * 3); dlp = landing ? c.take<double>(b * 3) : nullptr;
+    };
+    Carver sz(nullptr);
+    carve(sz);
+    int rc = ensure_ws(h, sz.off);
+    if (rc != SRBDQP_OK) return rc;
+    Carver cv(h->ws);
+    carve(cv);
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(dx0, x0, b * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dfe, feet, b * 12 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dst, stamp, b * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dv, v_ref, b * 16, hipMemcpyHostToDevice, st));
+    if (standing) HIP_TRY(h, hipMemcpyAsync(dsd, standing, b, hipMemcpyHostToDevice, st));
+    rc = srbdqp_mpc_inputs_device_f64(h, B, dx0, dfe, dst, dv, dsd, gait, dxr, dft, dct, dpc, dlp, st);
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(x_ref, dxr, b * N * 13 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(foot, dft, b * N * 12 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(contact, dct, b * N * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(pcom, dpc, b * N * 3 * 8, hipMemcpyDeviceToHost, st));
+    if (landing) HIP_TRY(h, hipMemcpyAsync(landing, dlp, b * 3 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return SRBDQP_OK;
+}
+
 }  // extern "C"

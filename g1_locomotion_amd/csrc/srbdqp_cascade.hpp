@@ -125,4 +125,106 @@ __global__ __launch_bounds__(256) void srbdqp_wbid_reference_kernel(WbidRefArgs 
     }
 }
 
+// ---- the step before the QP: gait schedule, landing position, input horizons (include/srbdqp_cascade.h) -----------------
+struct MpcInputsArgs {
+    const double* x0;        // [B][13]
+    const double* feet;      // [B][12]
+    const double* stamp;     // [B]
+    const double* v_ref;     // [B][2]
+    const uint8_t* standing; // [B] or null
+    double* x_ref;           // [B][N][13]
+    double* foot;            // [B][N][12]
+    uint8_t* contact;        // [B][N][4]
+    double* pcom;            // [B][N][3]
+    double* landing;         // [B][3] or null
+    double com_target[3];
+    double hip_offset_y, dt;
+    int32_t N, period, ds;
+    long long B;
+};
+
+// A workgroup takes tiles of 32 consecutive robots: their 28 input doubles each are staged in LDS with coalesced loads (the
+// algorithmic minimum of reads), then the tile's outputs -- contiguous in every output array -- are written element by
+// element, 512 contiguous bytes per store instruction of a wave.  (First version: one thread per (robot, step) writing rows
+// of 13 + 12 + 3 doubles: 1.2 TB/s; one thread per output element with the inputs re-read through L2: 2.4 TB/s.)  Every
+// product and sum is a single rounded operation in the order of msgs.MpcNode.step (no fused multiply-add: the oracle is
+// compared bit for bit).
+template <int NH>   // the horizon as a compile-time constant: every index division becomes a multiply-shift
+__global__ __launch_bounds__(256) void srbdqp_mpc_inputs_kernel(MpcInputsArgs a) {
+#pragma clang fp contract(off)   // no fused multiply-add in this kernel (HIP's __dmul_rn / __dadd_rn do not prevent it)
+    constexpr int R = 32, N = NH;
+    __shared__ double sx0[R * 13], sft[R * 12], sv[R * 2];
+    __shared__ int sph[R];                                               // phase of step 0 in [0, 2 period), or -1 = standing
+    const int t = threadIdx.x;
+    const long long tiles = (a.B + R - 1) / R;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long b0 = tile * R;
+        const int nr = (int)((a.B - b0 < R) ? (a.B - b0) : R);
+        for (int i = t; i < nr * 13; i += 256) sx0[i] = a.x0[b0 * 13 + i];
+        for (int i = t; i < nr * 12; i += 256) sft[i] = a.feet[b0 * 12 + i];
+        for (int i = t; i < nr * 2; i += 256) sv[i] = a.v_ref[b0 * 2 + i];
+        if (t < nr) {   // alternating single support with a double-support overlap (msgs.AlternatingGait.contact_horizon)
+            const bool stand = a.standing && a.standing[b0 + t];
+            const long long k0 = (long long)floor(a.stamp[b0 + t] / a.dt + 1e-9);
+            long long ph = k0 % (2LL * a.period);
+            if (ph < 0) ph += 2LL * a.period;
+            sph[t] = stand ? -1 : (int)ph;
+        }
+        __syncthreads();
+        auto flags = [&](int r, int k, bool& cl, bool& cr) {
+            const int p0 = sph[r];
+            const int ph = (p0 + k) % (2 * a.period);
+            const bool stand = p0 < 0, left_stance = ph < a.period, dsup = (ph % a.period) < a.ds;
+            cl = stand || left_stance || dsup; cr = stand || !left_stance || dsup;
+        };
+        double* xr = a.x_ref + b0 * (N * 13);
+        for (int e = t; e < nr * N * 13; e += 256) {                     // x_ref[r][k][c], reference index k + 1
+            const int row = e / 13, c = e - 13 * row, r = row / N, k = row - N * r;
+            const double* x0 = sx0 + 13 * r;
+            const double vx = sv[2 * r], vy = sv[2 * r + 1];
+            const bool moving = (vx != 0.0) || (vy != 0.0);
+            const double kk = (double)(k + 1);
+            double v = 0.0;
+            if (c == 2) v = x0[2];
+            else if (c == 3) v = moving ? x0[3] + (vx * kk) * a.dt : a.com_target[0];
+            else if (c == 4) v = moving ? x0[4] + (vy * kk) * a.dt : a.com_target[1];
+            else if (c == 5) v = a.com_target[2];
+            else if (c == 9) v = vx;
+            else if (c == 10) v = vy;
+            else if (c == 12) v = x0[12];
+            xr[e] = v;
+        }
+        double* fo = a.foot + b0 * (N * 12);
+        for (int e = t; e < nr * N * 12; e += 256) {                     // foot[r][k][c]: the current contact points, repeated
+            const int row = e / 12, c = e - 12 * row, r = row / N;
+            fo[e] = sft[12 * r + c];
+        }
+        double* pc = a.pcom + b0 * (N * 3);
+        for (int e = t; e < nr * N * 3; e += 256) {                      // pcom[r][k][c]: measured CoM + the commanded drift
+            const int row = e / 3, c = e - 3 * row, r = row / N, k = row - N * r;
+            const double vc = (c < 2) ? sv[2 * r + c] : 0.0;
+            pc[e] = sx0[13 * r + 3 + c] + (vc * (double)k) * a.dt;
+        }
+        uint32_t* cw = reinterpret_cast<uint32_t*>(a.contact) + b0 * N;  // 4 flags per step = one aligned word
+        for (int row = t; row < nr * N; row += 256) {
+            const int r = row / N, k = row - N * r;
+            bool cl, cr;
+            flags(r, k, cl, cr);
+            cw[row] = (cl ? 0x00000101u : 0u) | (cr ? 0x01010000u : 0u);
+        }
+        if (a.landing && t < nr * 3) {   // Raibert-style landing point of the foot that is (or goes next) in the air
+            const int r = t / 3, c = t - 3 * r;
+            const double* x0 = sx0 + 13 * r;
+            bool cl, cr;
+            flags(r, 0, cl, cr);
+            const double T = (double)a.period * a.dt, side = cl ? -1.0 : 1.0;
+            double v = 0.0;
+            if (c == 0) v = (x0[3] + (0.5 * T) * x0[9]) + 0.03 * (x0[9] - sv[2 * r]);
+            else if (c == 1) v = ((x0[4] + side * a.hip_offset_y) + (0.5 * T) * x0[10]) + 0.03 * (x0[10] - sv[2 * r + 1]);
+            a.landing[b0 * 3 + t] = v;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace srbdqp

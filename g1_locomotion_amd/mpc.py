@@ -240,6 +240,43 @@ class BatchMPC:
         return dict(R=R, base_vel=bv, base_acc=ba, com_acc=ca, com_pos=x[:, 3:6].copy(), com_vel=x[:, 9:12].copy(),
                     wrench=u.reshape(B, 4, 3).copy())
 
+    def _gait_struct(self, period_steps, double_support_steps, com_target, hip_offset_y):
+        g = _lib.Gait()
+        g.struct_size = C.sizeof(_lib.Gait)
+        g.period_steps, g.double_support_steps = int(period_steps), int(double_support_steps)
+        for i in range(3):
+            g.com_target[i] = float(com_target[i])
+        g.hip_offset_y = float(hip_offset_y)
+        return g
+
+    def mpc_inputs(self, x0, feet, stamp, v_ref, com_target, standing=None, period_steps=6, double_support_steps=1,
+                   hip_offset_y=0.0645):
+        """The step before the QP for B robots (msgs.MpcNode.step + msgs.AlternatingGait for one robot):
+        x0 (B,13), feet (B,12) or (B,4,3), stamp (B,), v_ref (B,2), standing (B,) flags or None.
+        Returns dict(x_ref (B,N,13), foot (B,N,12), contact (B,N,4) uint8, pcom (B,N,3), landing (B,3)) -- the arrays
+        solve() / solve_device() take."""
+        x = _c(x0, np.float64).reshape(-1, NX)
+        B, N = x.shape[0], self.N
+        f = _c(feet, np.float64).reshape(B, NU)
+        t = _c(stamp, np.float64).reshape(B)
+        v = _c(v_ref, np.float64).reshape(B, 2)
+        sd = None if standing is None else _c(standing, np.uint8).reshape(B)
+        g = self._gait_struct(period_steps, double_support_steps, com_target, hip_offset_y)
+        xr, ft, ct = np.empty((B, N, NX)), np.empty((B, N, NU)), np.empty((B, N, NC), dtype=np.uint8)
+        pc, lp = np.empty((B, N, 3)), np.empty((B, 3))
+        rc = self._lib.srbdqp_mpc_inputs_f64(self._h, B, _p(x), _p(f), _p(t), _p(v), _p(sd), C.byref(g), _p(xr), _p(ft), _p(ct), _p(pc), _p(lp))
+        _lib.check(rc, self._h)
+        return dict(x_ref=xr, foot=ft, contact=ct, pcom=pc, landing=lp)
+
+    def mpc_inputs_device(self, B, x0, feet, stamp, v_ref, com_target, x_ref, foot, contact, pcom, landing=0, standing=0,
+                          period_steps=6, double_support_steps=1, hip_offset_y=0.0645, stream=0):
+        """Device-pointer form of mpc_inputs(): raw addresses in, launch enqueued behind `stream`, returns at once."""
+        v = lambda q: C.c_void_p(int(q)) if q else None
+        g = self._gait_struct(period_steps, double_support_steps, com_target, hip_offset_y)
+        rc = self._lib.srbdqp_mpc_inputs_device_f64(self._h, int(B), v(x0), v(feet), v(stamp), v(v_ref), v(standing), C.byref(g),
+                                                    v(x_ref), v(foot), v(contact), v(pcom), v(landing), v(stream))
+        _lib.check(rc, self._h)
+
     def last_kernel_ms(self) -> float:
         return float(self._lib.srbdqp_last_kernel_ms(self._h))
 

@@ -1,5 +1,5 @@
 /* srbdqp_cascade.h -- the steps either side of the QP in the reference's control cascade, batched on the GPU
- * (SURVEY.md 8(f) rows 3 and 4).  Same library (libsrbdqp.so), same handle, same error convention as srbdqp.h.
+ * (SURVEY.md 8(f) rows 2, 3 and 4).  Same library (libsrbdqp.so), same handle, same error convention as srbdqp.h.
  *
  *   srbdqp_swing_*            replaces  SwingTrajectory.calculate_coeff / calculate_position_xy / calculate_position_z /
  *                             calculate_velocity_z / calculate_acceleration_z
@@ -46,6 +46,35 @@ int srbdqp_wbid_reference_f64(srbdqp_handle* h, int64_t B, const double* x_next,
 int srbdqp_wbid_reference_device_f64(srbdqp_handle* h, int64_t B, const double* x_next, const double* u0,
                                      const double* foot, int32_t as_written, double* R, double* base_vel,
                                      double* base_acc, double* com_acc, void* stream);
+
+/* ---- the step BEFORE the QP: gait schedule + landing position + the QP's input horizons, for B
+ * robots at once.  What the reference's MPC node does between receiving /srbd_current and calling MPC.update()
+ * (ros_run_simulation.py:214-218, 378-399 consume its outputs: contacts[i].active and landing_position; run_simulation.py:
+ * 73-101 builds the same horizons for one robot).  The schedule itself is inside the absent module: this is the builder's own
+ * design (fixed-period alternating single support with a double-support overlap, Raibert-style landing point), the same
+ * one g1_locomotion_amd/msgs.py (AlternatingGait, MpcNode.step) runs on the host for one robot.
+ *
+ * Outputs are laid out exactly as srbdqp_solve_batch_device_f64 takes them, so a fleet's control step stays on the device:
+ *   srbdqp_mpc_inputs_device_f64 -> srbdqp_solve_batch_device_f64(..., pcom) -> srbdqp_wbid_reference_device_f64. */
+typedef struct srbdqp_gait {
+    int32_t struct_size;          /* = sizeof(srbdqp_gait) */
+    int32_t period_steps;         /* horizon steps one foot swings (0.25 s / dt, ros_run_simulation.py:148) */
+    int32_t double_support_steps; /* steps of double support at the start of every half period */
+    int32_t reserved0;
+    double com_target[3];         /* CoM reference when v_ref = 0 (run_simulation.py:81) */
+    double hip_offset_y;          /* lateral offset of the landing point from the CoM */
+} srbdqp_gait;
+
+/* x0 [B][13] measured state; feet [B][12] current contact-point positions (srbdqp.h order); stamp [B] seconds;
+ * v_ref [B][2] commanded planar velocity; standing [B] non-zero = all four contacts in stance (may be NULL = walking).
+ * Horizon N and dt: the handle's config.  Outputs: x_ref [B][N][13], foot [B][N][12], contact [B][N][4], pcom [B][N][3],
+ * landing [B][3] (may be NULL): landing position of the foot that swings (or swings next) at the first step. */
+int srbdqp_mpc_inputs_f64(srbdqp_handle* h, int64_t B, const double* x0, const double* feet, const double* stamp,
+                          const double* v_ref, const uint8_t* standing, const srbdqp_gait* gait,
+                          double* x_ref, double* foot, uint8_t* contact, double* pcom, double* landing);
+int srbdqp_mpc_inputs_device_f64(srbdqp_handle* h, int64_t B, const double* x0, const double* feet, const double* stamp,
+                                 const double* v_ref, const uint8_t* standing, const srbdqp_gait* gait,
+                                 double* x_ref, double* foot, uint8_t* contact, double* pcom, double* landing, void* stream);
 
 #ifdef __cplusplus
 }

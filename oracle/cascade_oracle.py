@@ -1,4 +1,4 @@
-"""CPU restatement (NumPy) of the two steps either side of the QP that SURVEY.md 8(f) ranks next.
+"""CPU restatement (NumPy) of the steps either side of the QP that SURVEY.md 8(f) ranks next.
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's CPU leg, never by the product.
 
@@ -8,6 +8,9 @@ TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.
   * MPC -> WBID reference mapping -- follows g1_mujoco_sim/src/wbid.py:232-297.  Parity unpinned: wbid.py cannot be
     imported here (pyopensot, xbot2_interface, tf are absent) and the reference has no tests; the rotation is
     tf.transformations.euler_matrix's published 'sxyz' formula.
+  * the step before the QP (gait schedule, landing position, input horizons) -- the schedule is inside the
+    absent module: own design, the one g1_locomotion_amd/msgs.py runs on the host for one robot; mpc_inputs() below restates it
+    for B robots and tests/test_cascade_oracle.py checks it against what msgs.MpcNode.step hands to MPC.update().
 """
 import numpy as np
 
@@ -97,3 +100,42 @@ def wbid_reference_batch(x_next, u0, foot, mass, inertia=TORSO_INERTIA, as_writt
     xs, us, fs = np.asarray(x_next).reshape(-1, 13), np.asarray(u0).reshape(-1, 12), np.asarray(foot).reshape(-1, 12)
     outs = [wbid_reference(xs[i], us[i], fs[i], mass, inertia, as_written) for i in range(xs.shape[0])]
     return {k: np.stack([o[k] for o in outs]) for k in ("R", "base_vel", "base_acc", "com_acc")}
+
+
+def mpc_inputs(x0, feet, stamp, v_ref, com_target, N, dt, standing=None, period_steps=6, double_support_steps=1, hip_offset_y=0.0645):
+    """The QP inputs of B robots as msgs.MpcNode.step builds them for one (same operations in the same order, so the GPU
+    kernel can be compared bit for bit): x0 (B,13), feet (B,12), stamp (B,), v_ref (B,2), standing (B,) or None.
+    Returns dict(x_ref (B,N,13), foot (B,N,12), contact (B,N,4) uint8, pcom (B,N,3), landing (B,3))."""
+    x0 = np.asarray(x0, np.float64).reshape(-1, 13)
+    B = x0.shape[0]
+    feet = np.asarray(feet, np.float64).reshape(B, 12)
+    stamp = np.asarray(stamp, np.float64).reshape(B)
+    v_ref = np.asarray(v_ref, np.float64).reshape(B, 2)
+    standing = np.zeros(B, bool) if standing is None else np.asarray(standing).reshape(B) != 0
+    com_target = np.asarray(com_target, np.float64)
+    k = np.arange(1, N + 1, dtype=np.float64)
+    xr = np.zeros((B, N, 13))
+    moving = np.any(v_ref != 0.0, axis=1)
+    xr[:, :, 2] = x0[:, None, 2]
+    xr[:, :, 3] = np.where(moving[:, None], x0[:, None, 3] + v_ref[:, None, 0] * k[None, :] * dt, com_target[0])
+    xr[:, :, 4] = np.where(moving[:, None], x0[:, None, 4] + v_ref[:, None, 1] * k[None, :] * dt, com_target[1])
+    xr[:, :, 5] = com_target[2]
+    xr[:, :, 9] = v_ref[:, None, 0]
+    xr[:, :, 10] = v_ref[:, None, 1]
+    xr[:, :, 12] = x0[:, None, 12]
+    foot = np.repeat(feet[:, None, :], N, axis=1)
+    v3 = np.concatenate([v_ref, np.zeros((B, 1))], axis=1)
+    pcom = x0[:, None, 3:6] + v3[:, None, :] * (k[None, :, None] - 1.0) * dt
+    k0 = np.floor(stamp / dt + 1e-9).astype(np.int64)
+    ph = (k0[:, None] + np.arange(N)[None, :]) % (2 * period_steps)
+    left = ph < period_steps
+    ds = (ph % period_steps) < double_support_steps
+    cl = (standing[:, None] | left | ds).astype(np.uint8)
+    cr = (standing[:, None] | ~left | ds).astype(np.uint8)
+    contact = np.stack([cl, cl, cr, cr], axis=2)
+    T = period_steps * dt
+    side = np.where(contact[:, 0, 0] == 0, 1.0, -1.0)
+    landing = np.zeros((B, 3))
+    landing[:, 0] = x0[:, 3] + 0.5 * T * x0[:, 9] + 0.03 * (x0[:, 9] - v_ref[:, 0])
+    landing[:, 1] = x0[:, 4] + side * hip_offset_y + 0.5 * T * x0[:, 10] + 0.03 * (x0[:, 10] - v_ref[:, 1])
+    return dict(x_ref=xr, foot=foot, contact=contact, pcom=pcom, landing=landing)

@@ -86,3 +86,47 @@ def test_cascade_end_to_end_one_control_step(eng):
     # Newton: m a = sum f + m g, with the engine's own first-step forces
     want = out["u"][:, 0].reshape(8, 4, 3).sum(1) / eng.cfg.mass + np.array([0, 0, -9.80665])
     assert np.abs(r["com_acc"] - want).max() < 1e-9
+
+
+def test_mpc_inputs_kernel_is_bit_exact_and_feeds_the_solve(eng):
+    """SURVEY 8(f) row 2 on the GPU: srbdqp_mpc_inputs_f64 against the oracle bit for bit (every output is one rounded
+    operation per step of the host node's arithmetic), for standing and walking robots with and without a commanded
+    velocity; then the fleet step stays on the device -- mpc_inputs_device -> solve_device(pcom) -> wbid_reference_device
+    -- and matches the same chain through host buffers."""
+    import torch
+    rng = np.random.default_rng(5)
+    B, N = 517, eng.N
+    com = np.array([0.05268, 7.44e-5, 0.59798])
+    x0 = rng.normal(size=(B, 13)) * 0.05
+    x0[:, 3:6] += com
+    x0[:, 12] = -9.80665
+    half = np.array([[-0.05, 0.1, -0.6], [0.12, 0.1, -0.6], [-0.05, -0.1, -0.6], [0.12, -0.1, -0.6]])
+    feet = (x0[:, None, 3:6] + half[None] + rng.normal(size=(B, 4, 3)) * 0.01).reshape(B, 12)
+    stamp = rng.uniform(0.0, 5.0, size=B)
+    v_ref = np.where(rng.random((B, 1)) < 0.5, 0.0, rng.normal(size=(B, 2)) * 0.3)
+    standing = (rng.random(B) < 0.25).astype(np.uint8)
+    r = eng.mpc_inputs(x0, feet, stamp, v_ref, com, standing=standing)
+    assert eng.kernel_name() == "mpc_inputs_f64"
+    o = co.mpc_inputs(x0, feet, stamp, v_ref, com, N, eng.cfg.dt, standing=standing)
+    for k in ("x_ref", "foot", "contact", "pcom", "landing"):
+        assert np.array_equal(r[k], o[k]), k
+    assert set(np.unique(r["contact"].sum(axis=2))) <= {2, 4}
+    # the whole fleet step on device buffers
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_x0, d_ft, d_st, d_v, d_sd = t(x0), t(feet), t(stamp), t(v_ref), t(standing)
+    d_xr = torch.empty((B, N, 13), dtype=torch.float64, device=dev); d_f = torch.empty((B, N, 12), dtype=torch.float64, device=dev)
+    d_ct = torch.empty((B, N, 4), dtype=torch.uint8, device=dev); d_pc = torch.empty((B, N, 3), dtype=torch.float64, device=dev)
+    d_lp = torch.empty((B, 3), dtype=torch.float64, device=dev)
+    d_u = torch.empty((B, N, 12), dtype=torch.float64, device=dev); d_x = torch.empty((B, N + 1, 13), dtype=torch.float64, device=dev)
+    d_s = torch.empty(B, dtype=torch.int32, device=dev)
+    eng.mpc_inputs_device(B, d_x0.data_ptr(), d_ft.data_ptr(), d_st.data_ptr(), d_v.data_ptr(), com, d_xr.data_ptr(), d_f.data_ptr(),
+                          d_ct.data_ptr(), d_pc.data_ptr(), landing=d_lp.data_ptr(), standing=d_sd.data_ptr())
+    eng.solve_device(B, d_x0.data_ptr(), d_xr.data_ptr(), d_f.data_ptr(), d_ct.data_ptr(), d_u.data_ptr(), x_out=d_x.data_ptr(),
+                     status=d_s.data_ptr(), pcom=d_pc.data_ptr())
+    eng.synchronize()
+    host = eng.solve(x0, o["x_ref"], o["foot"], o["contact"], pcom=o["pcom"])
+    assert np.array_equal(d_s.cpu().numpy(), host["status"]) and (host["status"] > 0).all()
+    assert np.array_equal(d_u.cpu().numpy(), host["u"]) and np.array_equal(d_lp.cpu().numpy(), o["landing"])
+    fz = host["u"][:, 0].reshape(B, 4, 3)[:, :, 2]
+    assert np.all(fz[o["contact"][:, 0] == 0] == 0.0) and np.all(fz[o["contact"][:, 0] == 1] >= 10.0 - 1e-3)
