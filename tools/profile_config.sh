@@ -1,16 +1,18 @@
 #!/bin/bash
 # rocprofv3 evidence for one bench configuration, on the GPU box (through gpurun):
-#   bash tools/profile_config.sh <round tag, e.g. r02> <config 1|2> <bench kernel name> <B> <N> <esz> [launches per solve]
+#   bash tools/profile_config.sh <round tag, e.g. r02> <config 1|2> <bench kernel name> <B> <N> <esz> [launches per solve] [extra bench.py args ...]
 # writes gpurun_out/prof_<tag>_c<config>/{<tag>_<kernel>_kernel_stats.csv, <tag>_<kernel>_pmc_summary.json, bench json}
 set -eu
 RR=$1; CFG=$2; KN=$3; B=$4; N=$5; ESZ=$6; LPS=${7:-1}
+shift 6; [ $# -gt 0 ] && shift
+EXTRA="$*"
 R=$(cd "$(dirname "$0")/.." && pwd)
-O=$R/gpurun_out/prof_${RR}_c${CFG}
+O=$R/gpurun_out/prof_${RR}_c${CFG}${EXTRA:+_${KN}}
 mkdir -p "$O"
 cd "$R"
 STEPS=20; [ "$CFG" = "2" ] && STEPS=6
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --config $CFG --streams 1 --steps $STEPS --warmup 4 --no-cpu-baseline --no-latency > "$O/stats.log" 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --config $CFG --streams 1 --steps $STEPS --warmup 4 --no-cpu-baseline --no-latency $EXTRA > "$O/stats.log" 2>&1)
 find "$O/stats" -name "*kernel_stats.csv" -exec cp {} "$O/${RR}_${KN}_kernel_stats.csv" \;
-bash tools/pmc_collect.sh "prof_${RR}_c${CFG}/pmc" --config $CFG --streams 1 --steps 4 --warmup 4 > "$O/pmc_collect.log" 2>&1
+bash tools/pmc_collect.sh "$(basename "$O")/pmc" --config $CFG --streams 1 --steps 4 --warmup 4 $EXTRA > "$O/pmc_collect.log" 2>&1
 python tools/pmc_summary.py "$O/pmc" "$O/stats" "$O/${RR}_${KN}_pmc_summary.json" "$KN" $B $N $ESZ ${RR#r} $LPS > "$O/pmc_summary_print.txt" 2> "$O/pmc_summary.err"
 ls -la "$O" | grep "${RR}_"

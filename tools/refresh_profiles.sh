@@ -48,7 +48,8 @@ if [ "$PART" = all ] || [ "$PART" = profile ]; then
 # rocprofv3: kernel trace + stats, then the PMC passes (one counter group per run), both configs
 bash tools/profile_config.sh $RR 1 wave_f64_n10_s2 4096 10 8 1 > $O/profile_c1.log 2>&1 || { echo "FAILED: profile config 1"; FAILED="$FAILED profile1"; }
 bash tools/profile_config.sh $RR 2 wrench_f32_n20 65536 20 4 1 > $O/profile_c2.log 2>&1 || { echo "FAILED: profile config 2"; FAILED="$FAILED profile2"; }
-cp $R/gpurun_out/prof_${RR}_c1/${RR}_* $R/gpurun_out/prof_${RR}_c2/${RR}_* $O/ 2>/dev/null
+bash tools/profile_config.sh $RR 1 compact_f64_n10_s2 4096 10 8 1 --kernel compact > $O/profile_c1_compact.log 2>&1 || { echo "FAILED: profile config 1 (compact)"; FAILED="$FAILED profile1c"; }
+cp $R/gpurun_out/prof_${RR}_c1/${RR}_* $R/gpurun_out/prof_${RR}_c2/${RR}_* $R/gpurun_out/prof_${RR}_c1_compact_f64_n10_s2/${RR}_* $O/ 2>/dev/null
 fi
 ls -la $O | grep ${RR}_
 [ -z "$FAILED" ] || { echo "steps that failed:$FAILED"; exit 1; }
