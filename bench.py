@@ -9,7 +9,7 @@ iteration counts the SAME batch produced the last time it was solved.
   --config 1 (default; BASELINE.json configs[1], the config the metric is quoted on):
         B = 4096 QPs per GPU, N = 10, 2-contact alternating single support, fp64
   --config 2 (configs[2]): B = 65536 per GPU, N = 20, 4-contact double support, fp32 buffers and iterations
-        (fp64 set-up on chip; srbdqp_solve_batch_device_f32)
+        (fp64 assembly on chip, T factored in fp32 MFMA tiles; srbdqp_solve_batch_device_f32)
 
 With N > 1 ranks each rank owns its own batch (weak scaling, no data-path collective) and the first-step contact forces
 u_opt0 are all-gathered over RCCL/xGMI every step, as north_star specifies; the same run also times the steps without
@@ -51,7 +51,7 @@ CONFIGS = {
     1: dict(horizon=10, batch=4096, schedule="single", f32=False, maxs=2,
             workload="configs[1]: batch={B}/GPU random SRBD states, N=10, 2-contact alternating single support friction cone, fp64"),
     2: dict(horizon=20, batch=65536, schedule="double", f32=True, maxs=4,
-            workload="configs[2]: batch={B}/GPU random SRBD states, N=20, 4-contact double support, fp32 buffers + iterations (fp64 set-up)"),
+            workload="configs[2]: batch={B}/GPU random SRBD states, N=20, 4-contact double support, fp32 buffers + iterations (fp64 assembly; factorisation in fp32 MFMA tiles + one fp64 refinement step)"),
 }
 
 
@@ -277,7 +277,7 @@ def main(argv=None):
             c = eng.cfg
             out["config"].update({"eps_abs": max(c.eps_abs, 2e-6) if f32 else c.eps_abs, "eps_rel": max(c.eps_rel, 2e-6) if f32 else c.eps_rel,
                                   "rho": _auto_rho(N) if c.rho == 0 else c.rho, "max_iter": int(c.max_iter),
-                                  "rho_restart_iter": int(c.rho_restart_iter), "set_up_dtype": "f64"})
+                                  "rho_restart_iter": int(c.rho_restart_iter), "set_up_dtype": "f64" if not f32 else "f64 assembly, f32 tiles (f64 tiles for QPs with a step of <= 2 stance contacts)"})
         if elapsed_other is not None:
             key = "value_without_allgather" if use_ag else "value_with_allgather"
             out[key] = total_qp / elapsed_other
