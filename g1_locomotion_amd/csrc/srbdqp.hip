@@ -978,6 +978,9 @@ struct srbdqp_ragged {
     int device = 0;
     int32_t *d_perm = nullptr, *d_off = nullptr, *h_perm = nullptr, *h_off = nullptr;   // device arrays + pinned mirrors
     size_t cap = 0;
+    // rho restart of the long-horizon buckets: fp32 maxima of a QP's last check [cap][4], status when the caller passes none
+    // [cap], duals of the first pass [row_cap][20] (the second pass warm-starts from them)
+    float* d_resid = nullptr; int32_t* d_status = nullptr; double* d_y = nullptr; size_t row_cap = 0;
     char* ws = nullptr; size_t ws_bytes = 0;  // host-buffer entry point: device copies of the caller's arrays
     hipStream_t stream = nullptr;             // ... and the stream its copies run on
     std::string err;
@@ -1038,6 +1041,9 @@ int srbdqp_ragged_destroy(srbdqp_ragged* r) {
     if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
     if (r->d_perm) (void)hipFree(r->d_perm);
     if (r->d_off) (void)hipFree(r->d_off);
+    if (r->d_resid) (void)hipFree(r->d_resid);
+    if (r->d_status) (void)hipFree(r->d_status);
+    if (r->d_y) (void)hipFree(r->d_y);
     if (r->h_perm) (void)hipHostFree(r->h_perm);
     if (r->h_off) (void)hipHostFree(r->h_off);
     if (r->ws) (void)hipFree(r->ws);
@@ -1069,6 +1075,11 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
         RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_off), want * 4));
         RAG_TRY(r, hipHostMalloc(reinterpret_cast<void**>(&r->h_perm), want * 4, hipHostMallocDefault));
         RAG_TRY(r, hipHostMalloc(reinterpret_cast<void**>(&r->h_off), want * 4, hipHostMallocDefault));
+        if (r->d_resid) (void)hipFree(r->d_resid);
+        if (r->d_status) (void)hipFree(r->d_status);
+        r->d_resid = nullptr; r->d_status = nullptr;
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_resid), want * 16));
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_status), want * 4));
         r->cap = want;
         r->ev_in_pending = false;
     }
@@ -1086,6 +1097,16 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
         rows += N_per_qp[b];
     }
     for (size_t i = 0; i < nb; ++i) start[i + 1] = start[i] + cnt[i];
+    bool any_restart = false;
+    for (size_t i = 0; i < nb; ++i) any_restart = any_restart || (cnt[i] > 0 && restart_iter_of(r->hs[i], 4, cnt[i]) > 0);
+    if (any_restart && (size_t)rows > r->row_cap) {   // dual buffer of the restart (waits for earlier solves of this object only)
+        for (auto* h : r->hs) RAG_TRY(r, hipStreamSynchronize(h->stream));
+        if (r->d_y) (void)hipFree(r->d_y);
+        r->d_y = nullptr; r->row_cap = 0;
+        const size_t want = (size_t)rows + (size_t)rows / 4 + 64;
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_y), want * 20 * sizeof(double)));
+        r->row_cap = want;
+    }
     std::vector<int> fill(start.begin(), start.end() - 1);
     for (int32_t b = 0; b < B; ++b) r->h_perm[fill[(size_t)which[(size_t)b]]++] = b;
     RAG_TRY(r, hipMemcpyAsync(r->d_off, r->h_off, (size_t)B * 4, hipMemcpyHostToDevice, sin));
@@ -1105,7 +1126,23 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
         a.u_out = u_out; a.x_out = x_out; a.status = status; a.iters = iters;
         a.perm = r->d_perm + start[i]; a.row_off = r->d_off;
         a.B = cnt[i]; a.mode = 0;
-        const int rc = ragged_launch_bucket(bh, a, bs);
+        const int restart = restart_iter_of(bh, 4, cnt[i]);
+        int rc;
+        if (restart > 0) {   // two passes over the bucket, as srbdqp_solve_batch_* does (the second one selects its QPs in-kernel)
+            KArgs a1 = a;
+            a1.max_iter = restart; a1.resid_out = r->d_resid; a1.y_out = r->d_y;
+            if (!a1.status) a1.status = r->d_status;
+            rc = ragged_launch_bucket(bh, a1, bs);
+            if (rc == SRBDQP_OK) {
+                KArgs a2 = a1;
+                a2.resid_in = r->d_resid; a2.resid_out = nullptr;
+                a2.warm_u = u_out; a2.warm_y = r->d_y;
+                a2.max_iter = bh->cfg.max_iter - restart; a2.iters_base = restart;
+                rc = ragged_launch_bucket(bh, a2, bs);
+            }
+        } else {
+            rc = ragged_launch_bucket(bh, a, bs);
+        }
         if (rc != SRBDQP_OK) { r->err = std::string("bucket N=") + std::to_string(r->horizons[i]) + ": " + bh->err; return rc; }
         RAG_TRY(r, hipEventRecord(r->ev_out[i], bs));
         RAG_TRY(r, hipStreamWaitEvent(sin, r->ev_out[i], 0));

@@ -200,7 +200,8 @@ int srbdqp_assemble_wrench_f64(srbdqp_handle* h, int32_t B,
  *   x0 [B][13]   x_ref [sum N][13]   foot [sum N][12]   contact [sum N][4]   u_out [sum N][12]   x_out [sum N + B][13]
  *   (x_out of QP b starts at row off_b + b: N_b + 1 rows), status / iters [B] in the caller's QP order.
  * Every bucket runs the general kernel (any per-QP contact schedule); cfg is the template of the per-horizon engines
- * (horizon ignored, rho = 0 picks each horizon's own penalty).  No warm start and no rho restart on this path. */
+ * (horizon ignored, rho = 0 picks each horizon's own penalty, rho_restart_iter as for a homogeneous batch of that horizon:
+ * by default the N > 10 buckets take the two-pass rho restart).  No warm start on this path. */
 typedef struct srbdqp_ragged srbdqp_ragged;
 int srbdqp_ragged_create(const srbdqp_config* cfg, const int32_t* horizons, int32_t n_horizons, srbdqp_ragged** out);
 int srbdqp_ragged_destroy(srbdqp_ragged* r);

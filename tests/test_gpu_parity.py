@@ -399,6 +399,36 @@ def test_rho_restart_on_the_staged_batch1_path(torch_first, built_lib):
     MPC.close()
 
 
+def test_ragged_call_runs_the_automatic_rho_restart_of_its_long_buckets(torch_first, built_lib):
+    """Default rho_restart_iter on a ragged object: the N > 10 buckets take the same two passes as a homogeneous batch of that
+    horizon (restart after 100 / 125 iterations, second pass selected in-kernel), the N = 8 bucket none: statuses, iteration
+    counts and forces equal the per-horizon engines' bit for bit, and some QPs of the case do restart."""
+    from g1_locomotion_amd import RaggedMPC, BatchMPC, _lib
+    rng = np.random.default_rng(23)
+    hz = (8, 16, 24)
+    Bq = 300
+    Nq = rng.choice(hz, Bq).astype(np.int32)
+    parts = [[a[0] for a in orc.synthetic_batch(1, int(N), seed=8000 + i, schedule="single" if i % 2 else "mixed")] for i, N in enumerate(Nq)]
+    x0 = np.stack([p[0] for p in parts]); xr = np.concatenate([p[1] for p in parts]); ft = np.concatenate([p[2] for p in parts]); ct = np.concatenate([p[3] for p in parts])
+    eng = RaggedMPC(horizons=hz)
+    out = eng.solve_packed(Nq, x0, xr, ft, ct)
+    eng.close()
+    off = out["off"]
+    restarted = 0
+    for N in hz:
+        idx = np.where(Nq == N)[0]
+        with BatchMPC(horizon=int(N), kernel=_lib.KERNEL_WRENCH) as one:
+            ref = one.solve(x0[idx], np.stack([xr[off[i]:off[i + 1]] for i in idx]), np.stack([ft[off[i]:off[i + 1]] for i in idx]),
+                            np.stack([ct[off[i]:off[i + 1]] for i in idx]))
+        np.testing.assert_array_equal(out["status"][idx], ref["status"])
+        np.testing.assert_array_equal(out["iters"][idx], ref["iters"])
+        for j, i in enumerate(idx):
+            np.testing.assert_array_equal(out["u"][off[i]:off[i + 1]], ref["u"][j])
+        if N > 10:
+            restarted += int((ref["iters"] > (100 if N <= 16 else 125)).sum())
+    assert restarted >= 3, restarted
+
+
 def test_wave_kernel_with_ragged_contact_counts(torch_first, built_lib):
     """The one-wave kernel with fewer stance contacts than its template bound: single-support schedules with contacts
     dropped at random (0, 1 or 2 stance points per step, so n_eff varies from QP to QP and the tiles are padded)."""
