@@ -173,7 +173,10 @@ constexpr int kTileClassMinBatch = 512;
 inline bool uses_wrench(const srbdqp_handle* h, int maxs, int B) {
     const int N = h->cfg.horizon;
     if (h->cfg.kernel == SRBDQP_KERNEL_WRENCH || h->io_f32 || N == 24) return true;
-    if (N > 10) return maxs > 2;
+    // N = 20 single support too, for batches: the general kernel holds 2 workgroups per CU there, the compact one 1
+    // (tools/schedule_bench.py, 16,384 QPs: 2.85 M QP/s against 1.95 M; at N = 12 / 16 the compact kernel wins, 7.1 / 4.9 M
+    // against 5.7 / 4.2 M)
+    if (N > 10) return maxs > 2 || (N == 20 && h->cfg.kernel == SRBDQP_KERNEL_AUTO && B >= kWrenchMinBatch && !h->stamps && !h->signal_next);
     return h->cfg.kernel == SRBDQP_KERNEL_AUTO && maxs > 2 && B >= kWrenchMinBatch && !h->stamps && !h->signal_next;
 }
 
@@ -270,7 +273,7 @@ struct WrenchTraits {
 #ifndef SRBDQP_F64_SMALL_WPS
 #define SRBDQP_F64_SMALL_WPS 3
 #endif
-    static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 24 ? SRBDQP_F64_SMALL_WPS : (S::CHMAX <= 36 ? 2 : 1));   // register budget
+    static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 24 ? SRBDQP_F64_SMALL_WPS : (S::CHMAX <= 60 ? 2 : 1));   // register budget
 #endif
     static constexpr int wps = by_lds < want ? by_lds : want;
 };
