@@ -130,3 +130,25 @@ def test_mpc_inputs_kernel_is_bit_exact_and_feeds_the_solve(eng):
     assert np.array_equal(d_u.cpu().numpy(), host["u"]) and np.array_equal(d_lp.cpu().numpy(), o["landing"])
     fz = host["u"][:, 0].reshape(B, 4, 3)[:, :, 2]
     assert np.all(fz[o["contact"][:, 0] == 0] == 0.0) and np.all(fz[o["contact"][:, 0] == 1] >= 10.0 - 1e-3)
+
+
+@pytest.mark.parametrize("N", [4, 8, 12, 16, 20, 24])
+def test_mpc_inputs_kernel_every_horizon(N):
+    """The input kernel is instantiated per horizon (index divisions by a compile-time N): every instantiation against the
+    oracle bit for bit, with tile remainders (B not a multiple of 32), negative stamps and a long gait period."""
+    import torch  # noqa: F401
+    from g1_locomotion_amd import BatchMPC
+    rng = np.random.default_rng(100 + N)
+    B = 77
+    com = np.array([0.05, 0.0, 0.6])
+    x0 = rng.normal(size=(B, 13)) * 0.1
+    feet = rng.normal(size=(B, 12))
+    stamp = rng.uniform(-2.0, 50.0, size=B)
+    v_ref = rng.normal(size=(B, 2)) * 0.2
+    v_ref[::3] = 0.0
+    standing = (rng.random(B) < 0.2).astype(np.uint8)
+    with BatchMPC(horizon=N) as e:
+        r = e.mpc_inputs(x0, feet, stamp, v_ref, com, standing=standing, period_steps=9, double_support_steps=2, hip_offset_y=0.08)
+        o = co.mpc_inputs(x0, feet, stamp, v_ref, com, N, e.cfg.dt, standing=standing, period_steps=9, double_support_steps=2, hip_offset_y=0.08)
+    for k in ("x_ref", "foot", "contact", "pcom", "landing"):
+        assert np.array_equal(r[k], o[k]), k
