@@ -91,7 +91,11 @@ struct CompactSmem {
     // workgroups per CU that LDS admits (160 KiB per CU), capped at 3: the register budget the kernel is compiled for
     // (3 only for the small problems: a 168-register budget cannot hold a K^-1 row fragment of more than 30 doubles)
     static constexpr int lds_wgs = 163840 / (int)bytes;
+#ifdef SRBDQP_COMPACT_WPS   // experiments: one register budget for every instantiation
+    static constexpr int waves_per_simd = SRBDQP_COMPACT_WPS;
+#else
     static constexpr int waves_per_simd = (lds_wgs >= 4 && LPR == 4 && nmax <= 60) ? 4 : (lds_wgs >= 3 && nmax <= 72) ? 3 : (lds_wgs >= 2 ? 2 : 1);
+#endif
 };
 
 // Lane mapping of the presolved ADMM: a contact owns 3 LPR consecutive lanes (variable ax on lanes LPR ax .. LPR ax +
