@@ -376,8 +376,27 @@ def latency_batch1(synth, calls=2000):
                 ts.append(time.perf_counter() - t)
             ts = np.array(ts[50:]) * 1e6
             out[name] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
+    # the two-phase call: the set-up (contact schedule, contact points, reference known beforehand) has run and finished;
+    # timed = the second phase only, from "the measured state is in the staging array" to "the forces are there"
+    with BatchMPC(horizon=HORIZON) as eng:
+        st = eng.stage()
+        ts = []
+        for i in range(calls + 50):
+            b = i % 64
+            st["x0"][0] = x0[(b + 1) % 64]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]   # a wrong prediction
+            eng.prepare_staged(1)
+            eng.synchronize()
+            st["x0"][0] = x0[b]
+            t = time.perf_counter()
+            eng.solve_prepared(1, want_x=True)
+            ts.append(time.perf_counter() - t)
+        ts = np.array(ts[50:]) * 1e6
+        out["c_abi_prepared_phase2"] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
     out["note"] = ("cold / warm: MPC.update() from zero / from the previous call's shifted plan and duals; c_abi: "
-                   "srbdqp_solve_staged_f64(B=1) alone; eps1e-3: OSQP's default tolerance instead of 1e-6")
+                   "srbdqp_solve_staged_f64(B=1) alone (THE single-QP latency: everything between the inputs and the forces); "
+                   "eps1e-3: OSQP's default tolerance instead of 1e-6; c_abi_prepared_phase2: srbdqp_solve_prepared_f64 alone after a "
+                   "finished srbdqp_prepare_staged_f64 -- a different mode of operation (the factorisation ran before the state "
+                   "arrived), listed beside c_abi, not instead of it")
     return out
 
 

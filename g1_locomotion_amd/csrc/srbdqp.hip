@@ -65,6 +65,7 @@ struct srbdqp_handle {
     int32_t done_seq = 0;
     bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
     bool lazy_restart = false;     // staged path: run only the first pass; the host starts the second one if a status asks for it
+    int32_t prepared_B = 0; int prepared_maxs = 4; bool prepared_pcom = false;   // two-phase call: a set-up is pending
     KArgs last_args;               // arguments of that first pass (for the lazily started second pass)
     // kernels whose dynamic-LDS limit has been raised on this handle's device (function attributes are per device, and a
     // process may hold handles on several)
@@ -215,6 +216,53 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
     hipLaunchKernelGGL((srbdqp::srbdqp_admm_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), ldsB, st, a);
     HIP_TRY(h, hipGetLastError());
     return SRBDQP_OK;
+}
+
+// Two-phase call (srbdqp_prepare_staged_f64 / srbdqp_solve_prepared_f64): the split pipeline's two kernels launched apart.
+// phase 0 = set-up (+ dq/dx0) from a predicted x0, phase 1 = gradient patch for the measured x0 + ADMM + roll-out.
+template <int N, int MAXS>
+int launch_two_phase(srbdqp_handle* h, KArgs a, hipStream_t st, int phase) {
+    if constexpr (srbdqp::Setup1Smem<N, MAXS>::supported && srbdqp::SplitWs<N, MAXS>::supported) {
+        using W = srbdqp::SplitWs<N, MAXS>;
+        const size_t need = (size_t)a.B * W::doubles;
+        auto* slot = stream_slot(h, st);
+        if (!slot) return SRBDQP_E_INVALID;
+        if (need > slot->ws_doubles) {
+            if (phase == 1) { h->err = "srbdqp_solve_prepared_f64 without a matching srbdqp_prepare_staged_f64"; return SRBDQP_E_INVALID; }
+            HIP_TRY(h, hipStreamSynchronize(st));
+            if (slot->ws) { HIP_TRY(h, hipFree(slot->ws)); slot->ws = nullptr; slot->ws_doubles = 0; }
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&slot->ws), need * sizeof(double));
+            if (e != hipSuccess) { h->err = std::string("hipMalloc split workspace: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
+            slot->ws_doubles = need;
+        }
+        a.ws = slot->ws;
+        if (phase == 0) {
+            constexpr size_t lds1 = srbdqp::Setup1Smem<N, MAXS>::bytes;
+            hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, false, false, true>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
+            static const std::string nm = "prepare_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
+            h->kname = nm.c_str();
+        } else {
+            constexpr size_t ldsB = srbdqp::SplitSmem<N, MAXS>::bytes;
+            a.defer_x0 = 1;
+            hipLaunchKernelGGL((srbdqp::srbdqp_admm_kernel<N, MAXS>), dim3((unsigned)a.B), dim3(64), ldsB, st, a);
+            static const std::string nm = "prepared_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
+            h->kname = nm.c_str();
+        }
+        HIP_TRY(h, hipGetLastError());
+        return SRBDQP_OK;
+    } else {
+        h->err = "the two-phase call needs at most 64 presolved variables (N <= 10 with <= 2 stance contacts per step, N = 4 with 4)";
+        return SRBDQP_E_INVALID;
+    }
+}
+
+int launch_two_phase_any(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs, int phase) {
+    switch (h->cfg.horizon) {
+        case 4: return maxs <= 2 ? launch_two_phase<4, 2>(h, a, st, phase) : launch_two_phase<4, 4>(h, a, st, phase);
+        case 8: return maxs <= 2 ? launch_two_phase<8, 2>(h, a, st, phase) : launch_two_phase<8, 4>(h, a, st, phase);
+        case 10: return maxs <= 2 ? launch_two_phase<10, 2>(h, a, st, phase) : launch_two_phase<10, 4>(h, a, st, phase);
+        default: h->err = "the two-phase call is built for N in {4, 8, 10}"; return SRBDQP_E_INVALID;
+    }
 }
 
 // One wave per QP for the whole solve (srbdqp_setup1.hpp, FUSED): the default for large batches of the small
@@ -621,6 +669,72 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
         }
     }
     return rc;
+}
+
+namespace {
+int staged_maxs(srbdqp_handle* h, int32_t B) {
+    if (h->cfg.max_contacts_per_step > 0) return h->cfg.max_contacts_per_step;
+    int worst = 0;
+    const uint8_t* c = h->stage_h.contact;
+    for (size_t q = 0; q < (size_t)B * h->cfg.horizon; ++q) {
+        const int cnt = (c[4 * q] != 0) + (c[4 * q + 1] != 0) + (c[4 * q + 2] != 0) + (c[4 * q + 3] != 0);
+        if (cnt > worst) worst = cnt;
+    }
+    return (worst <= 2) ? 2 : 4;
+}
+KArgs staged_args(srbdqp_handle* h, int32_t B, bool use_pcom, bool want_x, bool want_y) {
+    const srbdqp_stage& d = h->stage_d;
+    KArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_args(h->cfg, a);
+    a.x0 = d.x0; a.xref = d.x_ref; a.foot = d.foot; a.contact = d.contact; a.pcom = use_pcom ? d.pcom : nullptr;
+    a.u_out = d.u; a.x_out = want_x ? d.x : nullptr; a.y_out = want_y ? d.y : nullptr;
+    a.status = d.status; a.iters = d.iters;
+    a.B = B; a.mode = 0;
+    return a;
+}
+}  // namespace
+
+int srbdqp_prepare_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B < 0 || B > h->stage_h.capacity) { h->err = "staged batch exceeds the staging capacity"; return SRBDQP_E_INVALID; }
+    if (B == 0) return SRBDQP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int maxs = staged_maxs(h, B);
+    KArgs a = staged_args(h, B, use_pcom != 0, true, false);
+    const int rc = launch_two_phase_any(h, a, h->stream, maxs, 0);
+    if (rc != SRBDQP_OK) return rc;
+    h->prepared_B = B; h->prepared_maxs = maxs; h->prepared_pcom = use_pcom != 0;
+    return SRBDQP_OK;   // asynchronous: the set-up runs behind the handle's stream; srbdqp_solve_prepared_f64 queues behind it
+}
+
+int srbdqp_solve_prepared_f64(srbdqp_handle* h, int32_t B, int32_t want_x, int32_t want_y) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (B <= 0 || B != h->prepared_B) { h->err = "srbdqp_solve_prepared_f64: no set-up of this batch size is pending (srbdqp_prepare_staged_f64)"; return SRBDQP_E_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const bool spin = !(h->cfg.flags & SRBDQP_FLAG_NO_SPIN);
+    KArgs a = staged_args(h, B, h->prepared_pcom, want_x != 0, want_y != 0);
+    if (spin) {
+        h->done_seq = (h->done_seq == INT32_MAX) ? 1 : h->done_seq + 1;
+        a.done_flag = h->done_dev; a.done_count = h->done_count; a.done_value = h->done_seq;
+    }
+    h->prepared_B = 0;
+    const int rc = launch_two_phase_any(h, a, h->stream, h->prepared_maxs, 1);
+    if (rc != SRBDQP_OK) return rc;
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned polls = 0;
+        while (*h->done_host != h->done_seq) {
+            if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return SRBDQP_OK;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SRBDQP_OK;
 }
 
 int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev, int32_t length) {

@@ -34,6 +34,8 @@ struct KArgs {
     double* l_out;           // [B][m]
     double* ub_out;          // [B][m]
     const int32_t* perm;     // optional dispatch order: workgroup i solves QP perm[i] (longest-first scheduling), or null
+    int defer_x0;            // split pipeline, second kernel: the set-up ran ahead of the state estimate (two-phase call) -- patch the
+                             //   gradient with dq/dx0 (x0 - x0 of the set-up) and use this x0 for the roll-out
     int tile_sel;            // general kernel, fp32 calls: 0 = every QP; 1 = only QPs whose steps all have 0 or >= 3 stance
                              //   contacts (the fp32-tile launch); 2 = only the others (the fp64-tile launch)
     const int32_t* row_off;  // ragged batches (general kernel): first horizon row of QP b in the packed [sum N][.] arrays, or

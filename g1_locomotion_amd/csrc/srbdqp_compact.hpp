@@ -307,7 +307,8 @@ struct SplitWs {
     static constexpr bool supported = (S::nmax <= 64);     // one K^-1 row per lane of ONE wave
     static constexpr int KS = (S::nmax + 1) & ~1;          // row stride (even: 16-byte loads)
     static constexpr int o_kinv = (S::o_R + 1) & ~1;
-    static constexpr int doubles = o_kinv + S::nmax * KS;
+    static constexpr int o_phi = o_kinv + S::nmax * KS;    // two-phase call: dq/dx0, [nmax][13] (+1 pad)
+    static constexpr int doubles = o_phi + ((S::nmax * 13 + 1) & ~1);
 };
 
 // Assembly dump shared by the compact and the one-wave kernels (mode 1): the reduced-KKT matrix K = P + sigma I + A' rho A

@@ -63,8 +63,11 @@ struct Setup1Smem {
 // FUSED = true : the whole solve on this wave ("wave" kernel): the K^-1 tiles are turned into one row per lane through
 //                the 2 KB transpose tile, then the ADMM iterations and the roll-out of srbdqp_split.hpp follow in place --
 //                nothing but the inputs and the outputs touches HBM.
-template <int N, int MAXS, bool FUSED, bool DUMP = false>
+// PHI (split only): also store dq/dx0 for the two-phase call (srbdqp_prepare_staged_f64): q is affine in x0, so 13 more
+//                passes of the gradient tables with x0 = e_k and x_ref = 0 give its 13 columns.
+template <int N, int MAXS, bool FUSED, bool DUMP = false, bool PHI = false>
 __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
+    static_assert(!(PHI && FUSED), "dq/dx0 is a hand-over of the split pipeline");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     using S = CompactSmem<N, MAXS>;
     using W = SplitWs<N, MAXS>;
@@ -295,6 +298,25 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         for (int c = lane; c < n_eff; c += 64) sm[S::o_px0 + c] = 0.0;
     }
 
+    if constexpr (PHI) {
+        double* phi = ws + W::o_phi;
+        for (int kc = 0; kc < 13; ++kc) {
+            __syncthreads();
+            if (lane < 13) sm[S::o_x0 + lane] = (lane == kc) ? 1.0 : 0.0;
+            __syncthreads();
+            for (int k = lane; k < n; k += 64) {
+                const int i = k / 12, kk = k - 12 * i;
+                sm[L1::o_eh + k] = SQ[kk] * free_response<N, L1>(a, sm, i, kk);
+            }
+            __syncthreads();
+            gt_tables(sm + L1::o_eh);
+            __syncthreads();
+            for (int c = lane; c < n_eff; c += 64) phi[c * 13 + kc] = gt_eval(c);
+        }
+        __syncthreads();
+        if (lane < 13) sm[S::o_x0 + lane] = a.x0[(size_t)b * 13 + lane];
+        __syncthreads();
+    }
     WSTAMP(a, b, 3);
     // ================= K = G'G + R s^2 + sigma + A' rho A, tile by tile through the 2 KB scratch tile ====================
     // Per upper tile (ta, tb): at most 6 x 6 contacts overlap its rows / columns; lane (i1, i2) of an 8 x 8 grid forms

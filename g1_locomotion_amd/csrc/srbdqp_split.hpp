@@ -189,9 +189,23 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
     const double rho_b = SRBDQP_RHO_OF(a, b);
     const int lane = threadIdx.x;
     const double* ws = a.ws + (size_t)b * W::doubles;
-    if (ws[S::o_misc + 1] != 0.0) return;                  // finished by the set-up kernel (no stance contact / bound)
+    if (ws[S::o_misc + 1] != 0.0) { signal_done(a); return; }   // finished by the set-up kernel (no stance contact / bound)
     for (int i = lane; i < S::o_R; i += 64) sm[i] = ws[i];
     __syncthreads();
+    if (a.defer_x0) {   // two-phase call: the set-up saw a predicted x0; q = q(x0_pred) + dq/dx0 (x0 - x0_pred), roll-out from x0
+        const double* phi = ws + W::o_phi;
+        const double* gx0 = a.x0 + (size_t)b * 13;
+        const int ne = 3 * (reinterpret_cast<const int*>(sm + S::o_int) + 2 * N)[0];
+        if (lane < ne) {
+            double dq = 0.0;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) dq = fma(phi[lane * 13 + k], gx0[k] - sm[S::o_x0 + k], dq);
+            sm[S::o_q + lane] += dq;
+        }
+        __syncthreads();
+        if (lane < 13) sm[S::o_x0 + lane] = gx0[lane];
+        __syncthreads();
+    }
     const int n_eff = 3 * (reinterpret_cast<const int*>(sm + S::o_int) + 2 * N)[0];
     // K^-1 row of this lane
     double kin[KS];
@@ -206,6 +220,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_admm_kernel(KArgs a) {
     }
 
     admm_wave_body<N, MAXS>(a, b, rho_b, sm, kin);
+    signal_done(a);   // two-phase staged call: completion word in host memory (no-op without a done_flag)
 }
 
 }  // namespace srbdqp

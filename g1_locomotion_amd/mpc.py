@@ -204,6 +204,15 @@ class BatchMPC:
         """One kernel launch over the first B staged QPs; inputs are read and outputs written in the staging arrays."""
         _lib.check(self._lib.srbdqp_solve_staged_f64(self._h, int(B), int(use_pcom), int(use_warm), int(want_x), int(want_y)), self._h)
 
+    def prepare_staged(self, B=1, use_pcom=False):
+        """Two-phase call, phase 1 (srbdqp_prepare_staged_f64): set-up of the first B staged QPs from a PREDICTED x0 (whatever the
+        staging x0 holds); asynchronous."""
+        _lib.check(self._lib.srbdqp_prepare_staged_f64(self._h, int(B), int(use_pcom)), self._h)
+
+    def solve_prepared(self, B=1, want_x=True, want_y=False):
+        """Two-phase call, phase 2 (srbdqp_solve_prepared_f64): x0 is read from the staging arrays again, the rest is as prepared."""
+        _lib.check(self._lib.srbdqp_solve_prepared_f64(self._h, int(B), int(want_x), int(want_y)), self._h)
+
     def synchronize(self):
         _lib.check(self._lib.srbdqp_synchronize(self._h), self._h)
 
@@ -452,6 +461,40 @@ class MPC:
         else:
             self._warm = False
         return self.u_opt, self.x_opt
+
+    def prepare(self, contact_horizon: Sequence, c_horizon: Sequence, p_com_horizon=None, x_predicted=None):
+        """Two-phase form of update() for loops that know the contact schedule, the contact points and x_ref_hor before the state
+        estimate arrives (NOT the reference's call pattern, which measures the feet with the state: run_simulation.py:94-97):
+        the factorisation runs now, asynchronously; update_prepared(x_current) then only patches the gradient and iterates.
+        x_predicted: any finite guess of the state (default: self.x0)."""
+        if self._engine is None:
+            self.init_matrices()
+        eng, N = self._engine, self.HORIZON_LENGTH
+        st = eng.stage()
+        st["x0"][0] = np.asarray(self.x0 if x_predicted is None else x_predicted, dtype=np.float64).reshape(NX)
+        st["x_ref"][0] = np.asarray(self.x_ref_hor, dtype=np.float64).reshape(N, NX)
+        st["foot"][0] = np.asarray(c_horizon, dtype=np.float64).reshape(N, NU)
+        st["contact"][0] = np.asarray(contact_horizon).reshape(N, NC) != 0
+        if p_com_horizon is not None:
+            st["pcom"][0] = np.asarray(p_com_horizon, dtype=np.float64).reshape(N, 3)
+        eng.prepare_staged(1, use_pcom=p_com_horizon is not None)
+
+    def update_prepared(self, x_current=None, one_rollout: bool = True):
+        """Second phase of prepare(): returns what update() returns, for the measured state x_current (default: self.x0)."""
+        eng = self._engine
+        st = eng.stage()
+        st["x0"][0] = np.asarray(self.x0 if x_current is None else x_current, dtype=np.float64).reshape(NX)
+        t0 = time.perf_counter()
+        eng.solve_prepared(1, want_x=True)
+        self.solve_time = time.perf_counter() - t0
+        self.status, self.iters = int(st["status"][0]), int(st["iters"][0])
+        if self.strict and self.status < 0:
+            raise SrbdqpError(f"MPC solve failed with status {self.status}; the kernel returned zero forces")
+        if self.strict and self.status == _lib.MAX_ITER:
+            warnings.warn(f"MPC solve stopped at the iteration cap ({self.iters} iterations): best iterate returned", RuntimeWarning, stacklevel=2)
+        self.u_opt, self.x_opt = st["u"][0].copy(), st["x"][0].copy()
+        self._warm = False
+        return self.u_opt[0].reshape(NU, 1).copy(), (self.x_opt.copy() if one_rollout else self.x_opt[:2].copy())
 
     def update(self, contact_horizon: Sequence, c_horizon: Sequence, p_com_horizon, x_current=None,
                one_rollout: bool = True):

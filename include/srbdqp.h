@@ -237,6 +237,21 @@ typedef struct srbdqp_stage {
 int srbdqp_stage_ptrs(srbdqp_handle* h, srbdqp_stage* out);
 int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32_t use_warm, int32_t want_x, int32_t want_y);
 
+/* Two-phase form of the staged call, for control loops that know the contact schedule, the contact-point positions and the
+ * reference horizon BEFORE the state estimate arrives.  K (and its factorisation) depends on neither x0 nor x_ref's non-yaw
+ * entries, and the gradient is affine in x0:
+ *   srbdqp_prepare_staged_f64  reads the staging arrays (x0 = a prediction, anything finite), runs the set-up and stores
+ *                              K^-1 and dq/dx0 on the device; returns at once (asynchronous on the handle's stream);
+ *   srbdqp_solve_prepared_f64  reads x0 (only) from the staging arrays again, patches the gradient, runs the ADMM iterations
+ *                              and the roll-out on one wave per QP and returns with the outputs in the staging arrays.
+ * Same QP, same iterates as srbdqp_solve_staged_f64 on the same inputs (the split pipeline of SRBDQP_KERNEL_SPLIT); no warm
+ * start, no rho restart.  Built for the instantiations with at most 64 presolved variables (N = 10 / 8 with <= 2 stance contacts
+ * per step, N = 4 any).  A QP without a stance contact is finished by prepare(): its predicted states are the free response
+ * of the PREDICTED x0.  The reference's own loop measures the contact points together with the state
+ * (run_simulation.py:94-97): there this is a different mode of operation, not the drop-in -- see DESIGN.md section 6. */
+int srbdqp_prepare_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom);
+int srbdqp_solve_prepared_f64(srbdqp_handle* h, int32_t B, int32_t want_x, int32_t want_y);
+
 /* Diagnostic: device buffer [B][16] of int64 that subsequent solves fill with per-QP s_memtime stamps of the kernel's
  * phase boundaries (100 MHz constant clock); NULL switches stamping off.  Not part of the drop-in surface. */
 int srbdqp_set_stamp_buffer(srbdqp_handle* h, void* device_ptr);

@@ -429,6 +429,55 @@ def test_ragged_call_runs_the_automatic_rho_restart_of_its_long_buckets(torch_fi
     assert restarted >= 3, restarted
 
 
+@pytest.mark.parametrize("N,schedule", [(10, "single"), (8, "single"), (4, "double")])
+def test_two_phase_call_equals_the_one_shot_call(torch_first, built_lib, N, schedule):
+    """srbdqp_prepare_staged_f64 + srbdqp_solve_prepared_f64: the set-up runs from a WRONG predicted state, the second phase
+    patches the gradient (q is affine in x0: q_pred + dq/dx0 (x0 - x0_pred)) and rolls out from the measured state.  Against
+    the one-shot call on the same inputs (split pipeline: same iterates): statuses and iteration counts equal, forces and
+    predicted states to 1e-8 (the patched gradient is summed in another order); and against the oracle twin."""
+    from g1_locomotion_amd import BatchMPC
+    B = 8
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=600 + N, schedule=schedule)
+    rng = np.random.default_rng(N)
+    with BatchMPC(horizon=N, rho_restart_iter=-1) as eng:
+        ref = eng.solve(x0, xr, ft, ct)
+        st = eng.stage()
+        assert st["capacity"] >= B
+        st["x_ref"][:B] = xr; st["foot"][:B] = ft.reshape(B, N, 12); st["contact"][:B] = ct.reshape(B, N, 4)
+        st["x0"][:B] = x0 + rng.normal(size=x0.shape) * np.array([0.2] * 3 + [0.05] * 3 + [0.5] * 6 + [0.0])     # the prediction: off
+        eng.prepare_staged(B)
+        assert eng.kernel_name().startswith("prepare_f64_n")
+        st["x0"][:B] = x0                                                                                          # the measurement
+        eng.solve_prepared(B, want_x=True)
+        assert eng.kernel_name().startswith("prepared_f64_n")
+        u, x, status, iters = st["u"][:B].copy(), st["x"][:B].copy(), st["status"][:B].copy(), st["iters"][:B].copy()
+        with pytest.raises(Exception):
+            eng.solve_prepared(B)                     # nothing pending any more
+    np.testing.assert_array_equal(status, ref["status"])
+    assert np.abs(iters - ref["iters"]).max() <= 5, (iters, ref["iters"])
+    assert np.abs(u - ref["u"]).max() <= 1e-6 and np.abs(x - ref["x"]).max() <= 1e-8
+    p = orc.params_for(N)
+    for b in range(B):
+        o = orc.update(p, x0[b], xr[b], ft[b], ct[b])
+        assert status[b] == o["status"] and np.abs(u[b] - o["u"]).max() <= TOL_TWIN_N
+
+
+def test_mpc_prepare_then_update_prepared(torch_first, built_lib):
+    """The drop-in object's two-phase form: prepare(...) from the previous state, update_prepared(x) = update(..., x)."""
+    from g1_locomotion_amd import mpc
+    N = 10
+    x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=77, schedule="single"))
+    M = mpc.MPC(dt=0.04)
+    M.init_matrices()
+    M.x_ref_hor[:] = xr
+    u_a, x_a = M.update(list(ct), list(ft), xr[:, 3:6], x_current=x0.reshape(13, 1))
+    M.prepare(list(ct), list(ft), xr[:, 3:6], x_predicted=x0 * 0.9)
+    u_b, x_b = M.update_prepared(x0.reshape(13, 1))
+    assert M.status == orc.STATUS_SOLVED
+    assert np.abs(u_a - u_b).max() <= 1e-6 and np.abs(x_a - x_b).max() <= 1e-8
+    M.close()
+
+
 def test_wave_kernel_with_ragged_contact_counts(torch_first, built_lib):
     """The one-wave kernel with fewer stance contacts than its template bound: single-support schedules with contacts
     dropped at random (0, 1 or 2 stance points per step, so n_eff varies from QP to QP and the tiles are padded)."""

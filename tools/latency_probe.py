@@ -43,6 +43,28 @@ def main():
             its.append(int(st["iters"][0]))
         out[f"c_abi_{name}"] = dict(pct(ts[100:]), mean_iters=float(np.mean(its[100:])))
         eng.close()
+    # two-phase call: set-up done beforehand (from a wrong predicted state), timed = srbdqp_solve_prepared_f64 alone; and both
+    # phases back to back (what the two-phase form costs when nothing is known beforehand)
+    eng = BatchMPC(horizon=10)
+    st = eng.stage()
+    ts, tb, its = [], [], []
+    for i in range(calls + 100):
+        b = i % 64
+        st["x0"][0] = x0[(b + 1) % 64]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]
+        eng.prepare_staged(1)
+        eng.synchronize()
+        st["x0"][0] = x0[b]
+        t = time.perf_counter()
+        eng.solve_prepared(1, want_x=True)
+        ts.append(time.perf_counter() - t)
+        its.append(int(st["iters"][0]))
+        t = time.perf_counter()
+        eng.prepare_staged(1)
+        eng.solve_prepared(1, want_x=True)
+        tb.append(time.perf_counter() - t)
+    out["c_abi_prepared_phase2"] = dict(pct(ts[100:]), mean_iters=float(np.mean(its[100:])))
+    out["c_abi_two_phases_back_to_back"] = pct(tb[100:])
+    eng.close()
     # PCIe-inclusive batch rate: host (pageable NumPy) buffers in, host buffers out, B = 4096
     xb, xrb, ftb, ctb = orc.synthetic_batch(4096, 10, seed=1000, schedule="single")
     eng = BatchMPC(horizon=10, max_contacts_per_step=2)
