@@ -462,6 +462,31 @@ def test_two_phase_call_equals_the_one_shot_call(torch_first, built_lib, N, sche
         assert status[b] == o["status"] and np.abs(u[b] - o["u"]).max() <= TOL_TWIN_N
 
 
+def test_two_phase_call_limits_and_pcom(torch_first, built_lib):
+    """Outside its instantiations (more than 64 presolved variables) the two-phase call refuses loudly; with a CoM horizon
+    (use_pcom) it still equals the one-shot call."""
+    from g1_locomotion_amd import BatchMPC, SrbdqpError
+    with BatchMPC(horizon=12) as eng:
+        st = eng.stage()
+        x0, xr, ft, ct = orc.synthetic_batch(1, 12, seed=3, schedule="single")
+        st["x0"][0] = x0[0]; st["x_ref"][0] = xr[0]; st["foot"][0] = ft[0].reshape(12, 12); st["contact"][0] = ct[0].reshape(12, 4)
+        with pytest.raises(SrbdqpError):
+            eng.prepare_staged(1)
+    N, B = 10, 4
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=91, schedule="single")
+    pc = xr[:, :, 3:6] + 0.01
+    with BatchMPC(horizon=N, rho_restart_iter=-1) as eng:
+        ref = eng.solve(x0, xr, ft, ct, pcom=pc)
+        st = eng.stage()
+        st["x_ref"][:B] = xr; st["foot"][:B] = ft.reshape(B, N, 12); st["contact"][:B] = ct.reshape(B, N, 4); st["pcom"][:B] = pc
+        st["x0"][:B] = 0.5 * x0
+        eng.prepare_staged(B, use_pcom=True)
+        st["x0"][:B] = x0
+        eng.solve_prepared(B)
+        np.testing.assert_array_equal(st["status"][:B], ref["status"])
+        assert np.abs(st["u"][:B] - ref["u"]).max() <= 1e-6
+
+
 def test_mpc_prepare_then_update_prepared(torch_first, built_lib):
     """The drop-in object's two-phase form: prepare(...) from the previous state, update_prepared(x) = update(..., x)."""
     from g1_locomotion_amd import mpc
