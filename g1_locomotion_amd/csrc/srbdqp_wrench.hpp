@@ -19,8 +19,12 @@
 // LDS vector (ONE barrier per iteration), t = T^-1 v is a register mat-vec (a half row per lane), and
 // x~ = x_q + Bd w + V' t is again local to the step.
 //
-// Precision (template parameter R): the set-up (assembly, Cholesky, T^-1) is always fp64.  R = float keeps T^-1, V, Bd
-// and the iterates in fp32 and reads / writes fp32 buffers.  What makes fp32 iterations converge at all is the split
+// Precision (template parameters R, TT): the assembly (tables, E^-1, the entries of T) is always fp64.  R = float keeps
+// T^-1, V, Bd and the iterates in fp32 and reads / writes fp32 buffers.  TT = the type of the 16 x 16 tiles T is stored,
+// factored (MFMA 16x16x4 f64 or f32) and inverted in: double everywhere, or float for the fp32 calls' QPs whose steps all
+// have 0 or >= 3 stance contacts (cond(T) ~ 5e4; half the LDS, three workgroups per CU at N = 20) -- x_q then gets one
+// refinement step with the fp64 residual K x_q + q, and V / Bd are formed after the factorisation from the triangle of
+// E^-1 kept in LDS.  What makes fp32 iterations converge at all is the split
 // x~ = x_q + K^-1 (sigma x + A'(rho z - y)) with x_q = -K^-1 q computed ONCE in fp64: q is O(1e4) in the scaled
 // variables and would otherwise drown the O(1) iterate in the mat-vec's cancellation; and the dual residual is
 // tracked as c = P x + q (recursion c~ = sigma (x - x~) - A' nu), which never sees q either.  R = double runs the same
