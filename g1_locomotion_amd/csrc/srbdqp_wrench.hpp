@@ -101,7 +101,12 @@ struct WrenchSmem {
     static constexpr int o_xs = o_vb + 2 * VB;            // n         full solution (scaled) for the roll-out
     static constexpr int o_scr = o_xs + n;                // 12N       roll-out scratch
     static constexpr int endC = o_scr + n + 2;
-    static constexpr int o_end = cmax(endA, cmax(endB, endC));
+    // fp64 iterations with a half row longer than 60 (N = 24): its last KTAIL entries per lane, entry-major [KTAIL][BT] (the tiles
+    // are dead by then and their region is far larger)
+    static constexpr int KTAIL = (TB == 8 && CHMAX > 60) ? CHMAX - 48 : 0;
+    static constexpr int o_kt = up2(endC);
+    static constexpr int endC2 = o_kt + KTAIL * BT;
+    static constexpr int o_end = cmax(endA, cmax(endB, endC2));
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr int lds_wgs = 163840 / (int)bytes;
 };
@@ -167,10 +172,14 @@ __device__ __forceinline__ double wg_max1(double v, double* red) {
 //             short of the 2e-6 tolerance (0.06 % with the explicit rows);
 //   BDN = 4:  {J[0..2][u], 1 / D_u}: Bd w = D^-1 (w - Y' v) from the step's own v = V w -- the fp64 iterations: 8 registers
 //             instead of 24, 6 multiply-adds instead of 12, and only the lane's half of the step's right-hand sides is read.
-template <typename R, int CHMAX, typename KT, int BDN, class Hook>
+// KREG < CHMAX (fp64 iterations at N = 24): the last CHMAX - KREG entries of the lane's T^-1 half row are read from LDS
+// (ktail[(c - KREG) kts], lane-contiguous per entry) instead of registers -- a 5-wave workgroup puts two waves on one SIMD,
+// so a wave has 256 registers, and the 72-double half row + V + state spilled 8 values per iteration to scratch memory.
+template <typename R, int CHMAX, int KREG = CHMAX, typename KT, int BDN, class Hook>
 __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, int sg, int ul, bool active_g, int Rrow, int CH,
                                         const KT (&kin)[CHMAX], const R (&vrow)[6], const R (&vcol)[6], const R (&bj)[BDN], int vsoff, int vssel,
-                                        Hook&& hook) {
+                                        Hook&& hook, const R* ktail = nullptr, int kts = 0) {
+    auto KIN = [&](int c) -> R { return (c < KREG) ? (R)kin[c] : ktail[(c - KREG) * kts]; };
     static_assert(BDN == 4 || BDN == 12, "Bd: implicit (4) or explicit row (12)");
     typedef R R4 __attribute__((ext_vector_type(4)));
     typedef R R2 __attribute__((ext_vector_type(2)));
@@ -278,8 +287,8 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
                     for (int i = 0; i < BL; ++i) {
                         const int c0 = 2 * (blk * BL + i);
                         if (c0 + 1 < CHMAX) {
-                            if (i & 1) { acc2 = fma((R)kin[c0], vv[i][0], acc2); acc3 = fma((R)kin[c0 + 1], vv[i][1], acc3); }
-                            else { acc0 = fma((R)kin[c0], vv[i][0], acc0); acc1 = fma((R)kin[c0 + 1], vv[i][1], acc1); }
+                            if (i & 1) { acc2 = fma(KIN(c0), vv[i][0], acc2); acc3 = fma(KIN(c0 + 1), vv[i][1], acc3); }
+                            else { acc0 = fma(KIN(c0), vv[i][0], acc0); acc1 = fma(KIN(c0 + 1), vv[i][1], acc1); }
                         }
                     }
                 }
@@ -1080,6 +1089,14 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     const bool failed = sm[S::o_misc] != 0.0;
     const int vsoff = stepok ? igoff[js] : 0, vssel = vsoff + bsel;   // the step's own v = V w inside the v buffer
     __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
+    constexpr int KREG = (sizeof(R) == 8 && S::KTAIL > 0) ? CHMAX - S::KTAIL : CHMAX;
+    [[maybe_unused]] const R* ktail = nullptr;
+    if constexpr (KREG < CHMAX) {
+        R* kt = reinterpret_cast<R*>(sm + S::o_kt) + t;
+#pragma unroll
+        for (int cc = KREG; cc < CHMAX; ++cc) kt[(cc - KREG) * BT] = (R)kin64[cc];
+        ktail = kt;                                           // (published by the barriers in front of its first use)
+    }
     int status = -1, iters = 0;
     R x = R(0), yA = R(0), yB = R(0);
     if (!failed) {
@@ -1098,6 +1115,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
                 for (int i = 0; i < 12; ++i) bdd[i] = (double)bdrow[i];
                 xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bdd, vsoff, vssel, [] {});
+            } else if constexpr (KREG < CHMAX) {
+                xq = apply_kinv<double, CHMAX, KREG>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {}, ktail, BT);
             } else {
                 xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {});
             }
@@ -1172,7 +1191,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         float lastv0 = 0.0f, lastv1 = 0.0f, lastv2 = 0.0f, lastv3 = 0.0f;   // maxima of the last full check (restart rule)
         for (int k = 1; k <= a.max_iter + 1 && !done; ++k) {
             R* vb = vbuf + (k & 1) * S::VB;
-            const R kw = apply_kinv<R, CHMAX>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
+            const R kw = apply_kinv<R, CHMAX, KREG>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
                 if (pending) {   // decision of the check made at iteration k - 1 (its maxima were published by this barrier)
                     const float* buf = redf + ((nchk - 1) & 1) * 4 * NW;
                     float v0 = buf[0], v1 = buf[1], v2 = buf[2], v3 = buf[3];
@@ -1194,7 +1213,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                     for (int q = 0; q < NW; ++q) vsum |= vflag[q];
                     vote_ok = (vsum == 0);
                 }
-            });
+            }, ktail, BT);
             if (done || k > a.max_iter) break;
             const bool check = ((ph == 0) && vote_ok) || (k == a.max_iter);
             const bool pretest = (ph == a.check_every - 1);
