@@ -103,7 +103,10 @@ struct WrenchSmem {
     static constexpr int endC = o_scr + n + 2;
     // fp64 iterations with a half row longer than 60 (N = 24): its last KTAIL entries per lane, entry-major [KTAIL][BT] (the tiles
     // are dead by then and their region is far larger)
-    static constexpr int KTAIL = (TB == 8 && CHMAX > 60) ? CHMAX - 48 : 0;
+    #ifndef SRBDQP_WRENCH_KREG64
+#define SRBDQP_WRENCH_KREG64 56   // entries of the fp64 half row kept in registers when it is longer than 60 (N = 24 mixed gait: 56 -> 1.06 M QP/s with 2 reloads from scratch left in the iteration, 48 -> 1.03 M with none, 40 -> 1.01 M)
+#endif
+    static constexpr int KTAIL = (TB == 8 && CHMAX > 60) ? CHMAX - SRBDQP_WRENCH_KREG64 : 0;
     static constexpr int o_kt = up2(endC);
     static constexpr int endC2 = o_kt + KTAIL * BT;
     static constexpr int o_end = cmax(endA, cmax(endB, endC2));
