@@ -314,14 +314,14 @@ int launch_n(srbdqp_handle* h, const KArgs& a, hipStream_t st, int maxs) {
 template <int N, typename R, int TB = 8>
 struct WrenchTraits {
     using S = srbdqp::WrenchSmem<N, TB>;
-    static constexpr int by_lds = (S::lds_wgs * S::NW) / 4 > 0 ? (S::lds_wgs * S::NW) / 4 : 1;   // waves per SIMD LDS admits
+    static constexpr int by_lds = (S::lds_wgs * S::NW + 3) / 4 > 0 ? (S::lds_wgs * S::NW + 3) / 4 : 1;   // waves per SIMD LDS admits (rounded up: 3 workgroups of 3 waves put 3 waves on one SIMD)
 #ifdef SRBDQP_F32TILE_WPS   // experiments: waves per SIMD the fp32-tile instantiation is compiled for
     static constexpr int want = (TB == 4) ? SRBDQP_F32TILE_WPS : ((sizeof(R) == 4) ? 3 : (S::CHMAX <= 36 ? 2 : 1));
 #else
 #ifndef SRBDQP_F64_SMALL_WPS
 #define SRBDQP_F64_SMALL_WPS 3
 #endif
-    static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 24 ? SRBDQP_F64_SMALL_WPS : (S::CHMAX <= 60 ? 2 : 1));   // register budget
+    static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 36 ? SRBDQP_F64_SMALL_WPS : (S::CHMAX <= 60 ? 2 : 1));   // register budget
 #endif
     static constexpr int wps = by_lds < want ? by_lds : want;
 };

@@ -103,12 +103,19 @@ struct WrenchSmem {
     static constexpr int endC = o_scr + n + 2;
     // fp64 iterations with a half row longer than 60 (N = 24): its last KTAIL entries per lane, entry-major [KTAIL][BT] (the tiles
     // are dead by then and their region is far larger)
-    #ifndef SRBDQP_WRENCH_KREG64
+    #ifndef SRBDQP_WRENCH_KTAIL36
+#define SRBDQP_WRENCH_KTAIL36 12
+#endif
+#ifndef SRBDQP_WRENCH_VLDS
+#define SRBDQP_WRENCH_VLDS 1
+#endif
+#ifndef SRBDQP_WRENCH_KREG64
 #define SRBDQP_WRENCH_KREG64 56   // entries of the fp64 half row kept in registers when it is longer than 60 (N = 24 mixed gait: 56 -> 1.06 M QP/s with 2 reloads from scratch left in the iteration, 48 -> 1.03 M with none, 40 -> 1.01 M)
 #endif
-    static constexpr int KTAIL = (TB == 8 && CHMAX > 60) ? CHMAX - SRBDQP_WRENCH_KREG64 : 0;
+    static constexpr int KTAIL = (TB == 8 && CHMAX > 60) ? CHMAX - SRBDQP_WRENCH_KREG64 : ((TB == 8 && CHMAX == 36) ? SRBDQP_WRENCH_KTAIL36 : 0);   // N = 12: 3 waves per SIMD
     static constexpr int o_kt = up2(endC);
-    static constexpr int endC2 = o_kt + KTAIL * BT;
+    static constexpr int o_vl = o_kt + KTAIL * BT;        // VL: row and column of V per lane, entry-major [12][BT]
+    static constexpr int endC2 = o_vl + ((TB == 8 && SRBDQP_WRENCH_VLDS && CHMAX <= 36) ? 12 * BT : 0);
     static constexpr int o_end = cmax(endA, cmax(endB, endC2));
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr int lds_wgs = 163840 / (int)bytes;
@@ -178,11 +185,16 @@ __device__ __forceinline__ double wg_max1(double v, double* red) {
 // KREG < CHMAX (fp64 iterations at N = 24): the last CHMAX - KREG entries of the lane's T^-1 half row are read from LDS
 // (ktail[(c - KREG) kts], lane-contiguous per entry) instead of registers -- a 5-wave workgroup puts two waves on one SIMD,
 // so a wave has 256 registers, and the 72-double half row + V + state spilled 8 values per iteration to scratch memory.
-template <typename R, int CHMAX, int KREG = CHMAX, typename KT, int BDN, class Hook>
+// VL (fp64 iterations of the small instantiations, 3 waves per SIMD): the lane's row and column of V are read from LDS
+// (vlds[i kts] = vrow[i], vlds[(6 + i) kts] = vcol[i], lane-contiguous per entry) instead of 24 registers.
+template <typename R, int CHMAX, int KREG = CHMAX, bool VL = false, typename KT, int BDN, class Hook>
 __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, int sg, int ul, bool active_g, int Rrow, int CH,
-                                        const KT (&kin)[CHMAX], const R (&vrow)[6], const R (&vcol)[6], const R (&bj)[BDN], int vsoff, int vssel,
-                                        Hook&& hook, const R* ktail = nullptr, int kts = 0) {
+                                        const KT (&kin)[CHMAX], const R (&vrow_)[6], const R (&vcol_)[6], const R (&bj)[BDN], int vsoff, int vssel,
+                                        Hook&& hook, const R* ktail = nullptr, int kts = 0, const R* vlds = nullptr) {
     auto KIN = [&](int c) -> R { return (c < KREG) ? (R)kin[c] : ktail[(c - KREG) * kts]; };
+    R vrow[6], vcol[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { vrow[i] = VL ? vlds[i * kts] : vrow_[i]; }
     static_assert(BDN == 4 || BDN == 12, "Bd: implicit (4) or explicit row (12)");
     typedef R R4 __attribute__((ext_vector_type(4)));
     typedef R R2 __attribute__((ext_vector_type(2)));
@@ -302,6 +314,8 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
     const R tv = tp + dpp_swap1(tp);
     if (h == 0) tbw[6 * sg + (ul >> 1)] = active_g ? tv : R(0);
     asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { vcol[i] = VL ? vlds[(6 + i) * kts] : vcol_[i]; }
     R xt;
     {
         const R* src = tbw + 6 * sg;                        // 6 sg elements: 8-byte aligned (float), 16-byte (double)
@@ -1161,6 +1175,14 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         for (int cc = 0; cc < CHMAX; ++cc) kin[cc] = (R)kin64[cc];
 #pragma unroll
         for (int i = 0; i < 6; ++i) { vr[i] = (R)vrow[i]; vc[i] = (R)vcol[i]; }
+        constexpr bool VL = SRBDQP_WRENCH_VLDS && sizeof(R) == 8 && sizeof(TT) == 8 && CHMAX <= 36;
+        [[maybe_unused]] const R* vlds = nullptr;
+        if constexpr (VL) {
+            R* vt = reinterpret_cast<R*>(sm + S::o_vl) + t;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { vt[i * BT] = vr[i]; vt[(6 + i) * BT] = vc[i]; }
+            vlds = vt;                                        // own entries only: no barrier needed
+        }
 #pragma unroll
         for (int i = 0; i < BDN; ++i) bd[i] = BD_EXPLICIT ? (R)bdrow[i] : (R)bjv[i < 4 ? i : 0];
         const R xqr = (R)xq;
@@ -1194,7 +1216,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         float lastv0 = 0.0f, lastv1 = 0.0f, lastv2 = 0.0f, lastv3 = 0.0f;   // maxima of the last full check (restart rule)
         for (int k = 1; k <= a.max_iter + 1 && !done; ++k) {
             R* vb = vbuf + (k & 1) * S::VB;
-            const R kw = apply_kinv<R, CHMAX, KREG>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
+            const R kw = apply_kinv<R, CHMAX, KREG, VL>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
                 if (pending) {   // decision of the check made at iteration k - 1 (its maxima were published by this barrier)
                     const float* buf = redf + ((nchk - 1) & 1) * 4 * NW;
                     float v0 = buf[0], v1 = buf[1], v2 = buf[2], v3 = buf[3];
@@ -1216,7 +1238,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                     for (int q = 0; q < NW; ++q) vsum |= vflag[q];
                     vote_ok = (vsum == 0);
                 }
-            }, ktail, BT);
+            }, ktail, BT, vlds);
             if (done || k > a.max_iter) break;
             const bool check = ((ph == 0) && vote_ok) || (k == a.max_iter);
             const bool pretest = (ph == a.check_every - 1);
