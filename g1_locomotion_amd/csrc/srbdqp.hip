@@ -164,7 +164,9 @@ constexpr int kSplitMinBatch = 512;
 // Batches of at least this many QPs with more than 2 stance contacts in a step go to the general kernel at N <= 10 too
 // (measured, tools/schedule_bench.py: N = 10 double support 10.8 M QP/s against 4.2 M on the 4-wave compact kernel, mixed
 // gait 10.4 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
-constexpr int kWrenchMinBatch = 256;
+constexpr int kWrenchMinBatch = 768;      // re-measured at the end of round 2 (mixed gait, N = 10): 512 QPs 4.43 M QP/s compact / 4.17 M general,
+                                          // 1024 QPs 6.12 M / 7.57 M -- up to two QPs per CU the 4-wave kernel's shorter set-up wins
+constexpr int kWrenchMinBatchN20 = 256;   // N = 20: one workgroup per CU on the compact kernel, two on the general one
 
 // fp32 calls of at least this many QPs are split by tile precision (two launches + the classification kernel); smaller
 // ones run on fp64 tiles, where the third workgroup per CU would stay empty anyway.
@@ -177,7 +179,7 @@ inline bool uses_wrench(const srbdqp_handle* h, int maxs, int B) {
     // N = 20 single support too, for batches: the general kernel holds 2 workgroups per CU there, the compact one 1
     // (tools/schedule_bench.py, 16,384 QPs: 2.85 M QP/s against 1.95 M; at N = 12 / 16 the compact kernel wins, 7.1 / 4.9 M
     // against 5.7 / 4.2 M)
-    if (N > 10) return maxs > 2 || (N == 20 && h->cfg.kernel == SRBDQP_KERNEL_AUTO && B >= kWrenchMinBatch && !h->stamps && !h->signal_next);
+    if (N > 10) return maxs > 2 || (N == 20 && h->cfg.kernel == SRBDQP_KERNEL_AUTO && B >= kWrenchMinBatchN20 && !h->stamps && !h->signal_next);
     return h->cfg.kernel == SRBDQP_KERNEL_AUTO && maxs > 2 && B >= kWrenchMinBatch && !h->stamps && !h->signal_next;
 }
 

@@ -261,7 +261,7 @@ def test_large_batch_against_c_oracle(torch_first, built_lib, N, pattern, B):
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     with _engine(N) as eng:
         out = eng.solve(x0, xr, ft, ct)
-        # AUTO: the one-wave kernel (<= 2 stance contacts per step), the general kernel (more, batches >= 256) or compact
+        # AUTO: the one-wave kernel (<= 2 stance contacts per step), the general kernel (more, batches >= 768) or compact
         assert eng.kernel_name().startswith(("compact_", "wave_", "wrench_"))
     np.testing.assert_array_equal(out["status"], ref["status"])
     assert np.abs(out["iters"].astype(int) - ref["iters"].astype(int)).max() <= p.check_every
