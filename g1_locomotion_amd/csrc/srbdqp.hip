@@ -162,8 +162,8 @@ int set_lds_once(srbdqp_handle* h, K kernel, size_t lds) {
 constexpr int kSplitMinBatch = 512;
 
 // Batches of at least this many QPs with more than 2 stance contacts in a step go to the general kernel at N <= 10 too
-// (measured, tools/schedule_bench.py: N = 10 double support 10.8 M QP/s against 4.2 M on the 4-wave compact kernel, mixed
-// gait 10.4 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
+// (measured, tools/schedule_bench.py, 4096 QPs: N = 10 double support 13.5 M QP/s against 4.2 M on the 4-wave compact kernel,
+// mixed gait 13.9 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
 constexpr int kWrenchMinBatch = 768;      // re-measured at the end of round 2 (mixed gait, N = 10): 512 QPs 4.43 M QP/s compact / 4.17 M general,
                                           // 1024 QPs 6.12 M / 7.57 M -- up to two QPs per CU the 4-wave kernel's shorter set-up wins
 constexpr int kWrenchMinBatchN20 = 256;   // N = 20: one workgroup per CU on the compact kernel, two on the general one
