@@ -300,6 +300,9 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
 
     if constexpr (PHI) {
         double* phi = ws + W::o_phi;
+        // the x0 the gradient above was formed with (NOT re-read from the staging array afterwards: the host may already have
+        // written the measured state there while this kernel runs)
+        const double x0_keep = (lane < 13) ? sm[S::o_x0 + lane] : 0.0;
         for (int kc = 0; kc < 13; ++kc) {
             __syncthreads();
             if (lane < 13) sm[S::o_x0 + lane] = (lane == kc) ? 1.0 : 0.0;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
             for (int c = lane; c < n_eff; c += 64) phi[c * 13 + kc] = gt_eval(c);
         }
         __syncthreads();
-        if (lane < 13) sm[S::o_x0 + lane] = a.x0[(size_t)b * 13 + lane];
+        if (lane < 13) sm[S::o_x0 + lane] = x0_keep;
         __syncthreads();
     }
     WSTAMP(a, b, 3);
