@@ -344,7 +344,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     constexpr int n = S::n, m = S::m, NW = S::NW, BT = S::BT, TS = S::TS, CHMAX = S::CHMAX;
     static_assert((S::o_R % 2) == 0 && (S::o_wb % 2) == 0 && (S::o_tb % 2) == 0 && (S::o_vb % 2) == 0, "16-byte alignment");
     static_assert(S::NT <= 2 * NW || S::WQ >= 1, "");
-    const double rho_b = SRBDQP_RHO_OF(a, b);
+    const double rho_b = uni(SRBDQP_RHO_OF(a, b));   // (per-QP values are wave-uniform: scalar registers, see uni())
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     int mcol = lane & 15, kq = lane >> 4;
@@ -437,26 +437,30 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
         __syncthreads();
     }
-    const int n_g = imisc[0];
-    const int na = imisc[1];
+    const int n_g = __builtin_amdgcn_readfirstlane(imisc[0]);
+    const int na = __builtin_amdgcn_readfirstlane(imisc[1]);
 
-    // ---- lane roles
-    const int sg = lane / 12, ul = lane - 12 * sg;
-    const int jstep = 5 * w + sg;
-    const bool stepok = (sg < 5) && (jstep < N);
-    const int js = stepok ? jstep : 0;
-    const int ci = ul / 3, ax = ul - 3 * ci;
-    const int rl = ul >> 1, h = ul & 1;
-    const int f0 = sct[4 * js], f1 = sct[4 * js + 1], f2 = sct[4 * js + 2], f3 = sct[4 * js + 3];
-    const int cj = f0 + f1 + f2 + f3;
-    const bool wrench = cj >= 3;
-    const bool active_u = stepok && sct[4 * js + ci] != 0;
-    const int gsj = stepok ? igsz[js] : 0;
-    const bool active_g = rl < gsj;
-    const int Rrow = igoff[js] + (active_g ? rl : 0);
-    const int uvar = 12 * js + ul;                                   // index in the full 12N vector
-    const int cbase = 12 * sg + 3 * ci;                              // first lane of this contact in the wave
-    const int irowA = 20 * js + 5 * ci + ((ax < 2) ? 2 * ax : 4), irowB = 20 * js + 5 * ci + 2 * ax + 1;
+    // ---- lane roles (plain variables: derived a second time behind the factorisation in the fp32-tile kernel, see REROLE below)
+    int sg, ul, js, ci, ax, rl, h, f0, f1, f2, f3, gsj, Rrow, uvar, cbase, irowA, irowB;
+    bool stepok, wrench, active_u, active_g;
+    auto lane_roles = [&](const int ln) __attribute__((always_inline)) {
+        sg = ln / 12; ul = ln - 12 * sg;
+        const int jstep = 5 * w + sg;
+        stepok = (sg < 5) && (jstep < N);
+        js = stepok ? jstep : 0;
+        ci = ul / 3; ax = ul - 3 * ci;
+        rl = ul >> 1; h = ul & 1;
+        f0 = sct[4 * js]; f1 = sct[4 * js + 1]; f2 = sct[4 * js + 2]; f3 = sct[4 * js + 3];
+        wrench = (f0 + f1 + f2 + f3) >= 3;
+        active_u = stepok && sct[4 * js + ci] != 0;
+        gsj = stepok ? igsz[js] : 0;
+        active_g = rl < gsj;
+        Rrow = igoff[js] + (active_g ? rl : 0);
+        uvar = 12 * js + ul;                                         // index in the full 12N vector
+        cbase = 12 * sg + 3 * ci;                                    // first lane of this contact in the wave
+        irowA = 20 * js + 5 * ci + ((ax < 2) ? 2 * ax : 4); irowB = 20 * js + 5 * ci + 2 * ax + 1;
+    };
+    lane_roles(lane);
 
     if constexpr (MODE == 1) { if (na == 0) return; }   // assembly dump of an empty problem: all zeros (the host cleared the buffers)
     if (na == 0) {   // nothing to solve: all forces 0
@@ -467,7 +471,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     } else {
 
     // ================= tables of the closed-form assembly (a6 + a7; srbdqp_compact.hpp has the derivation) =================
-    const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = dt2 * a.inv_mass;
+    const double dt = a.dt, dt2 = uni(a.dt * a.dt), dtm = uni(a.dt * a.inv_mass), dt2m = uni(dt2 * a.inv_mass);
     double* T1 = sm + S::o_t1;
     double* T2 = sm + S::o_t2;
     double* MT = sm + S::o_mt;
@@ -607,8 +611,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     }
 
     // ================= per-step wrench blocks: E^-1, V, Bd (registers of the step's lanes) =================
-    const double dxy = a.rs2 + a.sigma + 2.0 * rho_b, dz = a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b;
-    const double idxy = 1.0 / dxy, idz = 1.0 / dz;
+    const double dxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b);
+    const double idxy = uni(1.0 / dxy), idz = uni(1.0 / dz);
     // fp32 tiles (3 workgroups per CU, 168 registers): the rows / columns of V and Bd are formed AFTER the factorisation, from
     // the triangle of E^-1 kept in LDS behind the tiles, and held in fp32 from then on.  Formed here they waited in scratch
     // memory across phases F / W / I: 10 GB of HBM traffic per 65,536-QP launch against 0.29 GB of inputs and outputs
@@ -618,14 +622,19 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     VS vrow[6], vcol[6];
     double bjv[4];                                                   // bjv: J[:, u] of the lane's variable and 1 / D_u (apply_kinv)
     constexpr bool BD_EXPLICIT = (sizeof(R) == 4) || (MODE == 1);     // fp32 iterations and the assembly dump: Bd rows (apply_kinv)
+#ifndef SRBDQP_WRENCH_BD_LAST
+#define SRBDQP_WRENCH_BD_LAST 1
+#endif
+    constexpr bool BD_LAST = SRBDQP_WRENCH_BD_LAST && VBD_LATE && BD_EXPLICIT;   // ... formed after x_q and its refinement (form_bd)
     // explicit Bd rows: fp32 from the start in the fp32-tile kernel (only the iterations use them there; x_q and its refinement
     // run in fp64, where the implicit form is exact enough) -- 12 registers instead of 24 next to the T^-1 row
     typedef typename std::conditional<sizeof(TT) == 4, float, double>::type BS;
     [[maybe_unused]] BS bdrow[12];
     int bsel = 0;                                                    // g row (within the step) of the unit part of Y'[:, u]
-    const int before_ci = (ci > 0 ? f0 : 0) + (ci > 1 ? f1 : 0) + (ci > 2 ? f2 : 0);   // stance contacts of the step before ci
+    int before_ci = 0;                                               // stance contacts of the step before ci
     int ug_id = 0;                                                   // force-variable step: variable (0..11) of g row rl
-    {
+    auto lane_roles2 = [&]() __attribute__((always_inline)) {
+        before_ci = (ci > 0 ? f0 : 0) + (ci > 1 ? f1 : 0) + (ci > 2 ? f2 : 0);
         const int want = rl / 3;
         int cc = -1, seen = 0;
         if (f0) { if (seen == want && cc < 0) cc = 0; ++seen; }
@@ -633,7 +642,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         if (f2) { if (seen == want && cc < 0) cc = 2; ++seen; }
         if (f3) { if (seen == want && cc < 0) cc = 3; ++seen; }
         ug_id = (cc >= 0 ? 3 * cc : 0) + (rl % 3);
-    }
+    };
+    lane_roles2();
     // registers of V and Bd of a wrench step from er = row rl of E^-1 and yv = E^-1 omega_u, omega_u = [J[:, ul]; e_ax]
     // (the callers form the two from the register matrix in phase E, from the LDS triangle for the late formation; E^-1
     // itself must not be captured here: a by-reference capture turns its select chains into an indexed scratch array)
@@ -653,13 +663,26 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
         for (int r = 0; r < 6; ++r) vcol[r] = (VS)(wu * yv[r]);
         bjv[0] = j0; bjv[1] = j1; bjv[2] = j2; bjv[3] = wu; bsel = 3 + ax;
-        if constexpr (BD_EXPLICIT) {
+        if constexpr (BD_EXPLICIT && !BD_LAST) {
 #pragma unroll
             for (int u2 = 0; u2 < 12; ++u2) {
                 const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
                 const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
                 bdrow[u2] = (BS)(((u2 == ul) ? wu : 0.0) - wu * wgt2 * dotv);   // D^-1 - D^-1 Y' V (static index: select chain)
             }
+        }
+    };
+    // the explicit Bd row alone (fp32 tiles: formed after x_q and its refinement, which use the implicit form -- 12 registers
+    // less across those two fp64 applications of K^-1)
+    [[maybe_unused]] auto form_bd = [&](const double (&yv)[6]) __attribute__((always_inline)) {
+        const double* Jj = sm + S::o_J + js * 36;
+        const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
+        const double wu = active_u ? ((ax < 2) ? idxy : idz) : 0.0;
+#pragma unroll
+        for (int u2 = 0; u2 < 12; ++u2) {
+            const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
+            const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
+            bdrow[u2] = (BS)(((u2 == ul) ? wu : 0.0) - wu * wgt2 * dotv);
         }
     };
     // ... of a force-variable step: V = the selection of the stance variables, Bd = 0
@@ -670,7 +693,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
         for (int r = 0; r < 6; ++r) vcol[r] = (active_u && r == rank) ? VS(1) : VS(0);
         bjv[0] = 0.0; bjv[1] = 0.0; bjv[2] = 0.0; bjv[3] = 0.0; bsel = active_u ? rank : 0;
-        if constexpr (BD_EXPLICIT) {
+        if constexpr (BD_EXPLICIT && !BD_LAST) {
 #pragma unroll
             for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] = BS(0);
         }
@@ -1070,6 +1093,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     __syncthreads();
     SRBDQP_STAMP(a, b, 6);
 
+#ifndef SRBDQP_WRENCH_REROLE
+#define SRBDQP_WRENCH_REROLE 1
+#endif
+    if constexpr (SRBDQP_WRENCH_REROLE && (VBD_LATE || SRBDQP_WRENCH_REROLE > 1)) {
+        // the lane roles again, from a lane index the compiler cannot trace: the first set is dead from the last use in phase E on
+        // instead of waiting in scratch memory across phases F / W / I (24 registers of the 168; the flags come from LDS again)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        lane_roles(ln);
+        lane_roles2();
+    }
     if constexpr (VBD_LATE) {   // rows / columns of V and Bd now that the accumulator tiles are gone (see phase E)
         if (wrench) {
             const double* E4 = sm + S::o_e4 + 21 * js;
@@ -1161,6 +1195,21 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
         SRBDQP_STAMP(a, b, 7);
 
+        if constexpr (BD_LAST) {
+            if (wrench) {
+                const double* E4 = sm + S::o_e4 + 21 * js;
+                auto tri = [&](int r, int c) -> double { const int hi = r > c ? r : c, lo = r > c ? c : r; return E4[(hi * (hi + 1)) / 2 + lo]; };
+                const double* Jj = sm + S::o_J + js * 36;
+                const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
+                double yv[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) yv[r] = tri(r, 0) * j0 + tri(r, 1) * j1 + tri(r, 2) * j2 + tri(r, 3 + ax);
+                form_bd(yv);
+            } else {
+#pragma unroll
+                for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] = BS(0);
+            }
+        }
         // ================= ADMM iterations (a9) in R =================
         R* wbw = reinterpret_cast<R*>(sm + S::o_wb) + 64 * w;
         R* tbw = reinterpret_cast<R*>(sm + S::o_tb) + 32 * w;

@@ -32,6 +32,9 @@ for b in (1, B):
     print(f"B={b} kernel={eng.kernel_name()} {sched} mean iters {its.mean():.1f}")
     for i, nm in enumerate(names):
         print(f"  {nm:18s} mean {dl[:, i].mean():9.0f} cyc   median {np.median(dl[:, i]):9.0f}")
+    if s[:, 10].any():   # inside "fragments + x_q": 6 -> 10 late V / Bd + half rows, 10 -> 11 x_q, 11 -> 12 G'(G x_q), 12 -> 7 refinement step
+        sub = [s[:, 10] - s[:, 6], s[:, 11] - s[:, 10]] + ([s[:, 12] - s[:, 11], s[:, 7] - s[:, 12]] if s[:, 12].any() else [s[:, 7] - s[:, 11]])
+        print("    of which late V / Bd + half rows, x_q" + (", G'(G x_q), refinement step" if s[:, 12].any() else ", rest") + ": " + " ".join(f"{v.mean():.0f}" for v in sub))
     tot = s[:, 9] - s[:, 0]
     print(f"  total              mean {tot.mean():9.0f} cyc   per ADMM iteration {np.mean(dl[:, 7] / np.maximum(its, 1)):.0f} cyc   set-up share {1 - dl[:, 7].mean() / tot.mean():.2f}")
     eng.close()
