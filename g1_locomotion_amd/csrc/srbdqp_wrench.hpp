@@ -116,6 +116,15 @@ struct WrenchSmem {
     static constexpr int o_kt = up2(endC);
     static constexpr int o_vl = o_kt + KTAIL * BT;        // VL: row and column of V per lane, entry-major [12][BT]
     static constexpr int endC2 = o_vl + ((TB == 8 && SRBDQP_WRENCH_VLDS && CHMAX <= 36) ? 12 * BT : 0);
+    // fp32 tiles, long horizons: the lane's fp64 row and column of V wait in the dead tile region while x_q and its refinement run
+    // (entry-major [6][n] each, indexed by the lane's variable; two free regions: behind the ADMM vectors up to the G'v tables the
+    // refinement still needs, and the 6-vectors + E^-1 blocks of the assembly) -- they were the larger half of the kernel's spills
+#ifndef SRBDQP_WRENCH_VPARK
+#define SRBDQP_WRENCH_VPARK 1
+#endif
+    static constexpr int o_vpr = up2(endC);
+    static constexpr int o_vpc = o_zt;
+    static constexpr bool VPARK = TB == 4 && SRBDQP_WRENCH_VPARK && (o_gv - o_vpr >= 6 * n) && (o_vpc + 6 * n <= o_e4);
     static constexpr int o_end = cmax(endA, cmax(endB, endC2));
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr int lds_wgs = 163840 / (int)bytes;
@@ -190,7 +199,7 @@ __device__ __forceinline__ double wg_max1(double v, double* red) {
 template <typename R, int CHMAX, int KREG = CHMAX, bool VL = false, typename KT, int BDN, class Hook>
 __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, int sg, int ul, bool active_g, int Rrow, int CH,
                                         const KT (&kin)[CHMAX], const R (&vrow_)[6], const R (&vcol_)[6], const R (&bj)[BDN], int vsoff, int vssel,
-                                        Hook&& hook, const R* ktail = nullptr, int kts = 0, const R* vlds = nullptr) {
+                                        Hook&& hook, const R* ktail = nullptr, int kts = 0, const R* vlds = nullptr, const R* vldc = nullptr) {
     auto KIN = [&](int c) -> R { return (c < KREG) ? (R)kin[c] : ktail[(c - KREG) * kts]; };
     R vrow[6], vcol[6];
 #pragma unroll
@@ -315,7 +324,7 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
     if (h == 0) tbw[6 * sg + (ul >> 1)] = active_g ? tv : R(0);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { vcol[i] = VL ? vlds[(6 + i) * kts] : vcol_[i]; }
+    for (int i = 0; i < 6; ++i) { vcol[i] = VL ? (vldc ? vldc[i * kts] : vlds[(6 + i) * kts]) : vcol_[i]; }
     R xt;
     {
         const R* src = tbw + 6 * sg;                        // 6 sg elements: 8-byte aligned (float), 16-byte (double)
@@ -1104,7 +1113,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         lane_roles(ln);
         lane_roles2();
     }
-    if constexpr (VBD_LATE) {   // rows / columns of V and Bd now that the accumulator tiles are gone (see phase E)
+    constexpr bool VPARK = VBD_LATE && S::VPARK;
+    auto late_vbd = [&]() __attribute__((always_inline)) {   // rows / columns of V and Bd now that the accumulator tiles are gone (see phase E)
         if (wrench) {
             const double* E4 = sm + S::o_e4 + 21 * js;
             auto tri = [&](int r, int c) -> double { const int hi = r > c ? r : c, lo = r > c ? c : r; return E4[(hi * (hi + 1)) / 2 + lo]; };
@@ -1119,6 +1129,9 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         } else {
             form_vbd_identity();
         }
+    };
+    if constexpr (VBD_LATE && !VPARK) {
+        late_vbd();
         asm volatile("" ::: "memory");   // keep the reads of the T^-1 rows below this block (their 60 registers)
     }
     // ================= half rows of T^-1 (in the tiles' type), then x_q = -K^-1 q accumulated in fp64 =================
@@ -1138,8 +1151,20 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
     }
     const bool failed = sm[S::o_misc] != 0.0;
-    const int vsoff = stepok ? igoff[js] : 0, vssel = vsoff + bsel;   // the step's own v = V w inside the v buffer
+    const int vsoff = stepok ? igoff[js] : 0;                         // the step's own v = V w inside the v buffer
     __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
+    [[maybe_unused]] const double* vpr = sm + S::o_vpr + (stepok ? uvar : 0);
+    [[maybe_unused]] const double* vpc = sm + S::o_vpc + (stepok ? uvar : 0);
+    if constexpr (VPARK) {   // V formed only now, and parked in the dead tile region until the iterations start
+        late_vbd();
+        if (stepok) {
+            double* pr = sm + S::o_vpr + uvar;
+            double* pc = sm + S::o_vpc + uvar;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { pr[i * n] = vrow[i]; pc[i * n] = vcol[i]; }   // own entries only: no barrier needed
+        }
+    }
+    const int vssel = vsoff + bsel;
     constexpr int KREG = (sizeof(R) == 8 && S::KTAIL > 0) ? CHMAX - S::KTAIL : CHMAX;
     [[maybe_unused]] const R* ktail = nullptr;
     if constexpr (KREG < CHMAX) {
@@ -1161,8 +1186,10 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             double vrd[6], vcd[6];
             [[maybe_unused]] double bdd[12];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { vrd[i] = (double)vrow[i]; vcd[i] = (double)vcol[i]; }
-            if constexpr (BD_EXPLICIT && !VBD_LATE) {
+            for (int i = 0; i < 6; ++i) { vrd[i] = VPARK ? 0.0 : (double)vrow[i]; vcd[i] = VPARK ? 0.0 : (double)vcol[i]; }
+            if constexpr (VPARK) {
+                xq = apply_kinv<double, CHMAX, CHMAX, true>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {}, nullptr, n, vpr, vpc);
+            } else if constexpr (BD_EXPLICIT && !VBD_LATE) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) bdd[i] = (double)bdrow[i];
                 xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bdd, vsoff, vssel, [] {});
@@ -1188,7 +1215,9 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const double rres = active_u ? fma(dl, xq, gtg + qv) : 0.0;
                 for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
                 __syncthreads();
-                const double dxq = apply_kinv<double, CHMAX>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {});
+                double dxq;
+                if constexpr (VPARK) dxq = apply_kinv<double, CHMAX, CHMAX, true>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {}, nullptr, n, vpr, vpc);
+                else dxq = apply_kinv<double, CHMAX>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {});
                 xq = active_u ? xq + dxq : 0.0;
                 __syncthreads();
             }
@@ -1223,7 +1252,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
         for (int cc = 0; cc < CHMAX; ++cc) kin[cc] = (R)kin64[cc];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { vr[i] = (R)vrow[i]; vc[i] = (R)vcol[i]; }
+        for (int i = 0; i < 6; ++i) { vr[i] = VPARK ? (R)vpr[i * n] : (R)vrow[i]; vc[i] = VPARK ? (R)vpc[i * n] : (R)vcol[i]; }
         constexpr bool VL = SRBDQP_WRENCH_VLDS && sizeof(R) == 8 && sizeof(TT) == 8 && CHMAX <= 36;
         [[maybe_unused]] const R* vlds = nullptr;
         if constexpr (VL) {
