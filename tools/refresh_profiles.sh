@@ -26,7 +26,8 @@ run ${RR}_error_distribution_config2.json 400 python tools/error_distribution.py
 fi
 if [ "$PART" = all ] || [ "$PART" = sweeps ]; then
 { echo "# tools/schedule_bench.py on 1 x MI355X (4 rotating batches, 2 streams + longest-first hint, device-resident inputs)"
-  for a in "double 10 4096" "mixed 10 4096" "single 8 4096" "single 16 16384" "single 20 16384" "double 16 16384" "mixed 24 16384" "double 20 65536 auto 1" "single 20 16384 wrench 1" "mixed 24 16384 wrench 1"; do
+  for a in "double 10 4096" "mixed 10 4096" "double 10 16384" "mixed 8 4096" "single 8 4096" "single 12 16384" "mixed 12 16384" "single 16 16384" "mixed 16 16384" "double 16 16384" "single 20 16384" "mixed 20 16384" "double 20 16384" "mixed 24 16384" \
+           "mixed 10 4096 auto 1" "mixed 12 16384 auto 1" "double 16 16384 auto 1" "double 20 65536 auto 1" "single 20 16384 wrench 1" "mixed 24 16384 wrench 1"; do
       $T 100 python tools/schedule_bench.py $a 2>> $O/schedules.err || echo "FAILED: schedule_bench $a"; done; } > $O/${RR}_other_schedules.txt
 rm -f $O/batch_sweep.jsonl
 for B in 1 8 64 512 4096 32768 65536 262144; do
