@@ -14,7 +14,7 @@ f32 = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
 restart = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 dev = torch.device("cuda", 0)
 tdt = torch.float32 if f32 else torch.float64
-NB, S = 4, 2
+NB, S = 4, int(os.environ.get("STREAMS", "2"))
 d = [[torch.from_numpy(v).to(dev).to(tdt) if v.dtype == np.float64 else torch.from_numpy(v).to(dev) for v in synth.synthetic_batch(B, N, seed=77 + j, schedule=sched)] for j in range(NB)]
 maxs = 2 if sched == "single" else 4
 kid = {"auto": _lib.KERNEL_AUTO, "compact": _lib.KERNEL_COMPACT, "wave": _lib.KERNEL_WAVE, "wrench": _lib.KERNEL_WRENCH, "split": _lib.KERNEL_SPLIT}[kern]
