@@ -79,6 +79,40 @@ __device__ __forceinline__ double restart_rho_of(double rho0, const float* r) {
 #define SRBDQP_RESTART_SKIP(a, b) ((a).resid_in && (a).status[(b)] != 2)
 #define SRBDQP_RHO_OF(a, b) ((a).resid_in ? restart_rho_of((a).rho, (a).resid_in + (size_t)(b) * 4) : ((a).rho_qp ? (a).rho_qp[(b)] : (a).rho))
 
+// M(j, m), j <= m, of the closed-form assembly (derivation: srbdqp_compact.hpp, phase A) at MT[9 (m (m + 1) / 2 + j)]: one step
+// pair = one thread = its 9 entries (the index inversion, the 18 prefix-sum values and the 9 T1 entries are read once per pair;
+// entry by entry over all threads it was 4 x the instructions: 9.8 k -> 3.6 k cycles at N = 20 with three QPs per CU)
+template <int N>
+__device__ __forceinline__ void mt_tables(const double* CP, const double* T1, const double* T2, const double* SQ, const double dt2,
+                                          double* MT, const int t, const int nthreads) {
+    constexpr int NPAIR = N * (N + 1) / 2;
+    for (int pair = t; pair < NPAIR; pair += nthreads) {
+        int mm = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
+        mm += ((mm + 1) * (mm + 2) / 2 <= pair) ? 1 : 0;
+        mm -= (mm * (mm + 1) / 2 > pair) ? 1 : 0;
+        const int j = pair - mm * (mm + 1) / 2;
+        const double* Cm = CP + mm * 9;
+        const double* Cj = CP + j * 9;
+        const double* t1 = T1 + mm * 9;
+        const double* t2 = T2 + mm * 9;
+        const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2], d4 = dt2 * dt2, dl = (double)(N - mm) * dt2;
+        double dC[9], tt[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { dC[i] = Cm[i] - Cj[i]; tt[i] = t1[i]; }
+        double* out = MT + 9 * pair;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                double v = t2[3 * p + q];
+                v += dC[p] * w0 * tt[q] + dC[3 + p] * w1 * tt[3 + q] + dC[6 + p] * w2 * tt[6 + q];
+                v *= d4;
+                if (p == q) v += dl * SQ[6 + p] * SQ[6 + p];
+                out[3 * p + q] = v;
+            }
+    }
+}
+
 // diagnostic phase stamp (thread 0 only; leaves the kernel through a buffer nothing else reads)
 #define SRBDQP_STAMP(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 

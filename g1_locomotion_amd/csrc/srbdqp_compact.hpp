@@ -492,22 +492,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
         return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
     };
     gt_tables(sm + S::o_eh);
-    // M(j, m), j <= m, at MT[9 (m (m + 1) / 2 + j)]
-    for (int idx = t; idx < 9 * S::NPAIR; idx += kThreads) {
-        const int pair = idx / 9, pq = idx - 9 * pair, p = pq / 3, q = pq - 3 * p;
-        int mm = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
-        mm += ((mm + 1) * (mm + 2) / 2 <= pair) ? 1 : 0;
-        mm -= (mm * (mm + 1) / 2 > pair) ? 1 : 0;
-        const int j = pair - mm * (mm + 1) / 2;
-        const double* Cm = CP + mm * 9;
-        const double* Cj = CP + j * 9;
-        const double* t1 = T1 + mm * 9;
-        double v = T2[mm * 9 + pq];
-        v += (Cm[p] - Cj[p]) * (SQ[0] * SQ[0]) * t1[q] + (Cm[3 + p] - Cj[3 + p]) * (SQ[1] * SQ[1]) * t1[3 + q] + (Cm[6 + p] - Cj[6 + p]) * (SQ[2] * SQ[2]) * t1[6 + q];
-        v *= dt2 * dt2;
-        if (p == q) v += (double)(N - mm) * dt2 * SQ[6 + p] * SQ[6 + p];
-        MT[idx] = v;
-    }
+    mt_tables<N>(CP, T1, T2, SQ, dt2, MT, t, kThreads);
     __syncthreads();
     SRBDQP_STAMP(a, b, 2);
     for (int c = t; c < n_eff; c += kThreads) sm[S::o_q + c] = gt_eval(c);

@@ -407,17 +407,25 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             Tm[3] = -sn; Tm[4] = cs;  Tm[5] = 0.0;
             Tm[6] = 0.0; Tm[7] = 0.0; Tm[8] = 1.0;
         }
-        if (t == BT - 1) {   // presolve bookkeeping: g coordinates per step (serial over <= 24 steps)
-            int off = 0, na = 0, allw = 1;
-            for (int k = 0; k < N; ++k) {
-                const int c = sct[4 * k] + sct[4 * k + 1] + sct[4 * k + 2] + sct[4 * k + 3];
+        if (t >= BT - 64 && t < BT - 64 + N) {
+            // presolve bookkeeping: g coordinates per step.  One lane per step (last wave; the first one is in sincos): every lane
+            // walks the flag words of all steps -- N independent LDS reads instead of a serial chain of N dependent ones on one
+            // thread (15 k cycles of the 45 k of this phase at N = 20 with three QPs per CU, tools/wrench_stamps.py sub-stamps)
+            const int k = t - (BT - 64);
+            const uint32_t* cw = reinterpret_cast<const uint32_t*>(sct);          // 4 flags (0 / 1) per step
+            int off = 0, tot = 0, na = 0, allw = 1, gk = 0, wk = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int c = __popc(cw[j]);
                 const int g = (c >= 3) ? 6 : 3 * c;
+                off += (j < k) ? g : 0;
+                tot += g; na += c;
                 allw &= (c >= 3) ? 1 : 0;
-                igsz[k] = g; igoff[k] = off; iwr[k] = (c >= 3) ? 1 : 0;
-                for (int r = 0; r < g; ++r) gstep[off + r] = (uint8_t)k;
-                off += g; na += c;
+                if (j == k) { gk = g; wk = (c >= 3) ? 1 : 0; }
             }
-            igoff[N] = off; imisc[0] = off; imisc[1] = na; iwr[N] = allw;   // iwr[N]: every step in wrench coordinates
+            igsz[k] = gk; igoff[k] = off; iwr[k] = wk;
+            for (int r = 0; r < gk; ++r) gstep[off + r] = (uint8_t)k;
+            if (k == N - 1) { igoff[N] = tot; imisc[0] = tot; imisc[1] = na; iwr[N] = allw; }   // iwr[N]: every step in wrench coordinates
         }
         __syncthreads();
         if (t < 9) {
@@ -541,21 +549,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
     };
     gt_tables(sm + S::o_eh);
-    for (int idx = t; idx < 9 * S::NPAIR; idx += BT) {   // M(j, m), j <= m, at MT[9 (m (m + 1) / 2 + j)]
-        const int pair = idx / 9, pq = idx - 9 * pair, p = pq / 3, q = pq - 3 * p;
-        int mm = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
-        mm += ((mm + 1) * (mm + 2) / 2 <= pair) ? 1 : 0;
-        mm -= (mm * (mm + 1) / 2 > pair) ? 1 : 0;
-        const int j = pair - mm * (mm + 1) / 2;
-        const double* Cm = CP + mm * 9;
-        const double* Cj = CP + j * 9;
-        const double* t1 = T1 + mm * 9;
-        double v = T2[mm * 9 + pq];
-        v += (Cm[p] - Cj[p]) * (SQ[0] * SQ[0]) * t1[q] + (Cm[3 + p] - Cj[3 + p]) * (SQ[1] * SQ[1]) * t1[3 + q] + (Cm[6 + p] - Cj[6 + p]) * (SQ[2] * SQ[2]) * t1[6 + q];
-        v *= dt2 * dt2;
-        if (p == q) v += (double)(N - mm) * dt2 * SQ[6 + p] * SQ[6 + p];
-        MT[idx] = v;
-    }
+    mt_tables<N>(CP, T1, T2, SQ, dt2, MT, t, BT);
     __syncthreads();
     SRBDQP_STAMP(a, b, 1);
     const double qv = active_u ? gt_eval_u() : 0.0;                  // gradient of this lane's variable
