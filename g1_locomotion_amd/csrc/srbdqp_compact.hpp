@@ -460,29 +460,33 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
     __syncthreads();
     // G'v tables: per step j the 3-vector g (theta + omega rows) and the per-axis sums of the p and v rows
     auto gt_tables = [&](const double* vec) {
-        if (t < 9 * N) {
-            const int j = t / 9, comp = t - 9 * j;
+        // torque entries (O(N) loop of 7 LDS reads) on the first wave(s), force entries (1 read) on the following ones
+        constexpr int GT_HL = 64 * ((3 * N + 63) / 64);
+        static_assert(GT_HL + 6 * N <= kThreads, "one pass over the G'v tables");
+        if (t < 3 * N) {
+            const int j = t / 3, comp = t - 3 * j;
             const double* Cj = CP + j * 9;
             double acc = 0.0;
-            if (comp < 3) {
-                const double c0 = Cj[comp], c1 = Cj[3 + comp], c2 = Cj[6 + comp];
-                const double q0 = SQ[0] * dt2, q1 = SQ[1] * dt2, q2 = SQ[2] * dt2, qw = SQ[6 + comp] * dt;
+            const double c0 = Cj[comp], c1 = Cj[3 + comp], c2 = Cj[6 + comp];
+            const double q0 = SQ[0] * dt2, q1 = SQ[1] * dt2, q2 = SQ[2] * dt2, qw = SQ[6 + comp] * dt;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const double* Ci = CP + i * 9;
-                    const double* v = vec + 12 * i;
-                    const double on = (i >= j) ? 1.0 : 0.0;
-                    acc = fma(on, (Ci[comp] - c0) * (q0 * v[0]) + (Ci[3 + comp] - c1) * (q1 * v[1]) + (Ci[6 + comp] - c2) * (q2 * v[2]) + qw * v[6 + comp], acc);
-                }
-            } else {
-                const int kk = (comp < 6) ? comp : 3 + comp;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const double wgt = (i >= j) ? ((comp < 6) ? (double)(i - j) : 1.0) : 0.0;
-                    acc = fma(wgt, vec[12 * i + kk], acc);
-                }
+            for (int i = 0; i < N; ++i) {
+                const double* Ci = CP + i * 9;
+                const double* v = vec + 12 * i;
+                const double on = (i >= j) ? 1.0 : 0.0;
+                acc = fma(on, (Ci[comp] - c0) * (q0 * v[0]) + (Ci[3 + comp] - c1) * (q1 * v[1]) + (Ci[6 + comp] - c2) * (q2 * v[2]) + qw * v[6 + comp], acc);
             }
-            GV[t] = acc;
+            GV[9 * j + comp] = acc;
+        } else if (t >= GT_HL && t < GT_HL + 6 * N) {
+            const int e = t - GT_HL, j = e / 6, comp = 3 + (e - 6 * j);
+            const int kk = (comp < 6) ? comp : 3 + comp;
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double wgt = (i >= j) ? ((comp < 6) ? (double)(i - j) : 1.0) : 0.0;
+                acc = fma(wgt, vec[12 * i + kk], acc);
+            }
+            GV[9 * j + comp] = acc;
         }
     };
     auto gt_eval = [&](int c) -> double {   // (G'v)[c] for compact variable c, from the tables

@@ -203,23 +203,31 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     }
     __syncthreads();
     auto gt_tables = [&](const double* vec) {
-        for (int tt = lane; tt < 9 * N; tt += 64) {
-            const int j = tt / 9, comp = tt - 9 * j;
+        // the 3 torque entries of a step (an O(N) loop of 7 LDS reads) first, then the 6 force entries (1 read), the latter starting on
+        // the lanes the former leave free: entry by entry every round of the wave ran all three loops (N = 10: 2 x 3 loops -> 1 + 2)
+        for (int e = lane; e < 3 * N; e += 64) {
+            const int j = e / 3, comp = e - 3 * j;
             const double* Cj = CP + j * 9;
             double acc = 0.0;
-            if (comp < 3) {
-                for (int i = j; i < N; ++i) {
-                    const double* Ci = CP + i * 9;
-                    const double* v = vec + 12 * i;
-                    acc += dt2 * ((Ci[comp] - Cj[comp]) * (SQ[0] * v[0]) + (Ci[3 + comp] - Cj[3 + comp]) * (SQ[1] * v[1]) +
-                                  (Ci[6 + comp] - Cj[6 + comp]) * (SQ[2] * v[2])) + dt * (SQ[6 + comp] * v[6 + comp]);
-                }
-            } else if (comp < 6) {
+            for (int i = j; i < N; ++i) {
+                const double* Ci = CP + i * 9;
+                const double* v = vec + 12 * i;
+                acc += dt2 * ((Ci[comp] - Cj[comp]) * (SQ[0] * v[0]) + (Ci[3 + comp] - Cj[3 + comp]) * (SQ[1] * v[1]) +
+                              (Ci[6 + comp] - Cj[6 + comp]) * (SQ[2] * v[2])) + dt * (SQ[6 + comp] * v[6 + comp]);
+            }
+            GV[9 * j + comp] = acc;
+        }
+        constexpr int HL = (3 * N) % 64;
+        for (int e = lane - HL; e < 6 * N; e += 64) {
+            if (e < 0) continue;
+            const int j = e / 6, comp = 3 + (e - 6 * j);
+            double acc = 0.0;
+            if (comp < 6) {
                 for (int i = j; i < N; ++i) acc += (double)(i - j) * vec[12 * i + comp];
             } else {
                 for (int i = j; i < N; ++i) acc += vec[12 * i + 3 + comp];
             }
-            GV[tt] = acc;
+            GV[9 * j + comp] = acc;
         }
     };
     auto gt_eval = [&](int c) -> double {

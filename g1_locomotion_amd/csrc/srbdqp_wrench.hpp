@@ -516,30 +516,35 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         T2[idx] = s2;
     }
     __syncthreads();
+    // the 3 torque entries of a step are an O(N) loop of 7 LDS reads, the 6 force entries one of 1 read: the two kinds sit on
+    // different waves where the workgroup has more than one (entry by entry over all threads every wave ran both loops)
+    constexpr int GT_HL = (64 * ((3 * N + 63) / 64) + 6 * N <= BT) ? 64 * ((3 * N + 63) / 64) : 3 * N;
+    static_assert(GT_HL + 6 * N <= BT, "one pass over the G'v tables");
     auto gt_tables = [&](const double* vec) {
-        for (int idx = t; idx < 9 * N; idx += BT) {
-            const int j = idx / 9, comp = idx - 9 * j;
+        if (t < 3 * N) {
+            const int j = t / 3, comp = t - 3 * j;
             const double* Cj = CP + j * 9;
             double acc = 0.0;
-            if (comp < 3) {
-                const double c0 = Cj[comp], c1 = Cj[3 + comp], c2 = Cj[6 + comp];
-                const double q0 = SQ[0] * dt2, q1 = SQ[1] * dt2, q2 = SQ[2] * dt2, qw = SQ[6 + comp] * dt;
+            const double c0 = Cj[comp], c1 = Cj[3 + comp], c2 = Cj[6 + comp];
+            const double q0 = SQ[0] * dt2, q1 = SQ[1] * dt2, q2 = SQ[2] * dt2, qw = SQ[6 + comp] * dt;
 #pragma unroll 4
-                for (int i = 0; i < N; ++i) {
-                    const double* Ci = CP + i * 9;
-                    const double* v = vec + 12 * i;
-                    const double on = (i >= j) ? 1.0 : 0.0;
-                    acc = fma(on, (Ci[comp] - c0) * (q0 * v[0]) + (Ci[3 + comp] - c1) * (q1 * v[1]) + (Ci[6 + comp] - c2) * (q2 * v[2]) + qw * v[6 + comp], acc);
-                }
-            } else {
-                const int kk = (comp < 6) ? comp : 3 + comp;
-#pragma unroll 4
-                for (int i = 0; i < N; ++i) {
-                    const double wgt = (i >= j) ? ((comp < 6) ? (double)(i - j) : 1.0) : 0.0;
-                    acc = fma(wgt, vec[12 * i + kk], acc);
-                }
+            for (int i = 0; i < N; ++i) {
+                const double* Ci = CP + i * 9;
+                const double* v = vec + 12 * i;
+                const double on = (i >= j) ? 1.0 : 0.0;
+                acc = fma(on, (Ci[comp] - c0) * (q0 * v[0]) + (Ci[3 + comp] - c1) * (q1 * v[1]) + (Ci[6 + comp] - c2) * (q2 * v[2]) + qw * v[6 + comp], acc);
             }
-            GV[idx] = acc;
+            GV[9 * j + comp] = acc;
+        } else if (t >= GT_HL && t < GT_HL + 6 * N) {
+            const int e = t - GT_HL, j = e / 6, comp = 3 + (e - 6 * j);
+            const int kk = (comp < 6) ? comp : 3 + comp;
+            double acc = 0.0;
+#pragma unroll 4
+            for (int i = 0; i < N; ++i) {
+                const double wgt = (i >= j) ? ((comp < 6) ? (double)(i - j) : 1.0) : 0.0;
+                acc = fma(wgt, vec[12 * i + kk], acc);
+            }
+            GV[9 * j + comp] = acc;
         }
     };
     // (G'v)[u] for this lane's force variable, from the tables
