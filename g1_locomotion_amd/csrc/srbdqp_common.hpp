@@ -79,6 +79,14 @@ __device__ __forceinline__ double restart_rho_of(double rho0, const float* r) {
 #define SRBDQP_RESTART_SKIP(a, b) ((a).resid_in && (a).status[(b)] != 2)
 #define SRBDQP_RHO_OF(a, b) ((a).resid_in ? restart_rho_of((a).rho, (a).resid_in + (size_t)(b) * 4) : ((a).rho_qp ? (a).rho_qp[(b)] : (a).rho))
 
+// a wave-uniform value, moved to scalar registers (the float constants of the iteration are converted from doubles by the
+// vector ALU and would otherwise each hold a vector register for the whole loop)
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uni(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // M(j, m), j <= m, of the closed-form assembly (derivation: srbdqp_compact.hpp, phase A) at MT[9 (m (m + 1) / 2 + j)]: one step
 // pair = one thread = its 9 entries (the index inversion, the 18 prefix-sum values and the 9 T1 entries are read once per pair;
 // entry by entry over all threads it was 4 x the instructions: 9.8 k -> 3.6 k cycles at N = 20 with three QPs per CU)

@@ -186,20 +186,27 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         const int i = k / 12, kk = k - 12 * i;
         sm[L1::o_eh + k] = SQ[kk] * (free_response<N, L1>(a, sm, i, kk) - sm[L1::o_xref + i * 13 + kk]);
     }
-    for (int tt = lane; tt < 9 * N; tt += 64) {
-        const int mm = tt / 9, pq = tt - 9 * mm, p = pq / 3, q = pq - 3 * p;
+    // T2(m) is symmetric: one lane per (m, p <= q) -- 6 N entries, one round of the wave at N = 10 instead of two -- which also forms
+    // both T1 entries of its pair
+    for (int tt = lane; tt < 6 * N; tt += 64) {
+        const int mm = tt / 6, u = tt - 6 * mm;
+        const int p = (u < 3) ? 0 : ((u < 5) ? 1 : 2), q = (u < 3) ? u : ((u < 5) ? u - 2 : 2);   // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+        const int pq = 3 * p + q, qp = 3 * q + p;
         const double* Cm = CP + mm * 9;
         const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2];
-        double s1 = 0.0, s2 = 0.0;
+        double s1 = 0.0, s1t = 0.0, s2 = 0.0;
         for (int i = mm; i < N; ++i) {
             const double* Ci = CP + i * 9;
             s1 += Ci[pq] - Cm[pq];
+            s1t += Ci[qp] - Cm[qp];
             const double d0p = Ci[p] - Cm[p], d1p = Ci[3 + p] - Cm[3 + p], d2p = Ci[6 + p] - Cm[6 + p];
             const double d0q = Ci[q] - Cm[q], d1q = Ci[3 + q] - Cm[3 + q], d2q = Ci[6 + q] - Cm[6 + q];
             s2 += (w0 * d0p) * d0q + (w1 * d1p) * d1q + (w2 * d2p) * d2q;
         }
-        T1[tt] = s1;
-        T2[tt] = s2;
+        T1[9 * mm + pq] = s1;
+        T1[9 * mm + qp] = s1t;
+        T2[9 * mm + pq] = s2;
+        T2[9 * mm + qp] = s2;
     }
     __syncthreads();
     auto gt_tables = [&](const double* vec) {
@@ -326,6 +333,11 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
         double* tile = sm + L1::o_scr;
         const int i1 = lane >> 3, i2 = lane & 7;
+        // the per-axis factors of the force term and the diagonal shifts, once, in scalar registers (inside the tile loop they were
+        // re-read from LDS and re-multiplied for every tile: the stores into the scratch tile keep the compiler from hoisting them)
+        const double fa0 = uni(SQ[3] * SQ[3] * dt4m2), fa1 = uni(SQ[4] * SQ[4] * dt4m2), fa2 = uni(SQ[5] * SQ[5] * dt4m2);
+        const double fb0 = uni(SQ[9] * SQ[9] * dt2m2), fb1 = uni(SQ[10] * SQ[10] * dt2m2), fb2 = uni(SQ[11] * SQ[11] * dt2m2);
+        const double dgxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dgz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b);
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
@@ -348,13 +360,13 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
 #pragma unroll
                     for (int x = 0; x < 3; ++x) {                      // axis of the earlier contact
                         const double j0 = Jl[x], j1 = Jl[12 + x], j2 = Jl[24 + x];
-                        const double same = SQ[3 + x] * SQ[3 + x] * dt4m2 * sp + SQ[9 + x] * SQ[9 + x] * dt2m2 * ls;
+                        const double same = ((x == 0) ? fa0 : (x == 1) ? fa1 : fa2) * sp + ((x == 0) ? fb0 : (x == 1) ? fb1 : fb2) * ls;
 #pragma unroll
                         for (int y = 0; y < 3; ++y) {                  // axis of the later contact
                             double v = j0 * Bm[0][y] + j1 * Bm[1][y] + j2 * Bm[2][y];
                             if (x == y) v += same;
                             v *= s2;
-                            if (e1 == e2 && x == y) v += a.rs2 + a.sigma + ((x < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b);
+                            if (e1 == e2 && x == y) v += (x < 2) ? dgxy : dgz;
                             const int a1 = fwd ? x : y, a2 = fwd ? y : x;   // entry (3 e1 + a1, 3 e2 + a2)
                             const int r = 3 * e1 + a1 - 16 * ta, c = 3 * e2 + a2 - 16 * tb;
                             if (r >= 0 && r < 16 && c >= 0 && c < 16) tile[r * 16 + c] = v;

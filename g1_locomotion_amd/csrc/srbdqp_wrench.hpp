@@ -143,13 +143,6 @@ __device__ __forceinline__ double rmax(double a, double b) { return fmax(a, b); 
 __device__ __forceinline__ float rabs(float a) { return fabsf(a); }
 __device__ __forceinline__ double rabs(double a) { return fabs(a); }
 
-// a wave-uniform value, moved to scalar registers (the float constants of the iteration are converted from doubles by the
-// vector ALU and would otherwise each hold a vector register for the whole loop)
-__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ double uni(double v) {
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4d mma16(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ v4f mma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
