@@ -52,7 +52,7 @@ struct Setup1Smem {
     static constexpr int o_gx = o_foot;
     static constexpr int o_scr = o_xref;
     static constexpr int endIn = o_pcom + up2(N * 3);
-    static constexpr int endIn2 = (endIn > o_scr + 256) ? endIn : o_scr + 256;
+    static constexpr int endIn2 = (endIn > o_scr + 258) ? endIn : o_scr + 258;   // the tile + the spare slot of the K assembly
     static constexpr int o_end = (endIn2 > o_cp + S::NT * 256) ? endIn2 : o_cp + S::NT * 256;   // K^-1 block-column staging (wave kernel)
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr bool supported = SplitWs<N, MAXS>::supported && S::NT <= 4;
@@ -369,7 +369,9 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
                             if (e1 == e2 && x == y) v += (x < 2) ? dgxy : dgz;
                             const int a1 = fwd ? x : y, a2 = fwd ? y : x;   // entry (3 e1 + a1, 3 e2 + a2)
                             const int r = 3 * e1 + a1 - 16 * ta, c = 3 * e2 + a2 - 16 * tb;
-                            if (r >= 0 && r < 16 && c >= 0 && c < 16) tile[r * 16 + c] = v;
+                            // entries outside the tile go to a spare slot behind it: an address select instead of nine
+                            // exec-mask regions per tile (cmp + saveexec + branch + restore each)
+                            tile[((unsigned)r < 16u && (unsigned)c < 16u) ? r * 16 + c : 256] = v;
                         }
                     }
                 }
