@@ -338,15 +338,23 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         const double fa0 = uni(SQ[3] * SQ[3] * dt4m2), fa1 = uni(SQ[4] * SQ[4] * dt4m2), fa2 = uni(SQ[5] * SQ[5] * dt4m2);
         const double fb0 = uni(SQ[9] * SQ[9] * dt2m2), fb1 = uni(SQ[10] * SQ[10] * dt2m2), fb2 = uni(SQ[11] * SQ[11] * dt2m2);
         const double dgxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dgz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b);
+        // the stance-contact ids of the lane's row / column contact per tile row / column, read once (inside the loop the stores into
+        // the scratch tile made every tile re-read them)
+        int gr[NT], gc[NT];
+#pragma unroll
+        for (int tq = 0; tq < NT; ++tq) {
+            const int er = (16 * tq) / 3 + i1, ec = (16 * tq) / 3 + i2;
+            gr[tq] = act[er < na ? er : 0];
+            gc[tq] = act[ec < na ? ec : 0];
+        }
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
             for (int tb = ta; tb < NT; ++tb) {
                 const int e1 = (16 * ta) / 3 + i1, e2 = (16 * tb) / 3 + i2;
                 if (e1 < na && e2 < na && 3 * e1 <= 16 * ta + 15 && 3 * e2 <= 16 * tb + 15) {
-                    const bool fwd = e1 <= e2;
-                    const int elo = fwd ? e1 : e2, ehi = fwd ? e2 : e1;
-                    const int glo = act[elo], ghi = act[ehi], jlo = glo >> 2, mhi = ghi >> 2;
+                    const bool fwd = (ta < tb) || e1 <= e2;         // (an off-diagonal tile has e1 <= e2 throughout: folded at compile time)
+                    const int glo = fwd ? gr[ta] : gc[tb], ghi = fwd ? gc[tb] : gr[ta], jlo = glo >> 2, mhi = ghi >> 2;
                     const double* Jl = sm + S::o_J + jlo * 36 + 3 * (glo & 3);
                     const double* Jh = sm + S::o_J + mhi * 36 + 3 * (ghi & 3);
                     const double* M = MT + 9 * (mhi * (mhi + 1) / 2 + jlo);
