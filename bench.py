@@ -2,14 +2,30 @@
 """bench.py -- QP solves/sec of the SRBD convex-MPC hot path on MI355X (BASELINE.json's metric).
 
 A "step" = one pass of the hot path (linearise -> condense -> H,g,cone rows -> factor -> ADMM -> rollout) over one
-batch of synthetic QPs whose inputs are already resident in HBM.  Consecutive steps rotate over 4 DISTINCT device batches
-(different seeds), as the control steps of a fleet would differ; the longest-first dispatch hint of a step is the
-iteration counts the SAME batch produced the last time it was solved.
+batch of synthetic QPs whose inputs are already resident in HBM.  Consecutive steps rotate over DISTINCT device batches
+(different seeds), as the control steps of a fleet would differ.
 
-  --config 1 (default; BASELINE.json configs[1], the config the metric is quoted on):
+  --config 1 (default at --gpus 1; BASELINE.json configs[1], the config the metric is quoted on):
         B = 4096 QPs per GPU, N = 10, 2-contact alternating single support, fp64
   --config 2 (configs[2]): B = 65536 per GPU, N = 20, 4-contact double support, fp32 buffers and iterations
         (fp64 assembly on chip, T factored in fp32 MFMA tiles; srbdqp_solve_batch_device_f32)
+  --config 3 (default at --gpus N > 1; configs[3]): B = 65536 per GPU (524,288 over 8 GPUs), N = 10, 2-contact, fp64,
+        u_opt0 all-gathered over RCCL every step
+  --config 4 (configs[4]): ragged fleet, 16,384 QPs per GPU with N in {8, 12, 16, 24} drawn per QP and per-QP mixed-gait
+        contact schedules, through srbdqp_solve_ragged_device_f64 (bucketed launch)
+
+The one JSON line of the default run (`python bench.py`) carries, beside the configs[1] headline:
+  value             2 HIP streams + the longest-first dispatch hint taken from the SAME batch's previous solve (what a
+                    receding-horizon fleet has at hand: its own previous control step)
+  value_plain       1 stream, no hint: strictly serial steps in natural QP order
+  value_stale_hint  2 streams, hint taken from a DIFFERENT batch (uncorrelated iteration counts: a wrong hint)
+  roofline          frac = flops the kernel really ISSUES (rocprofv3 PMC, profiles/*_pmc_summary.json of the same kernel)
+                    over the live kernel time / the dense peak of the dtype; frac_algorithmic = SURVEY 8(d)'s W(N, K) of the
+                    dense 12N-variable path over the same time (a throughput yardstick: the kernels execute far fewer flops)
+  latency_batch1    single-QP calls, incl. the reference's own call pattern (full double support, run_simulation.py:100-106)
+  also              short legs of configs[2] and configs[4] with their own roofline
+  cpu_baseline      oracle/srbd_oracle.c (a plain-C port of the same algorithm; the reference's implementation is an
+                    absent submodule) on this node's host cores, bounded sample of the same workload
 
 With N > 1 ranks each rank owns its own batch (weak scaling, no data-path collective) and the first-step contact forces
 u_opt0 are all-gathered over RCCL/xGMI every step, as north_star specifies; the same run also times the steps without
@@ -20,15 +36,9 @@ the collective (`value_without_allgather`; --no-allgather makes that the headlin
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.
-`roofline`: `frac` = ALGORITHMIC flops of SURVEY.md section 8(d), W(N, K) of the dense 12N-variable path with K = the
-measured mean ADMM iteration count, over the live kernel time, against the dense peak of the iteration dtype -- a
-throughput yardstick (the kernels execute far fewer flops: presolve, closed-form assembly).  `frac_executed` = the flops
-the kernel really issues (rocprofv3 PMC: (FMA x 2 + ADD + MUL) x 64 lanes + MFMA x 2048, profiles/*_pmc_summary.json of the
-same kernel and batch) over the same live time: the hardware fraction.  `bound` is what those counters say.
-`cpu_baseline`: oracle/srbd_oracle.c (a plain-C port of the same algorithm; the reference's own implementation is an
-absent submodule) timed on this node's host cores on a bounded sample of the same workload.
 """
 import argparse
+import glob
 import json
 import os
 import socket
@@ -46,12 +56,17 @@ BATCH_PER_GPU = 4096
 PEAK_FP64_TFLOPS = 78.6          # MI355X dense fp64 (vector == MFMA rate), SURVEY.md section 8(d)
 PEAK_FP32_TFLOPS = 157.3         # MI355X dense fp32 vector (= fp32 MFMA rate), MI355X_MICROARCH.md
 NBATCH = 4                       # distinct device batches the timed steps rotate over
+RAGGED_HORIZONS = (8, 12, 16, 24)
 
 CONFIGS = {
-    1: dict(horizon=10, batch=4096, schedule="single", f32=False, maxs=2,
+    1: dict(horizon=10, batch=4096, schedule="single", f32=False, maxs=2, steps=500,
             workload="configs[1]: batch={B}/GPU random SRBD states, N=10, 2-contact alternating single support friction cone, fp64"),
-    2: dict(horizon=20, batch=65536, schedule="double", f32=True, maxs=4,
+    2: dict(horizon=20, batch=65536, schedule="double", f32=True, maxs=4, steps=40,
             workload="configs[2]: batch={B}/GPU random SRBD states, N=20, 4-contact double support, fp32 buffers + iterations (fp64 assembly; factorisation in fp32 MFMA tiles + one fp64 refinement step)"),
+    3: dict(horizon=10, batch=65536, schedule="single", f32=False, maxs=2, steps=100,
+            workload="configs[3]: batch={B}/GPU (524,288 over 8 GPUs) random SRBD states sharded over the ranks, N=10, 2-contact alternating single support, fp64"),
+    4: dict(horizon=0, batch=16384, schedule="mixed", f32=False, maxs=4, steps=10,
+            workload="configs[4]: ragged fleet of {B} QPs/GPU, horizon N in {{8,12,16,24}} drawn uniformly per QP, per-QP mixed-gait contact schedules, packed step-major arrays, bucketed launch (srbdqp_solve_ragged_device_f64), fp64"),
 }
 
 
@@ -71,9 +86,10 @@ def algorithmic_bytes(N: int, esz: int = 8) -> int:
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 500 for config 1, 40 for config 2)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 500 / 40 / 100 / 10 for config 1 / 2 / 3 / 4)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=0,
+                    help="default: 1 on one GPU, 3 (65,536 QPs per GPU, N = 10) on several")
     ap.add_argument("--batch", type=int, default=0, help="QPs per GPU per step (default: the config's)")
     ap.add_argument("--kernel", choices=["auto", "compact", "split", "wave", "wrench"], default="auto",
                     help="auto = the fastest parity-green kernel for the config")
@@ -86,8 +102,11 @@ def parse_args(argv=None):
     ap.add_argument("--same-batch", action="store_true", help="every step solves the same batch (round-1 behaviour; A/B)")
     ap.add_argument("--max-iter", type=int, default=0, help="override srbdqp_config.max_iter (0 = library default)")
     ap.add_argument("--rho-restart", type=int, default=0, help="override srbdqp_config.rho_restart_iter (0 = library default)")
+    ap.add_argument("--rho", type=float, default=0.0, help="override srbdqp_config.rho (0 = library default)")
+    ap.add_argument("--rho-fz-scale", type=float, default=0.0, help="override srbdqp_config.rho_fz_scale (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the value_plain / value_stale_hint variants and the configs[2] / configs[4] legs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (tests: gloo)")
     ap.add_argument("--stub-solve", action="store_true", help="tests of the launcher path only: no GPU, the solve is a stub")
     return ap.parse_args(argv)
@@ -116,15 +135,209 @@ def self_launch(args, argv):
     return rc
 
 
+def _auto_rho(N):
+    return 0.7
+
+
+def _auto_rho_fz(N):
+    return 4.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one configuration on this rank's GPU: device batches, outputs, engine, and step(i, mode)
+# ---------------------------------------------------------------------------------------------------------------------
+class Leg:
+    """Homogeneous batches (configs[1], [2], [3]).  step(i, streams, hint): hint in {"own", "none", "stale"}."""
+
+    def __init__(self, cid, B, args, rank, local_rank, dev, torch, nb, stub=False, max_streams=2):
+        from g1_locomotion_amd import synth
+        cfg = CONFIGS[cid]
+        self.cid, self.cfg, self.B, self.N, self.f32, self.nb, self.stub = cid, cfg, B, cfg["horizon"], cfg["f32"], nb, stub
+        self.torch, self.dev = torch, dev
+        N = self.N
+        self.host_batches = [synth.synthetic_batch(B, N, seed=1000 * cid + 97 * j + rank, schedule=cfg["schedule"]) for j in range(nb)]
+        self.tdt = tdt = torch.float32 if self.f32 else torch.float64
+        self.d_in = [[torch.from_numpy(v).to(dev).to(tdt) if v.dtype == np.float64 else torch.from_numpy(v).to(dev) for v in hb]
+                     for hb in self.host_batches]
+        self.NO = NO = max(nb, max_streams)      # output sets: steps in flight at the same time must not share outputs
+        self.d_u = [torch.zeros((B, N, 12), dtype=tdt, device=dev) for _ in range(NO)]
+        self.d_x = [torch.zeros((B, N + 1, 13), dtype=tdt, device=dev) for _ in range(NO)]
+        self.d_st = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NO)]
+        self.d_it = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NO)]
+        self.eng, self.kname = None, "stub"
+        self.streams = [None] * max_streams
+        if not stub:
+            from g1_locomotion_amd import BatchMPC, _lib
+            kid = {"auto": _lib.KERNEL_AUTO, "compact": _lib.KERNEL_COMPACT, "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE,
+                   "wrench": _lib.KERNEL_WRENCH}[args.kernel]
+            kw = {}
+            if args.max_iter > 0: kw["max_iter"] = args.max_iter
+            if args.rho_restart != 0: kw["rho_restart_iter"] = args.rho_restart
+            if args.rho > 0: kw["rho"] = args.rho
+            if args.rho_fz_scale > 0: kw["rho_fz_scale"] = args.rho_fz_scale
+            self.eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=cfg["maxs"], **kw)
+            # non-default streams: the C-ABI treats a NULL stream as "the handle's own", and the HIP events that time a kernel
+            # must sit on the stream the kernel is launched on
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(max_streams)]
+
+    def step(self, i, S=2, hint="own"):
+        o, d = i % self.NO, self.d_in[i % self.nb]
+        B, N = self.B, self.N
+        if self.stub:
+            self.d_u[o].copy_(d[2].reshape(B, N, 12))          # any deterministic function of the inputs
+            self.d_st[o].fill_(1); self.d_it[o].fill_(5)
+            return
+        st = self.streams[i % S]
+        if hint == "own":      # receding horizon: the iteration counts this batch produced the last time it was solved
+            self.eng.set_schedule_hint(self.d_it[o].data_ptr(), B)
+        elif hint == "stale":  # the counts ANOTHER batch produced: an uncorrelated, i.e. wrong, hint
+            self.eng.set_schedule_hint(self.d_it[(o + 1) % self.NO].data_ptr(), B)
+        else:
+            self.eng.set_schedule_hint(0, 0)
+        self.eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), self.d_u[o].data_ptr(),
+                              x_out=self.d_x[o].data_ptr(), status=self.d_st[o].data_ptr(), iters=self.d_it[o].data_ptr(),
+                              stream=st.cuda_stream, f32=self.f32)
+
+    def stats(self, solved_code):
+        iters = self.torch.stack([t.cpu() for t in self.d_it[:self.nb]]).numpy()
+        status = self.torch.stack([t.cpu() for t in self.d_st[:self.nb]]).numpy()
+        return float(iters.mean()), float((status == solved_code).mean()), iters
+
+    def flops_bytes(self, mean_iters):
+        esz = 4 if self.f32 else 8
+        return algorithmic_flops(self.N, mean_iters) * self.B, algorithmic_bytes(self.N, esz) * self.B
+
+    def close(self):
+        if self.eng is not None:
+            self.eng.close()
+
+
+class RaggedLeg:
+    """configs[4]: one ragged fleet per distinct batch, through srbdqp_solve_ragged_device_f64 (one call = one step)."""
+
+    def __init__(self, B, args, rank, local_rank, dev, torch, nb):
+        from g1_locomotion_amd import synth, RaggedMPC
+        self.cid, self.cfg, self.B, self.N, self.f32, self.nb, self.stub = 4, CONFIGS[4], B, 0, False, nb, False
+        self.torch, self.dev = torch, dev
+        self.sets = []
+        for j in range(nb):
+            rng = np.random.default_rng(4000 + 97 * j + rank)
+            Nq = rng.choice(RAGGED_HORIZONS, size=B).astype(np.int32)
+            x0 = np.empty((B, 13)); rows = int(Nq.sum())
+            xr = np.empty((rows, 13)); ft = np.empty((rows, 12)); ct = np.empty((rows, 4), np.uint8)
+            off = np.concatenate([[0], np.cumsum(Nq)])
+            for N in RAGGED_HORIZONS:
+                idx = np.where(Nq == N)[0]
+                a, b_, c, d = synth.synthetic_batch(len(idx), N, seed=4000 + 97 * j + N + rank, schedule="mixed")
+                x0[idx] = a
+                dst = (off[idx][:, None] + np.arange(N)[None, :]).reshape(-1)
+                xr[dst] = b_.reshape(-1, 13); ft[dst] = c.reshape(-1, 12); ct[dst] = d.reshape(-1, 4)
+            dd = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x0, xr, ft, ct)]
+            self.sets.append(dict(Nq=Nq, rows=rows, d=dd,
+                                  u=torch.empty((rows, 12), dtype=torch.float64, device=dev),
+                                  x=torch.empty((rows + B, 13), dtype=torch.float64, device=dev),
+                                  st=torch.zeros(B, dtype=torch.int32, device=dev), it=torch.zeros(B, dtype=torch.int32, device=dev)))
+        self.NO = nb
+        self.eng = RaggedMPC(horizons=RAGGED_HORIZONS, device=local_rank)
+        self.streams = [torch.cuda.Stream(device=dev)]
+        self.kname = "ragged_wrench_f64_n8_n12_n16_n24"
+        self.d_u = [s["u"] for s in self.sets]
+
+    def step(self, i, S=1, hint="none"):
+        s = self.sets[i % self.nb]
+        d = s["d"]
+        self.eng.solve_device(self.B, s["Nq"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), s["u"].data_ptr(),
+                              x_out=s["x"].data_ptr(), status=s["st"].data_ptr(), iters=s["it"].data_ptr(), stream=self.streams[0].cuda_stream)
+
+    def stats(self, solved_code):
+        it = np.concatenate([s["it"].cpu().numpy() for s in self.sets]); st = np.concatenate([s["st"].cpu().numpy() for s in self.sets])
+        self._it, self._Nq = it, np.concatenate([s["Nq"] for s in self.sets])
+        return float(it.mean()), float((st == solved_code).mean()), it
+
+    def flops_bytes(self, mean_iters):
+        fl = by = 0.0
+        for N in RAGGED_HORIZONS:
+            m = self._Nq == N
+            if m.any():
+                fl += algorithmic_flops(N, float(self._it[m].mean())) * m.sum() / self.nb
+                by += algorithmic_bytes(N, 8) * m.sum() / self.nb
+        return fl, by
+
+    def close(self):
+        self.eng.close()
+
+
+def isolated_kernel_ms(leg, torch, n_iso, k0):
+    """the step's kernels in isolation (HIP events on the launch stream, one solve at a time)"""
+    iso = []
+    for i in range(n_iso):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k = k0 + leg.NO * len(leg.streams) * (i + 1)                  # a multiple of S and NO: stream 0, output set 0
+        e0.record(leg.streams[0]); leg.step(k, S=1, hint="own" if leg.cid != 4 else "none"); e1.record(leg.streams[0])
+        torch.cuda.synchronize(leg.dev)
+        iso.append(e0.elapsed_time(e1))
+    return float(np.mean(iso)), len(iso)
+
+
+def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step, S, N):
+    """`frac` = the flops the kernel really issues (PMC summary of the same kernel under profiles/) over the live kernel time
+    and the dense peak; `frac_algorithmic` = SURVEY 8(d)'s W(N, K) over the same time."""
+    alg_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
+    hbm_gbs = abytes / (kernel_ms * 1e-3) / 1e9
+    r = {"bound": "unknown (no PMC summary for this kernel under profiles/)",
+         "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,
+         "frac_note": "frac / achieved = flops ISSUED by the step's kernels per launch (rocprofv3 PMC: SQ_INSTS_VALU_FLOPS_FP32/FP64 x 64 lanes + MFMA "
+                      "x 2048, EXEC-masked lanes and padded tiles included; profiles/*_pmc_summary.json of the same kernel) over the live kernel "
+                      "time below; frac_algorithmic = SURVEY 8(d)'s W(N, K) of the dense 12N-variable path over the same time -- a throughput "
+                      "yardstick that the presolved, closed-form kernels beat by construction, not a utilisation",
+         "achieved_algorithmic": alg_tf, "frac_algorithmic": alg_tf / peak,
+         "frac_algorithmic_at_step_rate": flops_launch / (ms_per_step * 1e-3) / 1e12 / peak,
+         "traffic": None,
+         "traffic_unit": "HBM bytes per solve = per launch of this step's kernels (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+         "algorithmic_bytes_per_launch": abytes, "kernel": kname, "kernel_ms": kernel_ms,
+         "kernel_ms_note": "mean of %d isolated solves, one at a time, after the warm-up steps and before the timed region (so the GPU is at its "
+                           "sustained clocks when the timed steps start); HIP events on the launch stream; with the rho restart on, a solve = the "
+                           "first pass + the pass in which the capped QPs continue; an _f32 solve of >= 512 QPs = the fp32-tile and the fp64-tile "
+                           "launch; a ragged solve = all its bucket launches.  The timed region overlaps consecutive steps on %d stream(s)" % (n_iso, S),
+         "algorithmic_flops_per_launch": flops_launch,
+         "hbm_algorithmic_GBps": hbm_gbs, "hbm_frac_of_8TBps": hbm_gbs / 8000.0}
+    try:
+        best, scaled = None, False
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+            d = json.load(open(f))
+            if d.get("bench_kernel_name") != kname:
+                continue
+            if d.get("batch_per_launch") == B or best is None or (best.get("batch_per_launch") != B and d.get("round", 0) >= best.get("round", 0)):
+                if best is None or best.get("batch_per_launch") != B or d.get("batch_per_launch") == B:
+                    best = d
+                    best["_file"] = f
+        if best is not None:
+            k = B / float(best["batch_per_launch"])               # executed work per QP does not depend on the batch size
+            scaled = abs(k - 1.0) > 1e-12
+            r["traffic"] = k * best["hbm"].get("traffic_bytes_per_solve", best["hbm"]["traffic_bytes_per_launch"])
+            ex = best.get("executed")
+            if ex:
+                fl = k * ex.get("flops_per_solve", ex["flops_per_launch"])
+                r["executed_flops_per_launch"] = fl
+                r["achieved"] = fl / (kernel_ms * 1e-3) / 1e12
+                r["frac"] = r["achieved"] / peak
+                r["bound"] = ex["bound"]
+                r["utilisation"] = ex["utilisation"]
+            r["pmc_summary"] = os.path.relpath(best["_file"], ROOT) + (" (counted at %d QPs per launch, scaled per QP)" % best["batch_per_launch"] if scaled else "")
+    except Exception as e:          # the summary is evidence, not a dependency
+        r["traffic_error"] = repr(e)
+    return r
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, argv))
-    cfg = CONFIGS[args.config]
-    N, f32 = cfg["horizon"], cfg["f32"]
+    cid = args.config or (1 if args.gpus == 1 else 3)
+    cfg = CONFIGS[cid]
     B = args.batch or cfg["batch"]
-    steps = args.steps or (500 if args.config == 1 else 40)
+    steps = args.steps or cfg["steps"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -147,69 +360,48 @@ def main(argv=None):
         else:
             dist_mod.init_process_group(backend=args.backend)
         dist = dist_mod
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
-    from g1_locomotion_amd import synth
     nb = 1 if args.same_batch else NBATCH
-    host_batches = [synth.synthetic_batch(B, N, seed=1000 * args.config + 97 * j + rank, schedule=cfg["schedule"]) for j in range(nb)]
-    tdt = torch.float32 if f32 else torch.float64
-    d_in = [[torch.from_numpy(v).to(dev).to(tdt) if v.dtype == np.float64 else torch.from_numpy(v).to(dev) for v in hb] for hb in host_batches]
     S = max(1, args.streams)
-    NO = max(nb, S)                 # output sets: steps in flight at the same time must not share outputs
-    d_u = [torch.zeros((B, N, 12), dtype=tdt, device=dev) for _ in range(NO)]
-    d_x = [torch.zeros((B, N + 1, 13), dtype=tdt, device=dev) for _ in range(NO)]
-    d_st = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NO)]
-    d_it = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NO)]
-    d_u0_all = [torch.empty((world * B, 12), dtype=tdt, device=dev) for _ in range(NO)] if world > 1 else None
-
-    if stub:
-        eng, streams, kname = None, [None] * S, "stub"
-        SOLVED = 1
-
-        def step(i):
-            o = i % NO
-            d_u[o].copy_(d_in[i % nb][2].reshape(B, N, 12))          # any deterministic function of the inputs
-            d_st[o].fill_(1); d_it[o].fill_(5)
-    else:
-        from g1_locomotion_amd import BatchMPC, _lib
+    SOLVED = 1
+    if not stub:
+        from g1_locomotion_amd import _lib
         SOLVED = _lib.SOLVED
-        kid = {"auto": _lib.KERNEL_AUTO, "compact": _lib.KERNEL_COMPACT, "split": _lib.KERNEL_SPLIT, "wave": _lib.KERNEL_WAVE,
-               "wrench": _lib.KERNEL_WRENCH}[args.kernel]
-        eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=cfg["maxs"],
-                       **({"max_iter": args.max_iter} if args.max_iter > 0 else {}),
-                       **({"rho_restart_iter": args.rho_restart} if args.rho_restart != 0 else {}))
-        # non-default streams: the C-ABI treats a NULL stream as "the handle's own", and the HIP events that time a kernel
-        # must sit on the stream the kernel is launched on
-        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    if cid == 4:
+        leg = RaggedLeg(B, args, rank, local_rank, dev, torch, nb)
+        S = 1
+    else:
+        leg = Leg(cid, B, args, rank, local_rank, dev, torch, nb, stub=stub, max_streams=S)
+    N, f32 = leg.N, leg.f32
+    NO = leg.NO
+    hint = "none" if (args.no_sched_hint or cid == 4) else "own"
+    d_u0_all = [torch.empty((world * B, 12), dtype=torch.float32 if f32 else torch.float64, device=dev) for _ in range(NO)] if (world > 1 and cid != 4) else None
 
-        def step(i):
-            st, o, d = streams[i % S], i % NO, d_in[i % nb]
-            if not args.no_sched_hint:   # receding horizon: the iteration counts this batch produced the last time it was solved
-                eng.set_schedule_hint(d_it[o].data_ptr() if i >= NO else 0, B)
-            eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_u[o].data_ptr(),
-                             x_out=d_x[o].data_ptr(), status=d_st[o].data_ptr(), iters=d_it[o].data_ptr(),
-                             stream=st.cuda_stream, f32=f32)
+    def u0_of(o):
+        return leg.d_u[o][:, 0, :].contiguous()
 
     def exchange(i):
-        if dist is None:
+        if dist is None or d_u0_all is None:
             return
         o = i % NO
         if stub:
-            dist.all_gather_into_tensor(d_u0_all[o], d_u[o][:, 0, :].contiguous())
+            dist.all_gather_into_tensor(d_u0_all[o], u0_of(o))
         else:   # all-gather of u_opt0 on the step's own stream: overlaps the next step's kernel
-            with torch.cuda.stream(streams[i % S]):
-                dist.all_gather_into_tensor(d_u0_all[o], d_u[o][:, 0, :].contiguous())
+            with torch.cuda.stream(leg.streams[i % S]):
+                dist.all_gather_into_tensor(d_u0_all[o], u0_of(o))
 
     def sync():
         if not stub:
             torch.cuda.synchronize(dev)
 
-    def timed(k0, K, with_exchange):
+    def timed(lg, k0, K, with_exchange, S_, hint_):
         if dist is not None:
             dist.barrier()
         sync()
         t0 = time.perf_counter()
         for k in range(k0, k0 + K):
-            step(k)
+            lg.step(k, S=S_, hint=hint_)
             if with_exchange:
                 exchange(k)
         sync()
@@ -225,163 +417,181 @@ def main(argv=None):
 
     sync()
     for i in range(max(args.warmup, NO)):
-        step(i)
+        leg.step(i, S=S, hint="none" if i < NO else hint)
         exchange(i)
     sync()
     base = max(args.warmup, NO)
     base += (-base) % (S * NO)      # keep the (step -> stream, batch, output set) phase
-    # ---- the dominant kernel in isolation (HIP events on its launch stream, one launch at a time): roofline numbers
-    kernel_ms = None
+    # ---- the dominant kernel in isolation: roofline numbers
+    kernel_ms, n_iso = None, 0
     if not stub:
-        iso = []
-        n_iso = 50 if args.config == 1 else 5       # ~12 ms / ~80 ms of isolated solves: a stable average, and the GPU is at its
-        for i in range(n_iso):                       # sustained clocks when the timed region starts (disclosed in kernel_ms_note)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            k = base + S * NO * (i + 1)                                # a multiple of S and NO: stream 0, output set 0
-            e0.record(streams[0]); step(k); e1.record(streams[0])
-            sync()
-            iso.append(e0.elapsed_time(e1))
-        kernel_ms = float(np.mean(iso))
-        kname = eng.kernel_name()
+        kernel_ms, n_iso = isolated_kernel_ms(leg, torch, {1: 50, 2: 5, 3: 8, 4: 3}[cid], base)
+        if cid != 4:
+            leg.kname = leg.eng.kernel_name()
+    kname = leg.kname
     # ---- timed region: exactly K steps (the headline), and the same K steps with / without the collective
-    use_ag = dist is not None and not args.no_allgather
-    elapsed = timed(base, steps, use_ag)
-    elapsed_other = timed(base, steps, not use_ag) if dist is not None else None
-
-    iters = torch.stack([t.cpu() for t in d_it[:nb]]).numpy()
-    status = torch.stack([t.cpu() for t in d_st[:nb]]).numpy()
-    mean_iters = float(iters.mean())
-    solved_frac = float((status == SOLVED).mean())
+    use_ag = dist is not None and not args.no_allgather and d_u0_all is not None
+    elapsed = timed(leg, base, steps, use_ag, S, hint)
+    elapsed_other = timed(leg, base, steps, not use_ag, S, hint) if (dist is not None and d_u0_all is not None) else None
+    mean_iters, solved_frac, _ = leg.stats(SOLVED)
     if dist is not None and use_ag:            # the collective really moved this rank's forces
         o = (base + steps - 1) % NO
         mine = d_u0_all[o][rank * B:(rank + 1) * B]
-        assert torch.equal(mine, d_u[o][:, 0, :]), "all-gather result does not hold this rank's forces"
+        assert torch.equal(mine, leg.d_u[o][:, 0, :]), "all-gather result does not hold this rank's forces"
+    # ---- the same K steps without the two things that shape the headline (configs[1] at one GPU)
+    extra = {}
+    if world == 1 and not stub and cid in (1, 3) and not args.no_also and hint == "own":
+        el_plain = timed(leg, base, steps, False, 1, "none")
+        for i in range(NO):                    # refresh every output set's counts, then hints taken from ANOTHER batch
+            leg.step(base + i, S=S, hint="none")
+        sync()
+        el_stale = timed(leg, base, steps, False, S, "stale")
+        extra["value_plain"] = B * steps / el_plain
+        extra["value_stale_hint"] = B * steps / el_stale
+        extra["value_variants_note"] = ("value: %d streams + longest-first hint = the same batch's previous iteration counts; value_plain: 1 stream, no hint "
+                                        "(strictly serial steps, natural QP order); value_stale_hint: %d streams, hint = the counts of a DIFFERENT "
+                                        "batch (uncorrelated: a wrong hint only reorders work)" % (S, S))
 
     if rank == 0:
         total_qp = world * B * steps
         value = total_qp / elapsed
         peak = PEAK_FP32_TFLOPS if f32 else PEAK_FP64_TFLOPS
-        esz = 4 if f32 else 8
         out = {
-            "metric": "QP solves/sec, SRBD N=%d 12-state/12-input" % N,
+            "metric": ("QP solves/sec, SRBD N=%d 12-state/12-input" % N) if cid != 4 else "QP solves/sec, SRBD mixed horizon N in {8,12,16,24} 12-state/12-input",
             "value": value, "unit": "QP/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(steps, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
             "config": {"workload": cfg["workload"].format(B=B) + ("; u_opt0 all-gather over RCCL every step" if use_ag else "")
                                    + (f"; steps rotate over {nb} distinct device batches" if nb > 1 else "; every step solves the same batch"),
-                       "horizon": N, "batch_per_gpu": B, "kernel": kname, "streams": S, "longest_first_hint": not args.no_sched_hint,
+                       "horizon": N if cid != 4 else list(RAGGED_HORIZONS), "batch_per_gpu": B, "kernel": kname, "streams": S,
+                       "longest_first_hint": hint == "own", "world_size": world if dist is None else dist.get_world_size(),
                        "distinct_batches": nb, "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
                        "allgather_in_value": bool(use_ag)},
         }
-        if eng is not None:
-            c = eng.cfg
+        out.update(extra)
+        if leg.eng is not None and cid != 4:
+            c = leg.eng.cfg
             out["config"].update({"eps_abs": max(c.eps_abs, 2e-6) if f32 else c.eps_abs, "eps_rel": max(c.eps_rel, 2e-6) if f32 else c.eps_rel,
-                                  "rho": _auto_rho(N) if c.rho == 0 else c.rho, "max_iter": int(c.max_iter),
-                                  "rho_restart_iter": int(c.rho_restart_iter), "set_up_dtype": "f64" if not f32 else "f64 assembly, f32 tiles (f64 tiles for QPs with a step of <= 2 stance contacts)"})
+                                  "rho": _auto_rho(N) if c.rho == 0 else c.rho, "rho_fz_scale": _auto_rho_fz(N) if c.rho_fz_scale == 0 else c.rho_fz_scale,
+                                  "max_iter": int(c.max_iter), "rho_restart_iter": int(c.rho_restart_iter),
+                                  "set_up_dtype": "f64" if not f32 else "f64 assembly, f32 tiles (f64 tiles for QPs with a step of <= 2 stance contacts)"})
         if elapsed_other is not None:
             key = "value_without_allgather" if use_ag else "value_with_allgather"
             out[key] = total_qp / elapsed_other
         if kernel_ms is not None:
-            out["roofline"] = roofline(kname, N, B, mean_iters, kernel_ms, peak, esz, 1e3 * elapsed / max(steps, 1), S)
-        if world == 1 and not args.no_latency and not stub and args.config == 1:
+            fl, by = leg.flops_bytes(mean_iters)
+            out["roofline"] = roofline(kname, fl, by, B, kernel_ms, n_iso, peak, 1e3 * elapsed / max(steps, 1), S, N)
+        if world == 1 and not args.no_latency and not stub and cid == 1:
+            from g1_locomotion_amd import synth
             out["latency_batch1"] = latency_batch1(synth)
-        if world == 1 and not args.no_cpu_baseline and not stub:
-            out["cpu_baseline"] = cpu_baseline(args.config, N, host_batches[0])
+        host_batch0 = leg.host_batches[0] if cid != 4 else None
+        leg.close()
+        leg = None
+        if world == 1 and not stub and cid == 1 and not args.no_also:
+            out["also"] = also_legs(args, rank, local_rank, dev, torch, SOLVED)
+        if world == 1 and not args.no_cpu_baseline and not stub and cid != 4:
+            out["cpu_baseline"] = cpu_baseline(cid, N, host_batch0)
         print(json.dumps(out), flush=True)
-    if eng is not None:
-        eng.close()
+    if leg is not None:
+        leg.close()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def _auto_rho(N):
-    return 1.0 if N <= 10 else (1.5 if N <= 16 else 2.0)
-
-
-def roofline(kname, N, B, mean_iters, kernel_ms, peak, esz, ms_per_step, S):
-    flops_launch = algorithmic_flops(N, mean_iters) * B
-    achieved_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
-    abytes = algorithmic_bytes(N, esz) * B
-    hbm_gbs = abytes / (kernel_ms * 1e-3) / 1e9
-    r = {"bound": "unknown (no PMC summary for this kernel / batch under profiles/)",
-         "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
-         "frac_note": "ALGORITHMIC-equivalent: SURVEY 8(d)'s W(N, K) of the dense 12N-variable path over the live kernel time; "
-                      "a throughput yardstick, not a utilisation -- see frac_executed",
-         "frac_executed": None, "traffic": None,
-         "traffic_unit": "bytes per solve = per launch of this step's kernels (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*_pmc_summary.json)",
-         "algorithmic_bytes_per_launch": abytes, "kernel": kname, "kernel_ms": kernel_ms,
-         "kernel_ms_note": "one solve at a time (50 isolated solves at configs[1], 5 at configs[2], after the W warm-up steps and "
-                           "before the timed region -- so the GPU is also at its sustained clocks when the K timed steps start; "
-                           "HIP events on the launch stream; with the rho restart on, a solve = the first pass + the pass in which "
-                           "the capped QPs continue; an _f32 solve of >= 512 QPs = the fp32-tile and the fp64-tile launch); the "
-                           "timed region overlaps consecutive steps on %d streams" % S,
-         "algorithmic_flops_per_qp": algorithmic_flops(N, mean_iters),
-         "hbm_algorithmic_GBps": hbm_gbs, "hbm_frac_of_8TBps": hbm_gbs / 8000.0,
-         # the same count over the DRIVER-visible step time (the streams overlap steps): a value > 1 here would say that the
-         # counted work is not what the kernel executes -- which is why frac_executed exists
-         "frac_at_step_rate": flops_launch / (ms_per_step * 1e-3) / 1e12 / peak}
-    try:
-        import glob
-        best = None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
-            d = json.load(open(f))
-            if d.get("bench_kernel_name") == kname and d.get("batch_per_launch") == B:
-                best = d
-                best["_file"] = f
-        if best is not None:
-            r["traffic"] = best["hbm"].get("traffic_bytes_per_solve", best["hbm"]["traffic_bytes_per_launch"])
-            ex = best.get("executed")
-            if ex:
-                fl = ex.get("flops_per_solve", ex["flops_per_launch"])
-                r["executed_flops_per_launch"] = fl
-                r["frac_executed"] = fl / (kernel_ms * 1e-3) / 1e12 / peak
-                r["frac_executed_note"] = ex["note"]
-                r["bound"] = ex["bound"]
-                r["utilisation"] = ex["utilisation"]
-            r["pmc_summary"] = os.path.relpath(best["_file"], ROOT)
-    except Exception as e:          # the summary is evidence, not a dependency
-        r["traffic_error"] = repr(e)
-    return r
+def also_legs(args, rank, local_rank, dev, torch, SOLVED):
+    """Short legs of the other single-GPU configurations, each with its own roofline (the headline stays configs[1])."""
+    import copy
+    args = copy.copy(args)          # the side legs always run the library defaults, whatever the headline was asked to A/B
+    args.kernel, args.max_iter, args.rho_restart, args.rho, args.rho_fz_scale = "auto", 0, 0, 0.0, 0.0
+    res = {}
+    for cid, nb, steps, n_iso in ((2, 2, 10, 3), (4, 2, 5, 2)):
+        try:
+            cfg = CONFIGS[cid]
+            B = cfg["batch"]
+            S = 2 if cid == 2 else 1
+            leg = Leg(cid, B, args, rank, local_rank, dev, torch, nb, max_streams=S) if cid != 4 else RaggedLeg(B, args, rank, local_rank, dev, torch, nb)
+            hint = "own" if cid != 4 else "none"
+            for i in range(2 * leg.NO):
+                leg.step(i, S=S, hint="none" if i < leg.NO else hint)
+            torch.cuda.synchronize(dev)
+            base = 2 * leg.NO
+            base += (-base) % (S * leg.NO)
+            kernel_ms, n = isolated_kernel_ms(leg, torch, n_iso, base)
+            if cid != 4:
+                leg.kname = leg.eng.kernel_name()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for k in range(base, base + steps):
+                leg.step(k, S=S, hint=hint)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            mean_iters, solved_frac, _ = leg.stats(SOLVED)
+            fl, by = leg.flops_bytes(mean_iters)
+            peak = PEAK_FP32_TFLOPS if leg.f32 else PEAK_FP64_TFLOPS
+            res["configs[%d]" % cid] = {
+                "workload": cfg["workload"].format(B=B) + f"; {steps} timed steps rotating over {nb} distinct device batches, {S} stream(s)",
+                "value": B * steps / el, "unit": "QP/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "dtype": "f32" if leg.f32 else "f64",
+                "kernel": leg.kname, "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
+                "roofline": roofline(leg.kname, fl, by, B, kernel_ms, n, peak, 1e3 * el / steps, S, leg.N)}
+            leg.close()
+        except Exception as e:      # a failed side leg must not take the headline down with it; it is reported, not hidden
+            res["configs[%d]" % cid] = {"error": repr(e)}
+    return res
 
 
 def latency_batch1(synth, calls=2000):
-    """p50/p99 of single-QP calls through the Python MPC.update() path (ctypes + H2D + kernel + D2H)."""
-    from g1_locomotion_amd import MPC
-    x0, xr, ft, ct = synth.synthetic_batch(64, HORIZON, seed=99, schedule="single")
+    """p50/p99 of single-QP calls: through the Python MPC.update() path (ctypes + staging + kernel) and through the C-ABI
+    alone, for the synthetic single-support gait of configs[1] AND for the reference's own call pattern -- full double
+    support on every step (g1_mujoco_sim/src/run_simulation.py:100-101 feeds [1, 1, 1, 1] per step, :106 calls update())."""
+    from g1_locomotion_amd import MPC, BatchMPC
     out = {}
-    for warm in (False, True):
+    sets = {"single": synth.synthetic_batch(64, HORIZON, seed=99, schedule="single"),
+            "double": synth.synthetic_batch(64, HORIZON, seed=98, schedule="double")}
+
+    def pct(ts):
+        ts = np.array(ts[50:]) * 1e6
+        return {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
+
+    def mpc_update(sched, warm, n):
+        x0, xr, ft, ct = sets[sched]
         mpc = MPC(dt=0.04, horizon=HORIZON, warm_start=warm)
         mpc.init_matrices()
-        ts = []
-        for i in range(calls + 50):
+        ts, its = [], []
+        for i in range(n + 50):
             b = i % 64
             mpc.x_ref_hor[:] = xr[b]
             t = time.perf_counter()
             mpc.update(list(ct[b]), list(ft[b]), xr[b][:, 3:6], x_current=x0[b].reshape(13, 1), one_rollout=True)
-            ts.append(time.perf_counter() - t)
-        ts = np.array(ts[50:]) * 1e6
-        out["warm" if warm else "cold"] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
+            ts.append(time.perf_counter() - t); its.append(mpc.iters)
         mpc.close()
-    # the C-ABI call alone (inputs already in the staging arrays), at the default tolerance and at OSQP's default 1e-3
-    from g1_locomotion_amd import BatchMPC
-    for name, kw in (("c_abi", {}), ("c_abi_eps1e-3", {"eps_abs": 1e-3, "eps_rel": 1e-3})):
+        return dict(pct(ts), mean_iters=float(np.mean(its[50:])))
+
+    def c_abi(sched, n, **kw):
+        x0, xr, ft, ct = sets[sched]
         with BatchMPC(horizon=HORIZON, **kw) as eng:
             st = eng.stage()
-            ts = []
-            for i in range(calls + 50):
+            ts, its = [], []
+            for i in range(n + 50):
                 b = i % 64
                 st["x0"][0] = x0[b]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]
                 t = time.perf_counter()
                 eng.solve_staged(1, want_x=True)
-                ts.append(time.perf_counter() - t)
-            ts = np.array(ts[50:]) * 1e6
-            out[name] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
+                ts.append(time.perf_counter() - t); its.append(int(st["iters"][0]))
+            return dict(pct(ts), mean_iters=float(np.mean(its[50:])), kernel=eng.kernel_name())
+
+    out["cold"] = mpc_update("single", False, calls)
+    out["warm"] = mpc_update("single", True, calls)
+    out["c_abi"] = c_abi("single", calls)
+    out["c_abi_eps1e-3"] = c_abi("single", calls, eps_abs=1e-3, eps_rel=1e-3)
+    out["c_abi_double_support"] = c_abi("double", calls)
+    out["mpc_update_double_support"] = mpc_update("double", False, calls)
     # the two-phase call: the set-up (contact schedule, contact points, reference known beforehand) has run and finished;
     # timed = the second phase only, from "the measured state is in the staging array" to "the forces are there"
+    x0, xr, ft, ct = sets["single"]
     with BatchMPC(horizon=HORIZON) as eng:
         st = eng.stage()
         ts = []
-        for i in range(calls + 50):
+        for i in range(calls // 2 + 50):
             b = i % 64
             st["x0"][0] = x0[(b + 1) % 64]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]   # a wrong prediction
             eng.prepare_staged(1)
@@ -390,13 +600,13 @@ def latency_batch1(synth, calls=2000):
             t = time.perf_counter()
             eng.solve_prepared(1, want_x=True)
             ts.append(time.perf_counter() - t)
-        ts = np.array(ts[50:]) * 1e6
-        out["c_abi_prepared_phase2"] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
-    out["note"] = ("cold / warm: MPC.update() from zero / from the previous call's shifted plan and duals; c_abi: "
-                   "srbdqp_solve_staged_f64(B=1) alone (THE single-QP latency: everything between the inputs and the forces); "
-                   "eps1e-3: OSQP's default tolerance instead of 1e-6; c_abi_prepared_phase2: srbdqp_solve_prepared_f64 alone after a "
-                   "finished srbdqp_prepare_staged_f64 -- a different mode of operation (the factorisation ran before the state "
-                   "arrived), listed beside c_abi, not instead of it")
+        out["c_abi_prepared_phase2"] = pct(ts)
+    out["note"] = ("cold / warm: MPC.update() on the single-support gait of configs[1], from zero / from the previous call's shifted plan and duals; "
+                   "c_abi: srbdqp_solve_staged_f64(B=1) alone on that gait (everything between the inputs and the forces); eps1e-3: OSQP's default "
+                   "tolerance instead of 1e-6; c_abi_double_support / mpc_update_double_support: the same two calls on the REFERENCE'S OWN call "
+                   "pattern, all four contact points active on every step (run_simulation.py:100-101,106); c_abi_prepared_phase2: "
+                   "srbdqp_solve_prepared_f64 alone after a finished srbdqp_prepare_staged_f64 -- a different mode of operation (the "
+                   "factorisation ran before the state arrived), listed beside c_abi, not instead of it")
     return out
 
 
@@ -427,11 +637,11 @@ def cpu_baseline(config, N, batch):
     import srbd_oracle as orc
     import c_oracle
     x0, xr, ft, ct = batch
-    p = orc.params_for(N, rho_restart_iter=0 if config == 1 else 125)    # as the engine runs the config by default
+    p = orc.params_for(N, rho_restart_iter=0 if N <= 10 else (100 if N <= 16 else 125))    # as the engine runs the config by default
     cores = _cpu_share()
-    # sized for ~10-30 s of CPU work: config 1 = the whole 4096-QP batch x 24 (0.15 ms per QP and thread), config 2 = 1024
-    # QPs x 2 (dense 240-variable factor: several ms per QP and thread)
-    Sall, reps, S1 = (x0.shape[0], 24, min(2048, x0.shape[0])) if config == 1 else (min(1024, x0.shape[0]), 2, 64)
+    # sized for ~10-30 s of CPU work: N = 10 -> 4096 QPs x 24 (0.15 ms per QP and thread), N = 20 -> 1024 QPs x 2 (dense
+    # 240-variable factor: several ms per QP and thread)
+    Sall, reps, S1 = (min(4096, x0.shape[0]), 24, min(2048, x0.shape[0])) if N <= 10 else (min(1024, x0.shape[0]), 2, 64)
     a = [v[:Sall] for v in (x0, xr, ft, ct)]
     t = time.perf_counter()
     c_oracle.solve_batch(p, x0[:S1], xr[:S1], ft[:S1], ct[:S1], nthreads=1)
@@ -442,7 +652,7 @@ def cpu_baseline(config, N, batch):
         c_oracle.solve_batch(p, *a, nthreads=cores)
     tall = (time.perf_counter() - t) / reps
     # the NumPy oracle (the "Python path" stand-in of SURVEY 8d) on a handful of QPs, and OSQP itself if this box has it
-    nnp = 16 if config == 1 else 4
+    nnp = 16 if N <= 10 else 4
     t = time.perf_counter()
     for b in range(nnp):
         orc.update(p, x0[b], xr[b], ft[b], ct[b])

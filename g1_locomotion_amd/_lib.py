@@ -23,6 +23,7 @@ FLAG_NO_SPIN = 2
 FLAG_SETUP4 = 4
 FLAG_F64_TILES = 8     # _f32 calls: fp64 tiles for every QP
 FLAG_F32_TILES = 16    # _f32 calls: fp32 tiles for the eligible QPs of small batches too
+FLAG_NO_LAT = 32       # staged calls on the general kernel: the batch instantiation instead of the low-latency one
 KERNEL_AUTO, KERNEL_COMPACT, KERNEL_SPLIT, KERNEL_WAVE, KERNEL_WRENCH = 0, 3, 4, 5, 6   # 1, 2: the retired round-1 baselines
 
 EXPORTS = (
@@ -55,7 +56,7 @@ class Config(C.Structure):
         ("dt", C.c_double), ("mass", C.c_double), ("inertia", C.c_double * 3), ("mu", C.c_double),
         ("fz_min", C.c_double), ("fz_max", C.c_double), ("q_diag", C.c_double * NX), ("r_diag", C.c_double),
         ("force_scale", C.c_double), ("rho", C.c_double), ("rho_eq_scale", C.c_double), ("sigma", C.c_double),
-        ("alpha", C.c_double), ("eps_abs", C.c_double), ("eps_rel", C.c_double),
+        ("alpha", C.c_double), ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("rho_fz_scale", C.c_double),
     ]
 
 

@@ -64,6 +64,8 @@ struct srbdqp_handle {
     int32_t* done_count = nullptr;
     int32_t done_seq = 0;
     bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
+    bool staged_call = false;      // inside srbdqp_solve_staged_f64 (with or without the completion word)
+    int staged_neff = 0;           // ... with the largest number of presolved variables (3 x stance contacts) among its QPs
     bool lazy_restart = false;     // staged path: run only the first pass; the host starts the second one if a status asks for it
     int32_t prepared_B = 0; int prepared_maxs = 4; bool prepared_pcom = false;   // two-phase call: a set-up is pending
     KArgs last_args;               // arguments of that first pass (for the lazily started second pass)
@@ -117,8 +119,8 @@ std::string g_create_err;
         }                                                                                        \
     } while (0)
 
-// fp64 instantiations: N in {4, 8, 10} with up to 4 stance contacts per step; N in {12, 16} with at most 2 (the dense
-// 12N x 12N inverse of the larger cases does not fit on chip)
+// horizons with an instantiation (the 4-wave compact kernel: N in {4, 8, 10} with up to 4 stance contacts per step, N in
+// {12, 16, 20} with at most 2; the one-wave kernel: <= 64 presolved variables; the general kernel: every horizon and pattern)
 bool horizon_supported(int N) { return N == 4 || N == 8 || N == 10 || N == 12 || N == 16 || N == 20 || N == 24; }
 
 int resolve_kernel(const srbdqp_config& c) {
@@ -140,6 +142,7 @@ void fill_args(const srbdqp_config& c, KArgs& a) {
     a.rs2 = c.r_diag * c.force_scale * c.force_scale;
     a.rho = c.rho;
     a.rho_eq = c.rho * c.rho_eq_scale;
+    a.rho_fz = c.rho_fz_scale;
     a.sigma = c.sigma;
     a.alpha = c.alpha;
     a.eps_abs = c.eps_abs;
@@ -166,6 +169,8 @@ constexpr int kSplitMinBatch = 512;
 // mixed gait 13.9 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
 constexpr int kWrenchMinBatch = 768;      // re-measured at the end of round 2 (mixed gait, N = 10): 512 QPs 4.43 M QP/s compact / 4.17 M general,
                                           // 1024 QPs 6.12 M / 7.57 M -- up to two QPs per CU the 4-wave kernel's shorter set-up wins
+constexpr int kStagedWrenchMinVars = 60;   // staged call: presolved variables (3 per stance contact) above which the wrench-space kernel's low-latency
+                                          // instantiation wins (B = 1, N = 10: mixed gait, 72 variables, 74 us compact / 69 us; double support, 120, 107 / 69)
 constexpr int kWrenchMinBatchN20 = 256;   // N = 20: one workgroup per CU on the compact kernel, two on the general one
 
 // fp32 calls of at least this many QPs are split by tile precision (two launches + the classification kernel); smaller
@@ -179,8 +184,13 @@ inline bool uses_wrench(const srbdqp_handle* h, int maxs, int B) {
     // N = 20 single support too, for batches: the general kernel holds 2 workgroups per CU there, the compact one 1
     // (tools/schedule_bench.py, 16,384 QPs: 2.85 M QP/s against 1.95 M; at N = 12 / 16 the compact kernel wins, 7.1 / 4.9 M
     // against 5.7 / 4.2 M)
-    if (N > 10) return maxs > 2 || (N == 20 && h->cfg.kernel == SRBDQP_KERNEL_AUTO && B >= kWrenchMinBatchN20 && !h->stamps && !h->signal_next);
-    return h->cfg.kernel == SRBDQP_KERNEL_AUTO && maxs > 2 && B >= kWrenchMinBatch && !h->stamps && !h->signal_next;
+    if (N > 10) return maxs > 2 || (N == 20 && h->cfg.kernel == SRBDQP_KERNEL_AUTO && B >= kWrenchMinBatchN20 && !h->stamps && !h->staged_call);
+    // N <= 10 with more than 2 stance contacts in a step: batches (the 4-wave kernel wins up to two QPs per CU) AND the staged
+    // low-latency path -- the reference's own call feeds full double support on every step (run_simulation.py:100-101), where the
+    // wrench-space problem is 60 x 60 against the 120 x 120 dense K of the compact kernel (round 3, tools/latency_patterns.py:
+    // B = 1 double support p50 82 us against 112 us)
+    if (h->cfg.kernel != SRBDQP_KERNEL_AUTO || maxs <= 2 || h->stamps) return false;
+    return B >= kWrenchMinBatch || (h->staged_call && N >= 8 && h->staged_neff > kStagedWrenchMinVars);
 }
 
 // KERNEL_SPLIT (A/B): the one-wave set-up and the one-wave ADMM as two kernels with the hand-over through HBM.
@@ -343,6 +353,23 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, double, double, 1, WPS>), dim3((unsigned)a.B), dim3(S::BT), lds, st, a);
         } else { h->err = "the assembly dump is fp64 only"; return SRBDQP_E_INVALID; }
     } else {
+        if constexpr (sizeof(R) == 8 && N <= 10) {
+            // staged batch-1 path (completion word): the low-latency instantiation -- two extra waves for the set-up (tables, T
+            // assembly, tile phases) that end before the iterations, one workgroup's worth of registers (no scratch, V in
+            // registers, every broadcast read of the T^-1 product in flight).  tools/latency_patterns.py
+            if (a.done_flag && !(h->cfg.flags & SRBDQP_FLAG_NO_LAT)) {
+                constexpr int XW = (N >= 8) ? 2 : 1;
+                using SL = srbdqp::WrenchSmem<N, 8, 5, XW>;
+                constexpr size_t ldsl = SL::bytes;
+                int rcl = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, 1, double, 5, XW>, ldsl);
+                if (rcl != SRBDQP_OK) return rcl;
+                static const std::string nml = nm + "_lat";
+                h->kname = nml.c_str();
+                hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, 1, double, 5, XW>), dim3((unsigned)a.B), dim3(SL::BT), ldsl, st, a);
+                HIP_TRY(h, hipGetLastError());
+                return SRBDQP_OK;
+            }
+        }
         int rc = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>, lds);
         if (rc != SRBDQP_OK) return rc;
         h->kname = nm.c_str();
@@ -435,7 +462,9 @@ struct Carver {
 };
 
 // Iteration at which a solve of this handle re-balances rho (0 = never).  srbdqp_config.rho_restart_iter: > 0 that
-// iteration, < 0 off, 0 = automatic: 100 (125 above N = 16) at N > 10 on every kernel -- the long horizons have a 1 - 2 % tail
+// iteration, < 0 off, 0 = automatic: 100 (125 above N = 16) at N > 10 on every kernel -- the long horizons have a 1 - 3 % tail (round 3, N = 20 double
+// support with the (0.7, 4) penalties: 17 % of the QPs run past 80 iterations, 8 % past 100, 3 % past 125 -- an earlier restart sends too many through a second set-up: 80
+// instead of 125 cost configs[2] 10 % for 99.90 % instead of 99.89 % solved)
 // of slow QPs (N = 20 single support: 98.4 % solved without, 99.3 % with) and at their 3 - 20 ms steps the second launch costs
 // 3 - 5 % -- off at N <= 10 (the batch kernels run 0.16 ms steps, where a second launch costs 15 %: DESIGN.md).
 inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B) {
@@ -511,6 +540,7 @@ int srbdqp_default_config(srbdqp_config* c) {
     c->rho = 0.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
     c->eps_abs = 1.0e-6; c->eps_rel = 1.0e-6;
     c->rho_restart_iter = 0; c->reserved0 = 0;
+    c->rho_fz_scale = 0.0;
     return SRBDQP_OK;
 }
 
@@ -526,7 +556,7 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     for (int i = 0; i < 13; ++i) if (!(cfg->q_diag[i] >= 0)) { g_create_err = "negative q_diag"; return SRBDQP_E_INVALID; }
     for (int i = 0; i < 3; ++i) if (!(cfg->inertia[i] > 0)) { g_create_err = "inertia must be positive"; return SRBDQP_E_INVALID; }
     if (!(cfg->alpha > 0 && cfg->alpha < 2) || !(cfg->eps_abs >= 0) || !(cfg->eps_rel >= 0) || !(cfg->eps_abs + cfg->eps_rel > 0) ||
-        !(cfg->fz_min >= 0) || !(cfg->fz_min <= cfg->fz_max) || !(cfg->r_diag >= 0) || !(cfg->rho_eq_scale > 0)) {
+        !(cfg->fz_min >= 0) || !(cfg->fz_min <= cfg->fz_max) || !(cfg->r_diag >= 0) || !(cfg->rho_eq_scale > 0) || !(cfg->rho_fz_scale >= 0)) {
         g_create_err = "invalid constants (alpha in (0, 2), eps >= 0, 0 <= fz_min <= fz_max, r_diag >= 0)"; return SRBDQP_E_INVALID;
     }
     int ndev = 0;
@@ -538,7 +568,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
     srbdqp_handle* h = new (std::nothrow) srbdqp_handle();
     if (!h) { g_create_err = "out of host memory"; return SRBDQP_E_NOMEM; }
     h->cfg = *cfg;
-    if (h->cfg.rho == 0.0) h->cfg.rho = (cfg->horizon <= 10) ? 1.0 : (cfg->horizon <= 16 ? 1.5 : 2.0);   // auto (oracle auto_rho())
+    if (h->cfg.rho == 0.0) h->cfg.rho = 0.7;                    // auto (oracle auto_rho()): friction rows
+    if (h->cfg.rho_fz_scale == 0.0) h->cfg.rho_fz_scale = 4.0;   // auto (oracle auto_rho_fz_scale()): normal-force rows at 4 rho
     auto fail = [&](const char* what, hipError_t er) {
         g_create_err = std::string(what) + ": " + hipGetErrorString(er);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -615,14 +646,23 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     if (B < 0 || B > h->stage_h.capacity) { h->err = "staged batch exceeds the staging capacity"; return SRBDQP_E_INVALID; }
     if (B == 0) return SRBDQP_OK;
     const srbdqp_stage& d = h->stage_d;
-    if (h->cfg.max_contacts_per_step <= 0) {   // same per-batch kernel choice as the host-buffer API
+    h->staged_neff = 0;
+    h->staged_call = true;
+    struct Reset { srbdqp_handle* h; ~Reset() { h->signal_next = false; h->staged_call = false; h->maxs_override = 0; h->staged_neff = 0; } } reset_on_return{h};
+    {   // same per-batch kernel choice as the host-buffer API, from the staged contact flags
         int worst = 0;
         const uint8_t* c = h->stage_h.contact;
-        for (size_t q = 0; q < (size_t)B * h->cfg.horizon; ++q) {
-            const int cnt = (c[4 * q] != 0) + (c[4 * q + 1] != 0) + (c[4 * q + 2] != 0) + (c[4 * q + 3] != 0);
-            if (cnt > worst) worst = cnt;
+        const size_t N = (size_t)h->cfg.horizon;
+        for (size_t b = 0; b < (size_t)B; ++b) {
+            int na = 0;
+            for (size_t q = b * N; q < (b + 1) * N; ++q) {
+                const int cnt = (c[4 * q] != 0) + (c[4 * q + 1] != 0) + (c[4 * q + 2] != 0) + (c[4 * q + 3] != 0);
+                if (cnt > worst) worst = cnt;
+                na += cnt;
+            }
+            if (3 * na > h->staged_neff) h->staged_neff = 3 * na;
         }
-        h->maxs_override = (worst <= 2) ? 2 : 4;
+        if (h->cfg.max_contacts_per_step <= 0) h->maxs_override = (worst <= 2) ? 2 : 4;
     }
     // completion: the compact kernel publishes a sequence number in host memory after its outputs (signal_done());
     // spinning on it skips the stream's completion interrupt (~15 us).  Other kernel variants: stream synchronise.
@@ -655,8 +695,7 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
                                            want_x ? d.x : nullptr, want_y ? d.y : nullptr, d.status, d.iters, h->stream);
     h->sched_hint = hint_keep;
     h->lazy_restart = false;
-    h->maxs_override = 0;
-    h->signal_next = false;
+    // (staged_call / maxs_override / staged_neff stay set until this call returns: a restart pass below must choose the same kernel)
     if (rc != SRBDQP_OK) return rc;
     rc = wait_done();
     if (rc != SRBDQP_OK) return rc;
@@ -991,7 +1030,7 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const dou
     HIP_TRY(h, hipGetLastError());
     // compact K, q, map -> full-size P, q in the original variable order (on the host: bookkeeping, not the hot path)
     std::vector<double> K(n * n), qc(n), mp(m);
-    const double rho = h->cfg.rho, aa = 4.0 * h->cfg.mu * h->cfg.mu + 1.0, sc = h->cfg.force_scale;
+    const double rho = h->cfg.rho, aa = 4.0 * h->cfg.mu * h->cfg.mu + h->cfg.rho_fz_scale, sc = h->cfg.force_scale;
     for (size_t q = 0; q < b; ++q) {
         HIP_TRY(h, hipMemcpyAsync(K.data(), dP + q * n * n, n * n * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipMemcpyAsync(qc.data(), dq + q * n, n * 8, hipMemcpyDeviceToHost, st));

@@ -62,6 +62,7 @@ struct KArgs {
     double sqrtq[12];        // sqrt(q_diag[0..11])
     double rs2;              // r_diag * s^2
     double rho, rho_eq, sigma, alpha, eps_abs, eps_rel;
+    double rho_fz;           // penalty of a stance contact's normal-force row relative to rho (srbdqp_config.rho_fz_scale, resolved)
 };
 
 // QP index of this workgroup

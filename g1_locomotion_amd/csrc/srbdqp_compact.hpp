@@ -138,7 +138,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu;
     float* redf = reinterpret_cast<float*>(sm + S::o_red);
     const double lo = (j < 4) ? -kInf : a.fzmin_s, hi = (j < 4) ? 0.0 : a.fzmax_s;
-    const double rho = rho_b, irho = 1.0 / rho;
+    const double rho = (j == 4) ? rho_b * a.rho_fz : rho_b, irho = 1.0 / rho;   // the normal-force row has its own penalty
     const double sgn = (j < 4 && h == 1) ? -1.0 : 1.0;
     const double muc = (j < 4) ? mu : 0.0;
     const double rowm = has_row ? 1.0 : 0.0;
@@ -599,7 +599,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
                     double v = j0 * Bm[0][a2] + j1 * Bm[1][a2] + j2 * Bm[2][a2];
                     if (a1 == a2) v += same;
                     v *= s2;
-                    if (R == Cc) v += a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b);
+                    if (R == Cc) v += a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + a.rho_fz) * rho_b);
                     if (tr <= tc) T[tile_id(tr, tc) * 256 + (R & 15) * 16 + (Cc & 15)] = v;
                     if (e1 != e2 && tc <= tr) T[tile_id(tc, tr) * 256 + (Cc & 15) * 16 + (R & 15)] = v;
                 }
@@ -646,7 +646,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
                     const double same = (a1 == a2) ? 1.0 : 0.0;
                     v = fma(same, SQ[3 + a1] * SQ[3 + a1] * dt4m2 * (double)sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * (double)Ls, v);
                     double val = s2 * v;
-                    val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + 1.0) * rho_b) : 0.0;
+                    val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + a.rho_fz) * rho_b) : 0.0;
                     val = in ? val : ((r == c) ? 1.0 : 0.0);                // padding -> identity
                     acc[s][q] = val;
                 }

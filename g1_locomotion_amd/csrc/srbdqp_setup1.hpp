@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         // re-read from LDS and re-multiplied for every tile: the stores into the scratch tile keep the compiler from hoisting them)
         const double fa0 = uni(SQ[3] * SQ[3] * dt4m2), fa1 = uni(SQ[4] * SQ[4] * dt4m2), fa2 = uni(SQ[5] * SQ[5] * dt4m2);
         const double fb0 = uni(SQ[9] * SQ[9] * dt2m2), fb1 = uni(SQ[10] * SQ[10] * dt2m2), fb2 = uni(SQ[11] * SQ[11] * dt2m2);
-        const double dgxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dgz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b);
+        const double dgxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dgz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + a.rho_fz) * rho_b);
         // the stance-contact ids of the lane's row / column contact per tile row / column, read once (inside the loop the stores into
         // the scratch tile made every tile re-read them)
         int gr[NT], gc[NT];

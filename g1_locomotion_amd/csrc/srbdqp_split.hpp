@@ -53,8 +53,10 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
     const int base = 3 * cg;
     const int gc = active ? act[cg] : 0;
     const bool rowA = active, rowB = active && ax < 2;
-    const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu, irho = 1.0 / rho_b;
-    const double rhoA = rowA ? rho_b : 0.0, rhoB = rowB ? rho_b : 0.0;      // rho = 0 freezes a slot at y = z = 0
+    const double sigma = a.sigma, alpha = a.alpha, oma = 1.0 - a.alpha, mu = a.mu;
+    const double rho_A = (ax < 2) ? rho_b : rho_b * a.rho_fz;              // slot A of the fz lane = the normal-force row: its own penalty
+    const double irhoA = 1.0 / rho_A, irhoB = 1.0 / rho_b;
+    const double rhoA = rowA ? rho_A : 0.0, rhoB = rowB ? rho_b : 0.0;      // rho = 0 freezes a slot at y = z = 0
     const double loA = !rowA ? 0.0 : (ax < 2 ? -kInf : a.fzmin_s), hiA = !rowA ? 0.0 : (ax < 2 ? 0.0 : a.fzmax_s);
     const double loB = rowB ? -kInf : 0.0, hiB = 0.0;
     const double mucA = (ax < 2) ? mu : 0.0;
@@ -116,7 +118,7 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
             // rows (two slots), relaxation, projection, dual update
             const double nuA = fma(rhoA, ztA - zA, yA), nuB = fma(rhoB, ztB - zB, yB);
             const double zhA = fma(alpha, ztA, oma * zA), zhB = fma(alpha, ztB, oma * zB);
-            const double znA = fmin(fmax(fma(yA, irho, zhA), loA), hiA), znB = fmin(fmax(fma(yB, irho, zhB), loB), hiB);
+            const double znA = fmin(fmax(fma(yA, irhoA, zhA), loA), hiA), znB = fmin(fmax(fma(yB, irhoB, zhB), loB), hiB);
             yA = fma(rhoA, zhA - znA, yA); yB = fma(rhoB, zhB - znB, yB);
             zA = znA; zB = znB;
             axA = fma(alpha, ztA, oma * axA); axB = fma(alpha, ztB, oma * axB);

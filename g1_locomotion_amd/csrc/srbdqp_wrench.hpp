@@ -2,7 +2,7 @@
 //
 // Presolve in two steps.  (1) Swing contacts are eliminated as in srbdqp_compact.hpp.  (2) A step's 3c stance-force
 // variables act on the body only through the 6-vector wrench g = W u, W = [J_e ... ; I I ...] (angular acceleration
-// I_w^-1 sum r x f, total force), and A'A is diagonal per contact (diag(2, 2, 4 mu^2 + 1)), so the reduced-KKT matrix of
+// I_w^-1 sum r x f, total force), and A' rho A is diagonal per contact (rho diag(2, 2, 4 mu^2 + rho_fz): the normal-force row has its own penalty), so the reduced-KKT matrix of
 // the ADMM is  K = D + Y' S Y  with D DIAGONAL and S the Hessian in the per-step coordinates g_j: the 6 wrench
 // coordinates when the step has >= 3 stance contacts (Y_j = W_j), the 3c force variables themselves otherwise (Y_j = I).
 // Woodbury twice:
@@ -44,11 +44,21 @@ namespace srbdqp {
 #define SRBDQP_PHASE_LOCAL(...) asm volatile("" : __VA_ARGS__)
 #endif
 
-template <int N, int TB = 8>   // TB = bytes per tile element: 8 (fp64 tiles) or 4 (fp32 tiles, double-support QPs of the fp32 path)
+// TB = bytes per tile element: 8 (fp64 tiles) or 4 (fp32 tiles, double-support QPs of the fp32 path)
+// SPW = horizon steps per wave: 5 (60 of 64 lanes busy)
+// XW  = extra waves of the workgroup that take part in the set-up only (tables, T assembly, the tile phases F / W / I) and end
+//       before x_q and the iterations: the low-latency instantiation of the staged batch-1 path (N = 10: 2 + 2 waves).  The
+//       tile phases want as many waves as there are tiles; the iteration wants as FEW waves as hold its lanes -- every wave
+//       reads the whole vector v from LDS for its T^-1 rows, so with the steps spread over 4 waves (3 per wave, tried first) the
+//       broadcast reads alone took ~550 of an iteration's ~1950 cycles (tools/wrench_stamps_staged.py, -DSRBDQP_PROFILE_WADMM)
+template <int N, int TB = 8, int SPW = 5, int XW = 0>
 struct WrenchSmem {
+    static_assert(SPW >= 1 && SPW <= 5, "12 lanes per step");
     static constexpr int n = 12 * N, m = 20 * N;
-    static constexpr int NW = (N + 4) / 5;                // waves per QP: 5 steps of 12 lanes per wave
+    static constexpr int NWS = (N + SPW - 1) / SPW;       // waves that carry horizon steps (and run x_q, the iterations, the roll-out)
+    static constexpr int NW = NWS + XW;                   // waves of the workgroup (tile phases)
     static constexpr int BT = 64 * NW;
+    static constexpr int LT = 64 * NWS;                   // threads alive behind the set-up
     static constexpr int NG = 6 * N;                      // upper bound of n_g
     static constexpr int NT = (NG + 15) / 16;
     static constexpr int NTT = NT * (NT + 1) / 2;
@@ -130,6 +140,20 @@ struct WrenchSmem {
     static constexpr int lds_wgs = 163840 / (int)bytes;
 };
 
+// diagnostic builds (-DSRBDQP_PROFILE_WADMM): s_memtime stamps inside the ADMM iteration of the general kernel, summed per
+// segment by thread 0 and written to the second row of the stamp buffer of a B = 1 solve (tools/wrench_stamps_staged.py prints them)
+#ifdef SRBDQP_PROFILE_WADMM
+#define WADMM_T(i) do { if (wadmm_t) { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); wadmm_t[i] = (long long)t_; } } while (0)
+#define WADMM_DECL long long wadmm_tt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wadmm_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long* wadmm_t = wadmm_tt
+#define WADMM_ARGS , wadmm_t
+#define WADMM_PARAMS , long long* wadmm_t = nullptr
+#else
+#define WADMM_T(i) do { } while (0)
+#define WADMM_DECL do { } while (0)
+#define WADMM_ARGS
+#define WADMM_PARAMS
+#endif
+
 // ---- small helpers on the iteration type ----------------------------------------------------------------------------
 __device__ __forceinline__ float dpp_swap1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
@@ -189,10 +213,13 @@ __device__ __forceinline__ double wg_max1(double v, double* red) {
 // so a wave has 256 registers, and the 72-double half row + V + state spilled 8 values per iteration to scratch memory.
 // VL (fp64 iterations of the small instantiations, 3 waves per SIMD): the lane's row and column of V are read from LDS
 // (vlds[i kts] = vrow[i], vlds[(6 + i) kts] = vcol[i], lane-contiguous per entry) instead of 24 registers.
-template <typename R, int CHMAX, int KREG = CHMAX, bool VL = false, typename KT, int BDN, class Hook>
+// WIDE (the low-latency instantiation: one workgroup's worth of registers): every broadcast read of the T^-1 product in flight
+// at once instead of blocks of four (each block was one more LDS round trip in the iteration's chain), and the 6-term
+// products on two accumulators.
+template <typename R, int CHMAX, int KREG = CHMAX, bool VL = false, bool WIDE = false, typename KT, int BDN, class Hook>
 __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, int sg, int ul, bool active_g, int Rrow, int CH,
                                         const KT (&kin)[CHMAX], const R (&vrow_)[6], const R (&vcol_)[6], const R (&bj)[BDN], int vsoff, int vssel,
-                                        Hook&& hook, const R* ktail = nullptr, int kts = 0, const R* vlds = nullptr, const R* vldc = nullptr) {
+                                        Hook&& hook, const R* ktail = nullptr, int kts = 0, const R* vlds = nullptr, const R* vldc = nullptr WADMM_PARAMS) {
     auto KIN = [&](int c) -> R { return (c < KREG) ? (R)kin[c] : ktail[(c - KREG) * kts]; };
     R vrow[6], vcol[6];
 #pragma unroll
@@ -213,8 +240,15 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
             for (int i = 0; i < 3; ++i) { const R2 v = s2[i]; wg[2 * i] = v[0]; wg[2 * i + 1] = v[1]; }
         }
         R vp = R(0);
+        if constexpr (WIDE) {
+            R vq = R(0);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) vp = fma(vrow[i], wg[i], vp);
+            for (int i = 0; i < 3; ++i) { vp = fma(vrow[2 * i], wg[2 * i], vp); vq = fma(vrow[2 * i + 1], wg[2 * i + 1], vq); }
+            vp += vq;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) vp = fma(vrow[i], wg[i], vp);
+        }
         const R v = vp + dpp_swap1(vp);
         if (active_g && h == 0) vb[Rrow] = v;
         asm volatile("" ::: "memory");
@@ -263,7 +297,9 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
             for (int i = 0; i < 12; ++i) xb = fma(bj[i], wg[i], xb);
         }
     }
+    WADMM_T(1);
     __syncthreads();
+    WADMM_T(2);
     hook();
     R tp;
     {
@@ -293,7 +329,7 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
             acc0 = a01[0]; acc1 = a01[1]; acc2 = a23[0]; acc3 = a23[1];
         } else {
             const R2* s2 = reinterpret_cast<const R2*>(src);
-            constexpr int NV = CHMAX / 2, BL = (NV <= 4) ? NV : 4, NB = (NV + BL - 1) / BL;
+            constexpr int NV = CHMAX / 2, BL = (WIDE || NV <= 4) ? NV : 4, NB = (NV + BL - 1) / BL;
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
                 if (blk == 0 || blk * 2 * BL < CH) {
@@ -314,6 +350,7 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
         tp = (acc0 + acc1) + (acc2 + acc3);
     }
     const R tv = tp + dpp_swap1(tp);
+    WADMM_T(3);
     if (h == 0) tbw[6 * sg + (ul >> 1)] = active_g ? tv : R(0);
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -329,8 +366,15 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
             xt = x2[0] + x2[1];
         } else {
             xt = xb;
+            if constexpr (WIDE) {
+                R xu = R(0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { const R2 vv = s2[i]; xt = fma(vcol[2 * i], vv[0], xt); xt = fma(vcol[2 * i + 1], vv[1], xt); }
+                for (int i = 0; i < 3; ++i) { const R2 vv = s2[i]; xt = fma(vcol[2 * i], vv[0], xt); xu = fma(vcol[2 * i + 1], vv[1], xu); }
+                xt += xu;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const R2 vv = s2[i]; xt = fma(vcol[2 * i], vv[0], xt); xt = fma(vcol[2 * i + 1], vv[1], xt); }
+            }
         }
     }
     asm volatile("" ::: "memory");
@@ -338,12 +382,13 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
 }
 
 // One QP (index b) on one workgroup of NW waves.  TIO = element type of the caller's buffers, R = iteration type.
-template <int N, typename R, typename TIO, int MODE, typename TT = double>
+template <int N, typename R, typename TIO, int MODE, typename TT = double, int SPW = 5, int XW = 0>
 __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* sm) {
-    using S = WrenchSmem<N, (int)sizeof(TT)>;
+    using S = WrenchSmem<N, (int)sizeof(TT), SPW, XW>;
     typedef TT v4t __attribute__((ext_vector_type(4)));
     static_assert(sizeof(TT) == 8 || (sizeof(R) == 4 && MODE == 0), "fp32 tiles belong to the fp32 path");
-    constexpr int n = S::n, m = S::m, NW = S::NW, BT = S::BT, TS = S::TS, CHMAX = S::CHMAX;
+    constexpr int n = S::n, m = S::m, NW = S::NW, NWS = S::NWS, BT = S::BT, LT = S::LT, TS = S::TS, CHMAX = S::CHMAX;
+    static_assert(XW == 0 || (sizeof(TT) == 8 && MODE == 0), "extra set-up waves: the fp64 low-latency instantiation");
     static_assert((S::o_R % 2) == 0 && (S::o_wb % 2) == 0 && (S::o_tb % 2) == 0 && (S::o_vb % 2) == 0, "16-byte alignment");
     static_assert(S::NT <= 2 * NW || S::WQ >= 1, "");
     const double rho_b = uni(SRBDQP_RHO_OF(a, b));   // (per-QP values are wave-uniform: scalar registers, see uni())
@@ -455,8 +500,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     bool stepok, wrench, active_u, active_g;
     auto lane_roles = [&](const int ln) __attribute__((always_inline)) {
         sg = ln / 12; ul = ln - 12 * sg;
-        const int jstep = 5 * w + sg;
-        stepok = (sg < 5) && (jstep < N);
+        const int jstep = SPW * w + sg;
+        stepok = (sg < SPW) && (jstep < N) && (XW == 0 || w < NWS);
         js = stepok ? jstep : 0;
         ci = ul / 3; ax = ul - 3 * ci;
         rl = ul >> 1; h = ul & 1;
@@ -612,7 +657,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     }
 
     // ================= per-step wrench blocks: E^-1, V, Bd (registers of the step's lanes) =================
-    const double dxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + 1.0) * rho_b);
+    const double dxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + a.rho_fz) * rho_b);
     const double idxy = uni(1.0 / dxy), idz = uni(1.0 / dz);
     // fp32 tiles (3 workgroups per CU, 168 registers): the rows / columns of V and Bd are formed AFTER the factorisation, from
     // the triangle of E^-1 kept in LDS behind the tiles, and held in fp32 from then on.  Formed here they waited in scratch
@@ -1145,6 +1190,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     const bool failed = sm[S::o_misc] != 0.0;
     const int vsoff = stepok ? igoff[js] : 0;                         // the step's own v = V w inside the v buffer
     __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
+    if constexpr (XW > 0) { if (w >= NWS) __builtin_amdgcn_endpgm(); }   // the set-up helpers end here (s_barrier counts live waves only)
     [[maybe_unused]] const double* vpr = sm + S::o_vpr + (stepok ? uvar : 0);
     [[maybe_unused]] const double* vpc = sm + S::o_vpc + (stepok ? uvar : 0);
     if constexpr (VPARK) {   // V formed only now, and parked in the dead tile region until the iterations start
@@ -1162,7 +1208,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     if constexpr (KREG < CHMAX) {
         R* kt = reinterpret_cast<R*>(sm + S::o_kt) + t;
 #pragma unroll
-        for (int cc = KREG; cc < CHMAX; ++cc) kt[(cc - KREG) * BT] = (R)kin64[cc];
+        for (int cc = KREG; cc < CHMAX; ++cc) kt[(cc - KREG) * LT] = (R)kin64[cc];
         ktail = kt;                                           // (published by the barriers in front of its first use)
     }
     int status = -1, iters = 0;
@@ -1173,7 +1219,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             double* wbw = sm + S::o_wb + 64 * w;
             double* tbw = sm + S::o_tb + 32 * w;
             double* vb = sm + S::o_vb;
-            for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
+            for (int i = t; i < 2 * S::VB; i += LT) vb[i] = 0.0;
             __syncthreads();
             double vrd[6], vcd[6];
             [[maybe_unused]] double bdd[12];
@@ -1186,7 +1232,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 for (int i = 0; i < 12; ++i) bdd[i] = (double)bdrow[i];
                 xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bdd, vsoff, vssel, [] {});
             } else if constexpr (KREG < CHMAX) {
-                xq = apply_kinv<double, CHMAX, KREG>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {}, ktail, BT);
+                xq = apply_kinv<double, CHMAX, KREG>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {}, ktail, LT);
             } else {
                 xq = apply_kinv<double, CHMAX>(-qv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {});
             }
@@ -1205,7 +1251,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const double gtg = gtg_of_x0c();
                 const double dl = (ax < 2) ? dxy : dz;
                 const double rres = active_u ? fma(dl, xq, gtg + qv) : 0.0;
-                for (int i = t; i < 2 * S::VB; i += BT) vb[i] = 0.0;
+                for (int i = t; i < 2 * S::VB; i += LT) vb[i] = 0.0;
                 __syncthreads();
                 double dxq;
                 if constexpr (VPARK) dxq = apply_kinv<double, CHMAX, CHMAX, true>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {}, nullptr, n, vpr, vpc);
@@ -1236,21 +1282,21 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         R* tbw = reinterpret_cast<R*>(sm + S::o_tb) + 32 * w;
         R* vbuf = reinterpret_cast<R*>(sm + S::o_vb);
         float* redf = reinterpret_cast<float*>(sm + S::o_red);          // [2][4 NW] check maxima
-        int* vflag = reinterpret_cast<int*>(redf + 8 * NW);             // [NW] pre-test votes
-        for (int i = t; i < 2 * S::VB; i += BT) vbuf[i] = R(0);
-        if (t < NW) vflag[t] = 0;
+        int* vflag = reinterpret_cast<int*>(redf + 8 * NWS);            // [NWS] pre-test votes
+        for (int i = t; i < 2 * S::VB; i += LT) vbuf[i] = R(0);
+        if (t < NWS) vflag[t] = 0;
         constexpr int BDN = BD_EXPLICIT ? 12 : 4;
         R kin[CHMAX], vr[6], vc[6], bd[BDN];
 #pragma unroll
         for (int cc = 0; cc < CHMAX; ++cc) kin[cc] = (R)kin64[cc];
 #pragma unroll
         for (int i = 0; i < 6; ++i) { vr[i] = VPARK ? (R)vpr[i * n] : (R)vrow[i]; vc[i] = VPARK ? (R)vpc[i * n] : (R)vcol[i]; }
-        constexpr bool VL = SRBDQP_WRENCH_VLDS && sizeof(R) == 8 && sizeof(TT) == 8 && CHMAX <= 36;
+        constexpr bool VL = SRBDQP_WRENCH_VLDS && sizeof(R) == 8 && sizeof(TT) == 8 && CHMAX <= 36 && XW == 0;   // (the low-latency instantiation has the registers)
         [[maybe_unused]] const R* vlds = nullptr;
         if constexpr (VL) {
             R* vt = reinterpret_cast<R*>(sm + S::o_vl) + t;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { vt[i * BT] = vr[i]; vt[(6 + i) * BT] = vc[i]; }
+            for (int i = 0; i < 6; ++i) { vt[i * LT] = vr[i]; vt[(6 + i) * LT] = vc[i]; }
             vlds = vt;                                        // own entries only: no barrier needed
         }
 #pragma unroll
@@ -1258,7 +1304,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const R xqr = (R)xq;
         const bool rowA = active_u, rowB = active_u && ax < 2;
         const R sigma = uni((R)a.sigma), alpha = uni((R)a.alpha), oma = uni((R)(1.0 - a.alpha)), mu = uni((R)a.mu), irho = uni((R)(1.0 / rho_b));
-        const R rhoA = rowA ? (R)rho_b : R(0), rhoB = rowB ? (R)rho_b : R(0);
+        const R irhoz = uni((R)(1.0 / (rho_b * a.rho_fz)));                  // slot A of the fz lane = the normal-force row: its own penalty
+        const R rhoA = rowA ? ((ax < 2) ? (R)rho_b : (R)(rho_b * a.rho_fz)) : R(0), rhoB = rowB ? (R)rho_b : R(0);
         const R loA = !rowA ? R(0) : (ax < 2 ? (R)-kInf : (R)a.fzmin_s), hiA = !rowA ? R(0) : (ax < 2 ? R(0) : (R)a.fzmax_s);
         const R loB = rowB ? (R)-kInf : R(0), hiB = R(0);
         const R mucA = (ax < 2) ? mu : R(0);
@@ -1274,7 +1321,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const R fz0 = bperm(x, cbase + 2);
         R axA = rowA ? fma(-mucA, fz0, x) : R(0), axB = rowB ? fma(-mu, fz0, -x) : R(0);
         R zA = rmin(rmax(axA, loA), hiA), zB = rmin(rmax(axB, loB), hiB);
-        const float qnf = uni((float)wg_max1<NW>(fabs(qv), sm + S::o_red + 24));
+        const float qnf = uni((float)wg_max1<NWS>(fabs(qv), sm + S::o_red + 24));
         R wv = fma(sigma, x, At(fma(rhoA, zA, -yA), fma(rhoB, zB, -yB)));
         __syncthreads();
         // fp32 iterations cannot certify residuals below ~2e-6 (1 + norm): the maxima themselves carry a few ulp of noise
@@ -1284,14 +1331,16 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         bool pending = false, vote_ok = true, done = false;
         double e_prim_last = kInf * 1.0e10;
         float lastv0 = 0.0f, lastv1 = 0.0f, lastv2 = 0.0f, lastv3 = 0.0f;   // maxima of the last full check (restart rule)
+        WADMM_DECL;
         for (int k = 1; k <= a.max_iter + 1 && !done; ++k) {
+            WADMM_T(0);
             R* vb = vbuf + (k & 1) * S::VB;
-            const R kw = apply_kinv<R, CHMAX, KREG, VL>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
+            const R kw = apply_kinv<R, CHMAX, KREG, VL, (XW > 0)>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
                 if (pending) {   // decision of the check made at iteration k - 1 (its maxima were published by this barrier)
-                    const float* buf = redf + ((nchk - 1) & 1) * 4 * NW;
+                    const float* buf = redf + ((nchk - 1) & 1) * 4 * NWS;
                     float v0 = buf[0], v1 = buf[1], v2 = buf[2], v3 = buf[3];
 #pragma unroll
-                    for (int q = 1; q < NW; ++q) { v0 = fmaxf(v0, buf[4 * q]); v1 = fmaxf(v1, buf[4 * q + 1]); v2 = fmaxf(v2, buf[4 * q + 2]); v3 = fmaxf(v3, buf[4 * q + 3]); }
+                    for (int q = 1; q < NWS; ++q) { v0 = fmaxf(v0, buf[4 * q]); v1 = fmaxf(v1, buf[4 * q + 1]); v2 = fmaxf(v2, buf[4 * q + 2]); v3 = fmaxf(v3, buf[4 * q + 3]); }
                     v0 = uni(v0); v1 = uni(v1); v2 = uni(v2); v3 = uni(v3);
                     const double e_prim = uni(eps_a + eps_r * (double)v1);
                     const double e_dual = eps_a + eps_r * fmax((double)v3, (double)qnf);
@@ -1305,15 +1354,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 if (ph == 0) {
                     int vsum = 0;
 #pragma unroll
-                    for (int q = 0; q < NW; ++q) vsum |= vflag[q];
+                    for (int q = 0; q < NWS; ++q) vsum |= vflag[q];
                     vote_ok = (vsum == 0);
                 }
-            }, ktail, BT, vlds);
+            }, ktail, LT, vlds, nullptr WADMM_ARGS);
+            WADMM_T(4);
             if (done || k > a.max_iter) break;
             const bool check = ((ph == 0) && vote_ok) || (k == a.max_iter);
             const bool pretest = (ph == a.check_every - 1);
             const R xt = active_u ? xqr + kw : R(0);
             const R fzt = bperm(xt, cbase + 2);
+            WADMM_T(5);
             R atw;
             if constexpr (sizeof(R) == 4) {
                 // rows A and B of the contact's cone block as one 2-vector: packed fp32 instructions in the fp32 kernels
@@ -1323,7 +1374,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const R2v zt2 = __builtin_elementwise_fma((R2v){-mucA, -mu}, (R2v){fzt, fzt}, (R2v){xt, -xt});
                 const R2v nu2 = __builtin_elementwise_fma(rho2, zt2 - z2, y2);
                 const R2v zh2 = __builtin_elementwise_fma(alpha2, zt2, oma2 * z2);
-                const R2v zc2 = __builtin_elementwise_fma(y2, (R2v){irho, irho}, zh2);
+                const R2v zc2 = __builtin_elementwise_fma(y2, (R2v){(ax < 2) ? irho : irhoz, irho}, zh2);
                 const R znA = rmin(rmax(zc2[0], loA), hiA), znB = rmin(rmax(zc2[1], loB), hiB);
                 const R2v zn2 = (R2v){znA, znB};
                 const R2v yn2 = __builtin_elementwise_fma(rho2, zh2 - zn2, y2);
@@ -1339,7 +1390,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const R ztA = fma(-mucA, fzt, xt), ztB = fma(-mu, fzt, -xt);
                 const R nuA = fma(rhoA, ztA - zA, yA), nuB = fma(rhoB, ztB - zB, yB);
                 const R zhA = fma(alpha, ztA, oma * zA), zhB = fma(alpha, ztB, oma * zB);
-                const R znA = rmin(rmax(fma(yA, irho, zhA), loA), hiA), znB = rmin(rmax(fma(yB, irho, zhB), loB), hiB);
+                const R znA = rmin(rmax(fma(yA, (ax < 2) ? irho : irhoz, zhA), loA), hiA), znB = rmin(rmax(fma(yB, irho, zhB), loB), hiB);
                 yA = fma(rhoA, zhA - znA, yA); yB = fma(rhoB, zhB - znB, yB);
                 zA = znA; zB = znB;
                 axA = fma(alpha, ztA, oma * axA); axB = fma(alpha, ztB, oma * axB);
@@ -1349,6 +1400,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             cpx = fma(alpha, sigma * (x - xt), oma * cpx);
             x = fma(alpha, xt, oma * x);
             wv = fma(sigma, x, atw);
+            WADMM_T(6);
             if (pretest) {
                 const bool bad = (rowA && !((double)rabs(axA - zA) <= e_prim_last)) || (rowB && !((double)rabs(axB - zB) <= e_prim_last));
                 const unsigned long long bal = __ballot(bad);
@@ -1365,12 +1417,19 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const float v2 = active_u ? (float)rd : 0.0f, v3 = active_u ? (float)rmax(rabs(cc - (R)qv), rabs(aty)) : 0.0f;
                 const float m0 = wave_maxf_nonneg(v0), m1 = wave_maxf_nonneg(v1), m2 = wave_maxf_nonneg(v2), m3 = wave_maxf_nonneg(v3);
                 if (lane == 63) {
-                    float* buf = redf + (nchk & 1) * 4 * NW + 4 * w;
+                    float* buf = redf + (nchk & 1) * 4 * NWS + 4 * w;
                     buf[0] = m0; buf[1] = m1; buf[2] = m2; buf[3] = m3;
                 }
                 ++nchk; pending = true;
             }
+#ifdef SRBDQP_PROFILE_WADMM
+            WADMM_T(7);
+            for (int q_ = 0; q_ < 7; ++q_) wadmm_s[q_] += wadmm_t[q_ + 1] - wadmm_t[q_];
+#endif
         }
+#ifdef SRBDQP_PROFILE_WADMM
+        if (a.stamps && t == 0 && a.B == 1) { for (int q_ = 0; q_ < 7; ++q_) a.stamps[16 + q_] = wadmm_s[q_]; }   // (B = 1 probes: second row of the stamp buffer)
+#endif
         if (status < 0) { x = R(0); yA = R(0); yB = R(0); }
         if (a.resid_out && status == 2 && t == 0) {   // for the rho restart (second launch over the capped QPs, srbdqp.hip)
             float* ro = a.resid_out + (size_t)b * 4;
@@ -1398,16 +1457,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     }   // na > 0
 
     // ================= roll-out (a10) and stores =================
+    if constexpr (XW > 0) { if (w >= NWS) __builtin_amdgcn_endpgm(); }   // (early-exit paths: the set-up helpers are still here)
     {
         const double* uh = sm + S::o_xs;
         double* scratch = sm + S::o_scr;
         const size_t row0 = a.row_off ? (size_t)a.row_off[b] : (size_t)b * N;
         TIO* uo = reinterpret_cast<TIO*>(a.u_out) + row0 * 12;
-        for (int c = t; c < n; c += BT) uo[c] = (TIO)(a.s * uh[c]);
+        for (int c = t; c < n; c += LT) uo[c] = (TIO)(a.s * uh[c]);
         if (a.x_out) {
             const double* x0 = sm + S::o_x0;
             double* sj = scratch + 6 * N;
-            for (int idx = t; idx < 6 * N; idx += BT) {
+            for (int idx = t; idx < 6 * N; idx += LT) {
                 const int j = idx / 6, comp = idx % 6;
                 const double* u = uh + 12 * j;
                 double s;
@@ -1422,7 +1482,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 sj[idx] = s;
             }
             __syncthreads();
-            for (int idx = t; idx < 6 * N; idx += BT) {
+            for (int idx = t; idx < 6 * N; idx += LT) {
                 const int k = idx / 6 + 1, comp = idx % 6;
                 double acc2 = 0.0;
                 for (int j = 0; j < k; ++j) acc2 += sj[6 * j + comp];
@@ -1432,7 +1492,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             }
             __syncthreads();
             TIO* xo = reinterpret_cast<TIO*>(a.x_out) + (row0 + (size_t)b) * 13;      // N + 1 rows per QP
-            for (int idx = t; idx < 13 * (N + 1); idx += BT) {
+            for (int idx = t; idx < 13 * (N + 1); idx += LT) {
                 const int k = idx / 13, comp = idx % 13;
                 double v;
                 if (k == 0) v = x0[comp];
@@ -1458,8 +1518,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     SRBDQP_STAMP(a, b, 9);
 }
 
-template <int N, typename R, typename TIO, int MODE, int WPS, typename TT = double>
-__global__ __launch_bounds__(WrenchSmem<N>::BT, WPS) void srbdqp_wrench_kernel(KArgs a) {
+template <int N, typename R, typename TIO, int MODE, int WPS, typename TT = double, int SPW = 5, int XW = 0>
+__global__ __launch_bounds__((WrenchSmem<N, 8, SPW, XW>::BT), WPS) void srbdqp_wrench_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if ((int)blockIdx.x >= a.B) return;
     if (a.tile_sel) {   // fp32 calls: this launch takes the QPs with (1) / without (2) wrench coordinates only
@@ -1473,7 +1533,7 @@ __global__ __launch_bounds__(WrenchSmem<N>::BT, WPS) void srbdqp_wrench_kernel(K
     // restart pass: the workgroup of a QP that did not end at the cap leaves at once; no loop over QPs here -- any loop around the body makes hipcc
     // hoist the body's lane-index expressions out of it and spill them (750 bytes of scratch per lane at N = 20)
     if ((!a.count_ptr || (int)blockIdx.x < *a.count_ptr) && !SRBDQP_RESTART_SKIP(a, SRBDQP_QP_INDEX(a)))
-        wrench_qp<N, R, TIO, MODE, TT>(a, SRBDQP_QP_INDEX(a), sm);
+        wrench_qp<N, R, TIO, MODE, TT, SPW, XW>(a, SRBDQP_QP_INDEX(a), sm);
     signal_done(a);   // staged path: every workgroup of the launch reports once, with or without work
 }
 

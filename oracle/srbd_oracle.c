@@ -29,6 +29,7 @@ typedef struct {
     double dt, mass, inertia[3], mu, fz_min, fz_max;
     double q_diag[NX], r_diag, force_scale;
     double rho, rho_eq_scale, sigma, alpha, eps_abs, eps_rel;
+    double rho_fz_scale;   /* penalty of a stance contact's normal-force row relative to rho (srbd_oracle.py SrbdParams) */
     int max_iter, check_every;
     int rho_restart_iter;  /* presolved path: one OSQP-style re-balancing of rho after this many iterations (0 = off) */
     int eliminate_swing;   /* presolve: drop the variables/rows of swing contacts (kernel v2); 0 = clamp via bounds */
@@ -173,7 +174,7 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
         for (int j = 0; j < 4; ++j) { lo[r0 + j] = -INF; hi[r0 + j] = 0.0; rho[r0 + j] = p->rho; }
         lo[r0 + 4] = on ? p->fz_min / sc : 0.0;
         hi[r0 + 4] = on ? p->fz_max / sc : 0.0;
-        rho[r0 + 4] = on ? p->rho : p->rho * p->rho_eq_scale;
+        rho[r0 + 4] = on ? p->rho * p->rho_fz_scale : p->rho * p->rho_eq_scale;
     }
     /* a9: K (compact), Cholesky, inverse */
 #define VIDX(v) (3 * cmap[(v) / 3] + (v) % 3)       /* compact variable -> original variable */
@@ -318,7 +319,7 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
         const double num = last_rp / fmax(last_np, 1e-30), den = last_rd / fmax(last_nd, 1e-30);
         double r1 = p->rho;
         if (num > 0.0 && den > 0.0 && num <= INF && den <= INF) r1 = fmin(fmax(p->rho * sqrt(num / den), p->rho * 0.1), p->rho * 5.0);
-        for (int i = 0; i < mr; ++i) rho[i] = r1;
+        for (int i = 0; i < mr; ++i) rho[i] = (i % 5 == 4) ? r1 * p->rho_fz_scale : r1;   /* (restart: presolved path only, every row a stance row) */
         iters_base = restart;
     }
     }   /* pass */

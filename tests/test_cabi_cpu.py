@@ -41,6 +41,7 @@ def test_config_struct_and_defaults_match_the_oracle(built_lib):
     for k in ("dt", "mass", "mu", "fz_min", "fz_max", "r_diag", "force_scale", "rho_eq_scale", "sigma", "alpha", "eps_abs", "eps_rel"):
         assert getattr(cfg, k) == getattr(p, k), k
     assert cfg.rho == 0.0 and orc.auto_rho(cfg.horizon) == p.rho          # 0 = chosen from the horizon (oracle auto_rho)
+    assert cfg.rho_fz_scale == 0.0 and orc.auto_rho_fz_scale(cfg.horizon) == p.rho_fz_scale
     assert tuple(cfg.inertia) == tuple(p.inertia) and tuple(cfg.q_diag) == tuple(p.q_diag)
     # the header's status / error codes are the ones the Python side and the oracle use
     hdr = open(os.path.join(ROOT, "include", "srbdqp.h")).read()

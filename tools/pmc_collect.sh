@@ -22,7 +22,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F64" \
            "SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64"; do
     i=$((i+1))
-    if ! timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 "$R/bench.py" "${BENCH_ARGS[@]}" --no-cpu-baseline --no-latency > "$OUT/g$i.log" 2>&1; then
+    if ! timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 "$R/bench.py" "${BENCH_ARGS[@]}" --no-cpu-baseline --no-latency --no-also > "$OUT/g$i.log" 2>&1; then
         echo "group $i FAILED ($grp)"; tail -5 "$OUT/g$i.log"; exit 1
     fi
     echo "group $i done: $grp"

@@ -10,8 +10,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/prof_${RR}_c${CFG}${EXTRA:+_${KN}}
 mkdir -p "$O"
 cd "$R"
-STEPS=20; [ "$CFG" = "2" ] && STEPS=6
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --config $CFG --streams 1 --steps $STEPS --warmup 4 --no-cpu-baseline --no-latency $EXTRA > "$O/stats.log" 2>&1)
+STEPS=20; [ "$CFG" = "2" ] && STEPS=6; [ "$CFG" = "4" ] && STEPS=5
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --config $CFG --streams 1 --steps $STEPS --warmup 4 --no-cpu-baseline --no-latency --no-also $EXTRA > "$O/stats.log" 2>&1)
 find "$O/stats" -name "*kernel_stats.csv" -exec cp {} "$O/${RR}_${KN}_kernel_stats.csv" \;
 bash tools/pmc_collect.sh "$(basename "$O")/pmc" --config $CFG --streams 1 --steps 4 --warmup 4 $EXTRA > "$O/pmc_collect.log" 2>&1
 python tools/pmc_summary.py "$O/pmc" "$O/stats" "$O/${RR}_${KN}_pmc_summary.json" "$KN" $B $N $ESZ ${RR#r} $LPS > "$O/pmc_summary_print.txt" 2> "$O/pmc_summary.err"
