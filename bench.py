@@ -321,6 +321,10 @@ def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step
                 r["executed_flops_per_launch"] = fl
                 r["achieved"] = fl / (kernel_ms * 1e-3) / 1e12
                 r["frac"] = r["achieved"] / peak
+                # the same issued flops over the DRIVER-visible step time: with the steps of two streams overlapping, a step takes less
+                # wall time than one launch lasts (profiles/r03_two_streams_timeline.txt), and an isolated launch of 4096 QPs lasts as
+                # long as its slowest QP (250 iterations) -- the chip-level rate of the kernel is this one
+                r["frac_at_step_rate"] = fl / (ms_per_step * 1e-3) / 1e12 / peak
                 r["bound"] = ex["bound"]
                 r["utilisation"] = ex["utilisation"]
             r["pmc_summary"] = os.path.relpath(best["_file"], ROOT) + (" (counted at %d QPs per launch, scaled per QP)" % best["batch_per_launch"] if scaled else "")

@@ -209,6 +209,7 @@ int launch_split(srbdqp_handle* h, KArgs a, hipStream_t st) {
         slot->ws_doubles = need;
     }
     a.ws = slot->ws;
+    h->prepared_B = 0;                                      // the split pipeline overwrites the workspace a pending two-phase set-up lives in
     constexpr size_t ldsA = srbdqp::CompactTraits<N, MAXS>::lds_bytes, ldsB = srbdqp::SplitSmem<N, MAXS>::bytes;
     int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, true>, ldsA);
     if (rc != SRBDQP_OK) return rc;
@@ -1054,16 +1055,21 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const dou
                 P[(size_t)vr * n + vc] = v;
             }
         }
-        // a8: rows 20 k + 5 i + j of step k, contact i
+        // a8: rows 20 k + 5 i + j of step k, contact i.  Stance contacts: the bounds the kernel dumped (what its ADMM loop uses);
+        // swing contacts were eliminated by the presolve (their rows do not exist on the device): force clamped to 0
         for (size_t k = 0; k < N; ++k)
             for (int i = 0; i < 4; ++i) {
-                const bool on = contact[(q * N + k) * 4 + i] != 0;
                 double* lo = l_out + q * m + 20 * k + 5 * i;
                 double* hi = ub_out + q * m + 20 * k + 5 * i;
-                for (int j = 0; j < 4; ++j) { lo[j] = -srbdqp::kInf; hi[j] = 0.0; }
-                lo[4] = on ? h->cfg.fz_min / sc : 0.0;
-                hi[4] = on ? h->cfg.fz_max / sc : 0.0;
+                for (int j = 0; j < 4; ++j) { lo[j] = mp[12 * N]; hi[j] = mp[12 * N + 1]; }
+                lo[4] = 0.0; hi[4] = 0.0;
             }
+        for (int e = 0; e < na; ++e) {
+            const int gc = (int)mp[e];
+            l_out[q * m + 5 * gc + 4] = mp[4 * N + e];
+            ub_out[q * m + 5 * gc + 4] = mp[8 * N + e];
+        }
+        (void)sc;
     }
     return SRBDQP_OK;
 }
@@ -1131,6 +1137,7 @@ struct srbdqp_ragged {
     std::vector<srbdqp_handle*> hs;          // one engine (own stream) per horizon bucket
     std::vector<int> horizons;
     std::vector<hipEvent_t> ev_out;
+    std::vector<char> ev_out_used;            // ev_out[i] has been recorded by an earlier call
     hipEvent_t ev_in = nullptr;
     bool ev_in_pending = false;
     int device = 0;
@@ -1183,6 +1190,7 @@ int srbdqp_ragged_create(const srbdqp_config* cfg, const int32_t* horizons, int3
         hipEvent_t ev = nullptr;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(SRBDQP_E_HIP, "hipEventCreate");
         r->ev_out.push_back(ev);
+        r->ev_out_used.push_back(0);
     }
     if (hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming) != hipSuccess) return fail(SRBDQP_E_HIP, "hipEventCreate");
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return fail(SRBDQP_E_HIP, "hipStreamCreate");
@@ -1267,6 +1275,9 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
     }
     std::vector<int> fill(start.begin(), start.end() - 1);
     for (int32_t b = 0; b < B; ++b) r->h_perm[fill[(size_t)which[(size_t)b]]++] = b;
+    // the index arrays (and the restart buffers) are shared by the calls of this object: the upload below must not overtake the
+    // bucket kernels of an earlier call made on ANOTHER caller stream (calls on one stream are ordered through ev_out already)
+    for (size_t i = 0; i < nb; ++i) if (r->ev_out_used[i]) RAG_TRY(r, hipStreamWaitEvent(sin, r->ev_out[i], 0));
     RAG_TRY(r, hipMemcpyAsync(r->d_off, r->h_off, (size_t)B * 4, hipMemcpyHostToDevice, sin));
     RAG_TRY(r, hipMemcpyAsync(r->d_perm, r->h_perm, (size_t)B * 4, hipMemcpyHostToDevice, sin));
     RAG_TRY(r, hipEventRecord(r->ev_in, sin));
@@ -1303,6 +1314,7 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
         }
         if (rc != SRBDQP_OK) { r->err = std::string("bucket N=") + std::to_string(r->horizons[i]) + ": " + bh->err; return rc; }
         RAG_TRY(r, hipEventRecord(r->ev_out[i], bs));
+        r->ev_out_used[i] = 1;
         RAG_TRY(r, hipStreamWaitEvent(sin, r->ev_out[i], 0));
     }
     return SRBDQP_OK;

@@ -314,7 +314,10 @@ struct SplitWs {
 // Assembly dump shared by the compact and the one-wave kernels (mode 1): the reduced-KKT matrix K = P + sigma I + A' rho A
 // of the PRESOLVED QP exactly as the kernel holds it before its factorisation (upper tiles, C layout -> `tiles(put)`
 // enumerates (row, col, value)), written dense at P_out with row stride 12N (both triangles), the compact gradient at
-// q_out, the compaction map (compact contact -> original contact 4 k + i) at l_out and na at ub_out[0].
+// q_out, the compaction map (compact contact -> original contact 4 k + i) at l_out and na at ub_out[0]; and the bounds of the
+// constraint rows exactly as the ADMM loops of these kernels form them (admm_loop_compact / admm_wave_body: friction rows
+// (-kInf, 0], normal-force row [fzmin_s, fzmax_s] from the same KArgs fields): l_out[4N + e], l_out[8N + e] = bounds of the
+// normal-force row of compact contact e, l_out[12N], l_out[12N + 1] = bounds of a friction row.
 template <int N, class Tiles>
 __device__ __forceinline__ void dump_presolved(const KArgs& a, int b, int n_eff, int na, const double* qc, const uint8_t* act, Tiles&& tiles) {
     constexpr int n = 12 * N, m = 20 * N;
@@ -323,8 +326,18 @@ __device__ __forceinline__ void dump_presolved(const KArgs& a, int b, int n_eff,
         if (r < n_eff && c < n_eff) { P[(size_t)r * n + c] = v; P[(size_t)c * n + r] = v; }
     });
     for (int c = threadIdx.x; c < n_eff; c += blockDim.x) a.q_out[(size_t)b * n + c] = qc[c];
-    for (int e = threadIdx.x; e < na; e += blockDim.x) a.l_out[(size_t)b * m + e] = (double)act[e];
-    if (threadIdx.x == 0) a.ub_out[(size_t)b * m] = (double)na;
+    for (int e = threadIdx.x; e < na; e += blockDim.x) {
+        a.l_out[(size_t)b * m + e] = (double)act[e];
+        const int j = 4;                                                   // row 4 of a contact: the normal-force row
+        a.l_out[(size_t)b * m + 4 * N + e] = (j < 4) ? -kInf : a.fzmin_s;   // (the expressions of admm_loop_compact())
+        a.l_out[(size_t)b * m + 8 * N + e] = (j < 4) ? 0.0 : a.fzmax_s;
+    }
+    if (threadIdx.x == 0) {
+        a.ub_out[(size_t)b * m] = (double)na;
+        const int j = 0;                                                   // rows 0..3: the friction pyramid
+        a.l_out[(size_t)b * m + 12 * N] = (j < 4) ? -kInf : a.fzmin_s;
+        a.l_out[(size_t)b * m + 12 * N + 1] = (j < 4) ? 0.0 : a.fzmax_s;
+    }
 }
 
 // One QP (index b) on one 256-thread workgroup; sm = the workgroup's dynamic LDS (CompactSmem<N, MAXS>::bytes).

@@ -59,12 +59,13 @@ __device__ __forceinline__ void store_tile(double* tile, const v4d& v, int lane)
     }
 }
 
-// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (d is a positive, normal pivot).
+// 1/sqrt(d) of a positive, normal pivot: v_rsq_f64 seed + ONE Newton step.  Measured on gfx950 (tools/rsq_probe.hip, 4 M random
+// doubles over 40 binades): seed 5.2e-8 relative, one step 4.1e-15, two steps 1.4e-16 -- the second step (four more dependent
+// fp64 instructions per pivot, 16 pivots per diagonal tile, on the critical path of every factorisation) bought nothing the
+// ADMM can see: K^-1 is applied to right-hand sides that are themselves only converged to 1e-6.
 __device__ __forceinline__ double fast_rsqrt(double d) {
-    double r = __builtin_amdgcn_rsq(d);
-    double h = 0.5 * d * r;
-    r = fma(r, fma(-h, r, 0.5), r);
-    h = 0.5 * d * r;
+    const double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d * r;
     return fma(r, fma(-h, r, 0.5), r);
 }
 

@@ -176,7 +176,9 @@ class BatchMPC:
 
     def set_schedule_hint(self, iters_prev_ptr=0, length=0):
         """Device address and length of the previous step's iters[] (or 0): longest-first dispatch for the next device
-        solves of at most `length` QPs."""
+        solves of at most `length` QPs.  A hint without a length is an error (it would silently never apply)."""
+        if iters_prev_ptr and int(length) <= 0:
+            raise ValueError("set_schedule_hint: pass the number of entries of iters_prev (length > 0) with the pointer")
         _lib.check(self._lib.srbdqp_set_schedule_hint(self._h, C.c_void_p(int(iters_prev_ptr)) if iters_prev_ptr else None,
                                                       int(length) if iters_prev_ptr else 0), self._h)
 

@@ -174,7 +174,9 @@ int srbdqp_solve_batch_device_f32(srbdqp_handle* h, int32_t B,
  *   P_out [B][12N][12N]   Hessian H = Bs' Q Bs + R s^2 of the PRESOLVED QP in the original variable order: rows / columns of
  *                         swing-contact variables (eliminated before anything is built) are 0
  *   q_out [B][12N]        gradient (0 for swing-contact variables)
- *   l_out, ub_out [B][20N] constraint bounds (rows 20k+5i+j; +-1e30 = unbounded)
+ *   l_out, ub_out [B][20N] constraint bounds (rows 20k+5i+j; +-1e30 = unbounded): for stance contacts the values the kernel's own
+ *                         ADMM loop uses (dumped by the kernel); rows of swing contacts do not exist on the device (presolve) and
+ *                         are reported as the clamp 0 <= fz <= 0 they stand for
  * Configurations that solve on the general kernel (SRBDQP_KERNEL_WRENCH, or what AUTO routes to it) return
  * SRBDQP_E_INVALID: their assembly is srbdqp_assemble_wrench_f64's.
  */
