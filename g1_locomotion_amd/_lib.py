@@ -31,6 +31,7 @@ EXPORTS = (
     "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_solve_batch_f32", "srbdqp_solve_batch_device_f32",
     "srbdqp_assemble_f64", "srbdqp_assemble_wrench_f64",
     "srbdqp_ragged_create", "srbdqp_ragged_destroy", "srbdqp_ragged_last_error", "srbdqp_solve_ragged_device_f64", "srbdqp_solve_ragged_f64",
+    "srbdqp_solve_ragged_device_f32", "srbdqp_solve_ragged_f32", "srbdqp_solve_ragged_warm_device_f64", "srbdqp_solve_ragged_warm_device_f32",
     "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
@@ -137,6 +138,13 @@ def load():
     lib.srbdqp_solve_ragged_device_f64.argtypes = [H, C.c_int32, C.c_void_p, dp, dp, dp, u8p, dp, dp, i32p, i32p, C.c_void_p]
     lib.srbdqp_solve_ragged_device_f64.restype = C.c_int
     lib.srbdqp_solve_ragged_f64.argtypes = [H, C.c_int32, C.c_void_p, dp, dp, dp, u8p, dp, dp, i32p, i32p]
+    lib.srbdqp_solve_ragged_device_f32.argtypes = [H, C.c_int32, C.c_void_p, dp, dp, dp, u8p, dp, dp, i32p, i32p, C.c_void_p]
+    lib.srbdqp_solve_ragged_device_f32.restype = C.c_int
+    lib.srbdqp_solve_ragged_f32.argtypes = [H, C.c_int32, C.c_void_p, dp, dp, dp, u8p, dp, dp, i32p, i32p]
+    lib.srbdqp_solve_ragged_f32.restype = C.c_int
+    for _fn in (lib.srbdqp_solve_ragged_warm_device_f64, lib.srbdqp_solve_ragged_warm_device_f32):
+        _fn.argtypes = [H, C.c_int32, C.c_void_p, dp, dp, dp, u8p, dp, dp, dp, dp, dp, i32p, i32p, C.c_void_p]
+        _fn.restype = C.c_int
     lib.srbdqp_solve_ragged_f64.restype = C.c_int
     lib.srbdqp_set_schedule_hint.argtypes = [H, C.c_void_p, C.c_int32]
     lib.srbdqp_set_schedule_hint.restype = C.c_int

@@ -1155,8 +1155,9 @@ namespace {
 std::string g_ragged_err;
 #define RAG_TRY(r, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (r)->err = std::string(#call) + ": " + hipGetErrorString(e_); return SRBDQP_E_HIP; } } while (0)
 
-int ragged_launch_bucket(srbdqp_handle* bh, const KArgs& a, hipStream_t st) {
-    bh->io_f32 = false;
+int ragged_launch_bucket(srbdqp_handle* bh, const KArgs& a, hipStream_t st, bool f32) {
+    bh->io_f32 = f32;
+    struct Reset { srbdqp_handle* h; ~Reset() { h->io_f32 = false; } } reset_on_return{bh};
     switch (bh->cfg.horizon) {
         case 4: return launch_wrench<4>(bh, a, st);
         case 8: return launch_wrench<8>(bh, a, st);
@@ -1219,9 +1220,13 @@ int srbdqp_ragged_destroy(srbdqp_ragged* r) {
 
 const char* srbdqp_ragged_last_error(const srbdqp_ragged* r) { return r ? r->err.c_str() : g_ragged_err.c_str(); }
 
-int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const double* x0, const double* x_ref,
-                                   const double* foot, const uint8_t* contact, double* u_out, double* x_out, int32_t* status,
-                                   int32_t* iters, void* stream) {
+}  // extern "C"
+
+namespace {
+// common body of the ragged device entry points; esz = element size of the caller's buffers (8 or 4)
+int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const void* x0, const void* x_ref, const void* foot,
+                       const uint8_t* contact, const void* warm_u, const void* warm_y, void* u_out, void* x_out, void* y_out,
+                       int32_t* status, int32_t* iters, void* stream, bool f32) {
     if (!r) return SRBDQP_E_INVALID;
     if (B < 0 || (B > 0 && (!N_per_qp || !x0 || !x_ref || !foot || !contact || !u_out))) { r->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
     if (B == 0) return SRBDQP_OK;
@@ -1291,26 +1296,29 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
         KArgs a;
         std::memset(&a, 0, sizeof(a));
         fill_args(bh->cfg, a);
-        a.x0 = x0; a.xref = x_ref; a.foot = foot; a.contact = contact;
-        a.u_out = u_out; a.x_out = x_out; a.status = status; a.iters = iters;
+        a.x0 = static_cast<const double*>(x0); a.xref = static_cast<const double*>(x_ref); a.foot = static_cast<const double*>(foot); a.contact = contact;
+        a.warm_u = static_cast<const double*>(warm_u); a.warm_y = static_cast<const double*>(warm_y);
+        a.u_out = static_cast<double*>(u_out); a.x_out = static_cast<double*>(x_out); a.y_out = static_cast<double*>(y_out);
+        a.status = status; a.iters = iters;
         a.perm = r->d_perm + start[i]; a.row_off = r->d_off;
         a.B = cnt[i]; a.mode = 0;
         const int restart = restart_iter_of(bh, 4, cnt[i]);
         int rc;
         if (restart > 0) {   // two passes over the bucket, as srbdqp_solve_batch_* does (the second one selects its QPs in-kernel)
             KArgs a1 = a;
-            a1.max_iter = restart; a1.resid_out = r->d_resid; a1.y_out = r->d_y;
+            a1.max_iter = restart; a1.resid_out = r->d_resid;
+            if (!a1.y_out) a1.y_out = r->d_y;               // (the second pass warm-starts from the first pass's duals)
             if (!a1.status) a1.status = r->d_status;
-            rc = ragged_launch_bucket(bh, a1, bs);
+            rc = ragged_launch_bucket(bh, a1, bs, f32);
             if (rc == SRBDQP_OK) {
                 KArgs a2 = a1;
                 a2.resid_in = r->d_resid; a2.resid_out = nullptr;
-                a2.warm_u = u_out; a2.warm_y = r->d_y;
+                a2.warm_u = a1.u_out; a2.warm_y = a1.y_out;
                 a2.max_iter = bh->cfg.max_iter - restart; a2.iters_base = restart;
-                rc = ragged_launch_bucket(bh, a2, bs);
+                rc = ragged_launch_bucket(bh, a2, bs, f32);
             }
         } else {
-            rc = ragged_launch_bucket(bh, a, bs);
+            rc = ragged_launch_bucket(bh, a, bs, f32);
         }
         if (rc != SRBDQP_OK) { r->err = std::string("bucket N=") + std::to_string(r->horizons[i]) + ": " + bh->err; return rc; }
         RAG_TRY(r, hipEventRecord(r->ev_out[i], bs));
@@ -1320,8 +1328,9 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
     return SRBDQP_OK;
 }
 
-int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const double* x0, const double* x_ref,
-                            const double* foot, const uint8_t* contact, double* u_out, double* x_out, int32_t* status, int32_t* iters) {
+// common body of the ragged host entry points
+int ragged_host_impl(srbdqp_ragged* r, int32_t B, size_t esz, const int32_t* N_per_qp, const void* x0, const void* x_ref, const void* foot,
+                     const uint8_t* contact, void* u_out, void* x_out, int32_t* status, int32_t* iters) {
     if (!r) return SRBDQP_E_INVALID;
     if (B < 0 || (B > 0 && (!N_per_qp || !x0 || !x_ref || !foot || !contact || !u_out))) { r->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
     if (B == 0) return SRBDQP_OK;
@@ -1330,10 +1339,10 @@ int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp
     for (int32_t b = 0; b < B; ++b) { if (N_per_qp[b] < 1 || N_per_qp[b] > SRBDQP_MAX_HORIZON) { r->err = "bad horizon in N_per_qp"; return SRBDQP_E_INVALID; } rows += (size_t)N_per_qp[b]; }
     const size_t b = (size_t)B;
     Carver sz(nullptr);
-    double *dx0, *dxr, *dft, *du, *dx; uint8_t* dct; int32_t *dst, *dit;
+    char *dx0, *dxr, *dft, *du, *dx; uint8_t* dct; int32_t *dst, *dit;
     auto carve = [&](Carver& c) {
-        dx0 = c.take<double>(b * 13); dxr = c.take<double>(rows * 13); dft = c.take<double>(rows * 12); dct = c.take<uint8_t>(rows * 4);
-        du = c.take<double>(rows * 12); dx = x_out ? c.take<double>((rows + b) * 13) : nullptr;
+        dx0 = c.take<char>(b * 13 * esz); dxr = c.take<char>(rows * 13 * esz); dft = c.take<char>(rows * 12 * esz); dct = c.take<uint8_t>(rows * 4);
+        du = c.take<char>(rows * 12 * esz); dx = x_out ? c.take<char>((rows + b) * 13 * esz) : nullptr;
         dst = c.take<int32_t>(b); dit = c.take<int32_t>(b);
     };
     carve(sz);
@@ -1346,18 +1355,55 @@ int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp
     Carver cv(r->ws);
     carve(cv);
     hipStream_t st = r->stream;
-    RAG_TRY(r, hipMemcpyAsync(dx0, x0, b * 13 * 8, hipMemcpyHostToDevice, st));
-    RAG_TRY(r, hipMemcpyAsync(dxr, x_ref, rows * 13 * 8, hipMemcpyHostToDevice, st));
-    RAG_TRY(r, hipMemcpyAsync(dft, foot, rows * 12 * 8, hipMemcpyHostToDevice, st));
+    RAG_TRY(r, hipMemcpyAsync(dx0, x0, b * 13 * esz, hipMemcpyHostToDevice, st));
+    RAG_TRY(r, hipMemcpyAsync(dxr, x_ref, rows * 13 * esz, hipMemcpyHostToDevice, st));
+    RAG_TRY(r, hipMemcpyAsync(dft, foot, rows * 12 * esz, hipMemcpyHostToDevice, st));
     RAG_TRY(r, hipMemcpyAsync(dct, contact, rows * 4, hipMemcpyHostToDevice, st));
-    const int rc = srbdqp_solve_ragged_device_f64(r, B, N_per_qp, dx0, dxr, dft, dct, du, dx, dst, dit, st);
+    const int rc = ragged_device_impl(r, B, N_per_qp, dx0, dxr, dft, dct, nullptr, nullptr, du, dx, nullptr, dst, dit, st, esz == 4);
     if (rc != SRBDQP_OK) return rc;
-    RAG_TRY(r, hipMemcpyAsync(u_out, du, rows * 12 * 8, hipMemcpyDeviceToHost, st));
-    if (x_out) RAG_TRY(r, hipMemcpyAsync(x_out, dx, (rows + b) * 13 * 8, hipMemcpyDeviceToHost, st));
+    RAG_TRY(r, hipMemcpyAsync(u_out, du, rows * 12 * esz, hipMemcpyDeviceToHost, st));
+    if (x_out) RAG_TRY(r, hipMemcpyAsync(x_out, dx, (rows + b) * 13 * esz, hipMemcpyDeviceToHost, st));
     if (status) RAG_TRY(r, hipMemcpyAsync(status, dst, b * 4, hipMemcpyDeviceToHost, st));
     if (iters) RAG_TRY(r, hipMemcpyAsync(iters, dit, b * 4, hipMemcpyDeviceToHost, st));
     RAG_TRY(r, hipStreamSynchronize(st));
     return SRBDQP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const double* x0, const double* x_ref,
+                                   const double* foot, const uint8_t* contact, double* u_out, double* x_out, int32_t* status,
+                                   int32_t* iters, void* stream) {
+    return ragged_device_impl(r, B, N_per_qp, x0, x_ref, foot, contact, nullptr, nullptr, u_out, x_out, nullptr, status, iters, stream, false);
+}
+
+int srbdqp_solve_ragged_device_f32(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const float* x0, const float* x_ref,
+                                   const float* foot, const uint8_t* contact, float* u_out, float* x_out, int32_t* status,
+                                   int32_t* iters, void* stream) {
+    return ragged_device_impl(r, B, N_per_qp, x0, x_ref, foot, contact, nullptr, nullptr, u_out, x_out, nullptr, status, iters, stream, true);
+}
+
+int srbdqp_solve_ragged_warm_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const double* x0, const double* x_ref,
+                                        const double* foot, const uint8_t* contact, const double* warm_u, const double* warm_y,
+                                        double* u_out, double* x_out, double* y_out, int32_t* status, int32_t* iters, void* stream) {
+    return ragged_device_impl(r, B, N_per_qp, x0, x_ref, foot, contact, warm_u, warm_y, u_out, x_out, y_out, status, iters, stream, false);
+}
+
+int srbdqp_solve_ragged_warm_device_f32(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const float* x0, const float* x_ref,
+                                        const float* foot, const uint8_t* contact, const float* warm_u, const float* warm_y,
+                                        float* u_out, float* x_out, float* y_out, int32_t* status, int32_t* iters, void* stream) {
+    return ragged_device_impl(r, B, N_per_qp, x0, x_ref, foot, contact, warm_u, warm_y, u_out, x_out, y_out, status, iters, stream, true);
+}
+
+int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const double* x0, const double* x_ref,
+                            const double* foot, const uint8_t* contact, double* u_out, double* x_out, int32_t* status, int32_t* iters) {
+    return ragged_host_impl(r, B, sizeof(double), N_per_qp, x0, x_ref, foot, contact, u_out, x_out, status, iters);
+}
+
+int srbdqp_solve_ragged_f32(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const float* x0, const float* x_ref,
+                            const float* foot, const uint8_t* contact, float* u_out, float* x_out, int32_t* status, int32_t* iters) {
+    return ragged_host_impl(r, B, sizeof(float), N_per_qp, x0, x_ref, foot, contact, u_out, x_out, status, iters);
 }
 
 // ---- the steps either side of the QP (include/srbdqp_cascade.h) --------------------------------------------------

@@ -331,27 +331,37 @@ class RaggedMPC:
             msg = self._lib.srbdqp_ragged_last_error(self._h)
             raise SrbdqpError(f"srbdqp error {rc}: {msg.decode() if msg else '?'}")
 
-    def solve_packed(self, N_per_qp, x0, x_ref, foot, contact, want_x=True):
+    def solve_packed(self, N_per_qp, x0, x_ref, foot, contact, want_x=True, dtype=np.float64):
         """Step-major packed host arrays (include/srbdqp.h): x0 (B,13), x_ref (sum N,13), foot (sum N,12), contact (sum N,4).
-        Returns dict(u (sum N,12), x (sum N + B,13), status (B,), iters (B,), off (B+1,) row offsets)."""
+        Returns dict(u (sum N,12), x (sum N + B,13), status (B,), iters (B,), off (B+1,) row offsets).
+        dtype=np.float32: fp32 buffers and iterations (srbdqp_solve_ragged_f32)."""
+        dt = np.dtype(dtype)
         Nq = np.ascontiguousarray(N_per_qp, dtype=np.int32)
         B, rows = Nq.size, int(Nq.sum())
-        x0 = _as(x0, np.float64, (B, NX), "x0")
-        x_ref = _as(x_ref, np.float64, (rows, NX), "x_ref")
-        foot = _as(foot, np.float64, (rows, NU), "foot")
+        x0 = _as(x0, dt, (B, NX), "x0")
+        x_ref = _as(x_ref, dt, (rows, NX), "x_ref")
+        foot = _as(foot, dt, (rows, NU), "foot")
         contact = _as(np.asarray(contact) != 0, np.uint8, (rows, NC), "contact")
-        u = np.empty((rows, NU)); x = np.empty((rows + B, NX)) if want_x else None
+        u = np.empty((rows, NU), dt); x = np.empty((rows + B, NX), dt) if want_x else None
         status = np.empty(B, np.int32); iters = np.empty(B, np.int32)
-        self._check(self._lib.srbdqp_solve_ragged_f64(self._h, B, _ptr(Nq), _ptr(x0), _ptr(x_ref), _ptr(foot), _ptr(contact),
-                                                      _ptr(u), _ptr(x), _ptr(status), _ptr(iters)))
+        fn = self._lib.srbdqp_solve_ragged_f64 if dt == np.dtype(np.float64) else self._lib.srbdqp_solve_ragged_f32
+        self._check(fn(self._h, B, _ptr(Nq), _ptr(x0), _ptr(x_ref), _ptr(foot), _ptr(contact), _ptr(u), _ptr(x), _ptr(status), _ptr(iters)))
         return dict(u=u, x=x, status=status, iters=iters, off=np.concatenate([[0], np.cumsum(Nq)]))
 
-    def solve_device(self, B, N_per_qp, x0, x_ref, foot, contact, u_out, x_out=0, status=0, iters=0, stream=0):
-        """Packed arrays resident in HBM (raw device addresses); N_per_qp is a HOST int32 array.  Does not synchronise."""
+    def solve_device(self, B, N_per_qp, x0, x_ref, foot, contact, u_out, x_out=0, status=0, iters=0, stream=0, f32=False,
+                     warm_u=0, warm_y=0, y_out=0):
+        """Packed arrays resident in HBM (raw device addresses); N_per_qp is a HOST int32 array.  Does not synchronise.
+        f32=True: float32 buffers and iterations.  warm_u (sum N,12) [N] / warm_y (sum N,20) / y_out (sum N,20): warm start in,
+        dual solution out (srbdqp_solve_ragged_warm_device_*)."""
         Nq = np.ascontiguousarray(N_per_qp, dtype=np.int32)
         v = lambda p: C.c_void_p(int(p)) if p else None
-        self._check(self._lib.srbdqp_solve_ragged_device_f64(self._h, int(B), _ptr(Nq), v(x0), v(x_ref), v(foot), v(contact), v(u_out),
-                                                             v(x_out), v(status), v(iters), v(stream)))
+        if warm_u or warm_y or y_out:
+            fn = self._lib.srbdqp_solve_ragged_warm_device_f32 if f32 else self._lib.srbdqp_solve_ragged_warm_device_f64
+            self._check(fn(self._h, int(B), _ptr(Nq), v(x0), v(x_ref), v(foot), v(contact), v(warm_u), v(warm_y), v(u_out), v(x_out),
+                           v(y_out), v(status), v(iters), v(stream)))
+        else:
+            fn = self._lib.srbdqp_solve_ragged_device_f32 if f32 else self._lib.srbdqp_solve_ragged_device_f64
+            self._check(fn(self._h, int(B), _ptr(Nq), v(x0), v(x_ref), v(foot), v(contact), v(u_out), v(x_out), v(status), v(iters), v(stream)))
 
     def solve(self, problems):
         """problems: sequence of dicts(x0 (13,), x_ref (N,13), foot (N,12), contact (N,4)) with per-QP N.

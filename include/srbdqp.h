@@ -208,7 +208,7 @@ int srbdqp_assemble_wrench_f64(srbdqp_handle* h, int32_t B,
  *   (x_out of QP b starts at row off_b + b: N_b + 1 rows), status / iters [B] in the caller's QP order.
  * Every bucket runs the general kernel (any per-QP contact schedule); cfg is the template of the per-horizon engines
  * (horizon ignored, rho = 0 picks each horizon's own penalty, rho_restart_iter as for a homogeneous batch of that horizon:
- * by default the N > 10 buckets take the two-pass rho restart).  No warm start on this path. */
+ * by default the N > 10 buckets take the two-pass rho restart).  Warm starts: srbdqp_solve_ragged_warm_device_*. */
 typedef struct srbdqp_ragged srbdqp_ragged;
 int srbdqp_ragged_create(const srbdqp_config* cfg, const int32_t* horizons, int32_t n_horizons, srbdqp_ragged** out);
 int srbdqp_ragged_destroy(srbdqp_ragged* r);
@@ -221,6 +221,25 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
 int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,
                             const double* x0, const double* x_ref, const double* foot, const uint8_t* contact,
                             double* u_out, double* x_out, int32_t* status, int32_t* iters);
+/* The same two calls with fp32 buffers and fp32 ADMM iterations (as srbdqp_solve_batch_device_f32 / _f32; every bucket factors
+ * its T in fp64 tiles: a bucket's QPs are not split by tile precision). */
+int srbdqp_solve_ragged_device_f32(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,
+                                   const float* x0, const float* x_ref, const float* foot, const uint8_t* contact,
+                                   float* u_out, float* x_out, int32_t* status, int32_t* iters, void* stream);
+int srbdqp_solve_ragged_f32(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,
+                            const float* x0, const float* x_ref, const float* foot, const uint8_t* contact,
+                            float* u_out, float* x_out, int32_t* status, int32_t* iters);
+/* Ragged solves with a warm start and / or the dual solution back (what a receding-horizon fleet carries from one control
+ * step to the next), DEVICE buffers, packed like u_out:  warm_u [sum N][12] (newtons) and warm_y [sum N][20] may each be NULL
+ * (cold start), y_out [sum N][20] may be NULL. */
+int srbdqp_solve_ragged_warm_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,
+                                        const double* x0, const double* x_ref, const double* foot, const uint8_t* contact,
+                                        const double* warm_u, const double* warm_y,
+                                        double* u_out, double* x_out, double* y_out, int32_t* status, int32_t* iters, void* stream);
+int srbdqp_solve_ragged_warm_device_f32(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,
+                                        const float* x0, const float* x_ref, const float* foot, const uint8_t* contact,
+                                        const float* warm_u, const float* warm_y,
+                                        float* u_out, float* x_out, float* y_out, int32_t* status, int32_t* iters, void* stream);
 
 /* Longest-first scheduling hint for the DEVICE-buffer API only (the host-buffer and the staged calls ignore it):
  * `device_iters_prev` = the iters[] array (device memory, `length` entries) of the previous control step of the same

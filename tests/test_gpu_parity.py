@@ -623,3 +623,55 @@ def test_empty_batch_and_null_optional_outputs(torch_first, built_lib):
         np.testing.assert_array_equal(u.cpu().numpy(), full["u"])
         us.append(full)
     assert (us[1]["status"] == orc.STATUS_SOLVED).sum() >= (us[0]["status"] == orc.STATUS_SOLVED).sum()
+
+
+def test_ragged_f32_and_warm_start_entry_points(torch_first, built_lib):
+    """srbdqp_solve_ragged_f32 / _device_f32 and srbdqp_solve_ragged_warm_device_f64: a mixed-horizon fleet in fp32 equals the
+    per-horizon fp32 engines bit for bit (same kernel, same fp64-tile factorisation), and a ragged solve warm-started from its own
+    primal / dual solution stops at the first check with the same forces."""
+    torch = torch_first
+    from g1_locomotion_amd import RaggedMPC, BatchMPC, _lib
+    rng = np.random.default_rng(31)
+    hz = (8, 12, 20)
+    Bq = 90
+    Nq = rng.choice(hz, Bq).astype(np.int32)
+    parts = [[a[0] for a in orc.synthetic_batch(1, int(N), seed=8100 + i, schedule=("single", "mixed", "double")[i % 3])] for i, N in enumerate(Nq)]
+    x0 = np.stack([p[0] for p in parts]); xr = np.concatenate([p[1] for p in parts]); ft = np.concatenate([p[2] for p in parts]); ct = np.concatenate([p[3] for p in parts])
+    eng = RaggedMPC(horizons=hz, rho_restart_iter=-1)
+    out = eng.solve_packed(Nq, x0, xr, ft, ct, dtype=np.float32)
+    off = out["off"]
+    assert out["u"].dtype == np.float32 and set(np.unique(out["status"])) <= {orc.STATUS_SOLVED, orc.STATUS_MAX_ITER}
+    for N in hz:
+        idx = np.where(Nq == N)[0]
+        with BatchMPC(horizon=int(N), kernel=_lib.KERNEL_WRENCH, rho_restart_iter=-1, flags=_lib.FLAG_F64_TILES) as one:
+            ref = one.solve(x0[idx], np.stack([xr[off[i]:off[i + 1]] for i in idx]), np.stack([ft[off[i]:off[i + 1]] for i in idx]),
+                            np.stack([ct[off[i]:off[i + 1]] for i in idx]), dtype=np.float32)
+        np.testing.assert_array_equal(out["status"][idx], ref["status"])
+        np.testing.assert_array_equal(out["iters"][idx], ref["iters"])
+        for j, i in enumerate(idx):
+            np.testing.assert_array_equal(out["u"][off[i]:off[i + 1]], ref["u"][j])
+    # fp64, device buffers: cold solve with the duals out, then warm-started from its own solution
+    dev = torch.device("cuda", 0)
+    rows = int(Nq.sum())
+    d = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x0, xr, ft, ct)]
+    u = torch.zeros((rows, 12), dtype=torch.float64, device=dev); y = torch.zeros((rows, 20), dtype=torch.float64, device=dev)
+    u2 = torch.zeros_like(u); y2 = torch.zeros_like(y)
+    st = torch.zeros(Bq, dtype=torch.int32, device=dev); it = torch.zeros(Bq, dtype=torch.int32, device=dev)
+    st2 = torch.zeros_like(st); it2 = torch.zeros_like(it)
+    eng.solve_device(Bq, Nq, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(), status=st.data_ptr(),
+                     iters=it.data_ptr(), y_out=y.data_ptr())
+    eng.solve_device(Bq, Nq, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u2.data_ptr(), status=st2.data_ptr(),
+                     iters=it2.data_ptr(), warm_u=u.data_ptr(), warm_y=y.data_ptr(), y_out=y2.data_ptr())
+    torch.cuda.synchronize()
+    eng.close()
+    ok = (st.cpu().numpy() == orc.STATUS_SOLVED)
+    assert ok.mean() > 0.9
+    assert (it2.cpu().numpy()[ok] == 5).all() and (st2.cpu().numpy()[ok] == orc.STATUS_SOLVED).all()
+    du = (u2 - u).abs().cpu().numpy()
+    rows_ok = np.concatenate([np.full(int(n), o) for n, o in zip(Nq, ok)])
+    assert du[rows_ok].max() < 5e-3
+    # the cold fp64 result is the ordinary ragged result
+    ref64 = RaggedMPC(horizons=hz, rho_restart_iter=-1)
+    o64 = ref64.solve_packed(Nq, x0, xr, ft, ct)
+    ref64.close()
+    np.testing.assert_array_equal(o64["u"], u.cpu().numpy())
