@@ -32,6 +32,32 @@ __device__ __forceinline__ double bperm_f64(double v, int src_lane) {   // value
     return __hiloint2double(hi, lo);
 }
 
+// acc += k * (value of `chunk` in lane J of this lane's 16-lane row): a DP-ALU DPP operand (gfx90a+: 64-bit VOP2 instructions take
+// row_newbcast), so a wave-wide broadcast mat-vec needs no LDS read per term.  Measured against the LDS form (one ds_write_b64 +
+// broadcast ds_read_b128s + v_fmac_f64) on a 64 x 64 row-per-lane product, tools/dpp_probe.hip: 545 against 781 cycles per
+// product for one wave alone, 666 against 1082 with 8 waves per CU -- the broadcast reads of 8 resident QPs keep the CU's LDS
+// pipeline busier than its vector ALUs.
+// (The first use of a chunk carries two wait states in front: a VGPR written by a vector instruction must not be read through DPP
+// by the next one, and the hazard recogniser cannot see into inline asm -- the compiler may have just moved the chunk into place.)
+template <int J>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double chunk, double k) {
+    if constexpr (J == 0)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(chunk), "v"(k), "n"(J));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(chunk), "v"(k), "n"(J));
+}
+// acc[j & 3] += kin[16 C + j] * bcast_j(ch) for j = J .. 15, columns < KS
+template <int KS, int C, int J = 0>
+struct RowBcastChunk {
+    template <int KN>
+    static __device__ __forceinline__ void run(double (&acc)[4], double ch, const double (&kin)[KN]) {
+        if constexpr (16 * C + J < KS) {
+            fmac_row_bcast<J>(acc[J & 3], ch, kin[16 * C + J]);
+            if constexpr (J + 1 < 16) RowBcastChunk<KS, C, J + 1>::run(acc, ch, kin);
+        }
+    }
+};
+
 // max over the wave of a NON-NEGATIVE value (0 is shifted in at the row edges), result valid in lane 63
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_max_step(double v) {

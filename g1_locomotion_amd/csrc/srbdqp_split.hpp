@@ -35,10 +35,8 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
     using L = SplitSmem<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m, KS = W::KS;
     const int lane = threadIdx.x;
-    double* rb = sm + L::o_rhs;
     double* xs_full = sm + L::o_xs;
     for (int i = lane; i < n; i += 64) xs_full[i] = 0.0;
-    if (lane < 8) rb[64 + lane] = 0.0;
     __syncthreads();
     const int* icnt = reinterpret_cast<const int*>(sm + S::o_int);
     const int* imisc = icnt + 2 * N;
@@ -80,7 +78,7 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
         double axA = rowA ? fma(-mucA, fz0, x) : 0.0, axB = rowB ? fma(-mu, fz0, -x) : 0.0;     // (A x)_slot by recursion
         double zA = fmin(fmax(axA, loA), hiA), zB = fmin(fmax(axB, loB), hiB);
         const float qnf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg((float)fabs(qv))), 63));
-        rb[lane] = sigma * x - qv + At(rhoA * zA - yA, rhoB * zB - yB);
+        double rhs = sigma * x - qv + At(rhoA * zA - yA, rhoB * zB - yB);     // (inactive lanes: 0)
         status = 2; iters = a.max_iter;
         double e_prim_last = kInf * 1.0e10;
         bool vote_ok = true;
@@ -91,27 +89,25 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
             const bool at_mark = (ph == 0);
             const bool check = (at_mark && vote_ok) || (k == a.max_iter);
             const bool pretest = (ph == a.check_every - 1);
-            // x~ = K^-1 rhs: rhs broadcast from LDS in blocks of 8 ds_read_b128, four accumulators
-            asm volatile("" ::: "memory");                                  // rb is written as double, read as double2
-            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            // x~ = K^-1 rhs, a K^-1 row per lane.  The right-hand side never leaves the register file's neighbourhood: every 16-lane
+            // row fetches the four 16-value chunks of the vector with ds_bpermute (8 instructions), then each term is one
+            // v_fmac_f64 whose operand is broadcast inside the row by DPP (fmac_row_bcast).  Until round 3 this was one ds_write_b64
+            // and KS / 2 broadcast ds_read_b128 per iteration: with 8 QPs resident per CU the LDS pipeline, not the vector ALU,
+            // paced the iteration.
+            double acc4[4] = {0.0, 0.0, 0.0, 0.0};
             {
-                const double2* rv = reinterpret_cast<const double2*>(rb);
-                constexpr int NV = KS / 2, BL = 8;
+                constexpr int NCH = (KS + 15) / 16;
+                static_assert(NCH <= 4, "one K^-1 row per lane of one wave");
+                double ch[NCH];
+                const int li = lane & 15;
 #pragma unroll
-                for (int blk = 0; blk < (NV + BL - 1) / BL; ++blk) {
-                    double2 v[BL];
-#pragma unroll
-                    for (int i = 0; i < BL; ++i) v[i] = (blk * BL + i < NV) ? rv[blk * BL + i] : make_double2(0.0, 0.0);
-#pragma unroll
-                    for (int i = 0; i < BL; ++i) {
-                        const int c0 = 2 * (blk * BL + i);
-                        if (c0 + 1 < KS) {
-                            if (i & 1) { acc2 = fma(kin[c0], v[i].x, acc2); acc3 = fma(kin[c0 + 1], v[i].y, acc3); }
-                            else { acc0 = fma(kin[c0], v[i].x, acc0); acc1 = fma(kin[c0 + 1], v[i].y, acc1); }
-                        }
-                    }
-                }
+                for (int c = 0; c < NCH; ++c) ch[c] = bperm_f64(rhs, 16 * c + li);
+                RowBcastChunk<KS, 0>::run(acc4, ch[0], kin);
+                if constexpr (NCH > 1) RowBcastChunk<KS, 1>::run(acc4, ch[NCH > 1 ? 1 : 0], kin);
+                if constexpr (NCH > 2) RowBcastChunk<KS, 2>::run(acc4, ch[NCH > 2 ? 2 : 0], kin);
+                if constexpr (NCH > 3) RowBcastChunk<KS, 3>::run(acc4, ch[NCH > 3 ? 3 : 0], kin);
             }
+            const double acc0 = acc4[0], acc1 = acc4[1], acc2 = acc4[2], acc3 = acc4[3];
             const double xt = (acc0 + acc1) + (acc2 + acc3);
             const double fzt = bperm_f64(xt, base + 2);
             const double ztA = fma(-mucA, fzt, xt), ztB = fma(-mu, fzt, -xt);
@@ -126,8 +122,7 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
             const double atw = At(fma(rhoA, zA, -yA), fma(rhoB, zB, -yB));
             cpx = fma(alpha, fma(sigma, x - xt, -qv), oma * cpx);
             x = fma(alpha, xt, oma * x);
-            rb[lane] = fma(sigma, x, -qv) + atw;                           // every lane writes (inactive lanes: 0)
-            asm volatile("" ::: "memory");
+            rhs = fma(sigma, x, -qv) + atw;                                // (inactive lanes: 0)
             if (pretest) {
                 const bool bad = (rowA && !(fabs(axA - zA) <= e_prim_last)) || (rowB && !(fabs(axB - zB) <= e_prim_last));
                 vote_ok = __ballot(bad) == 0ull;
