@@ -345,6 +345,12 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     constexpr int WPS = WrenchTraits<N, R>::wps;
     constexpr size_t lds = S::bytes;
     static_assert(lds <= 163840, "one QP must fit the LDS of a CU");
+    // N = 24 on fp64 tiles holds ONE workgroup of 5 waves per CU (102 KB of LDS): three extra waves that take part in the set-up only
+    // (45 tiles over 8 waves instead of 5; they end before the iterations) cost nothing the CU was using (round 3)
+    constexpr int BXW = (N == 24) ? 3 : 0;
+    using SB = srbdqp::WrenchSmem<N, 8, 5, BXW>;
+    constexpr size_t ldsb = SB::bytes;
+    static_assert(ldsb <= 163840, "one QP must fit the LDS of a CU");
     static const std::string nm = std::string("wrench_") + (sizeof(R) == 4 ? "f32" : "f64") + "_n" + std::to_string(N);
     if (a.mode == 1) {
         if constexpr (sizeof(R) == 8) {
@@ -371,7 +377,7 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
                 return SRBDQP_OK;
             }
         }
-        int rc = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>, lds);
+        int rc = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS, double, 5, BXW>, ldsb);
         if (rc != SRBDQP_OK) return rc;
         h->kname = nm.c_str();
         if constexpr (sizeof(R) == 4) {
@@ -389,12 +395,12 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
                 KArgs a4 = a, a8 = a;
                 a4.tile_sel = 1; a8.tile_sel = 2;
                 hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS4, float>), dim3((unsigned)a.B), dim3(S::BT), lds4, st, a4);
-                hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>), dim3((unsigned)a.B), dim3(S::BT), lds, st, a8);
+                hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS, double, 5, BXW>), dim3((unsigned)a.B), dim3(SB::BT), ldsb, st, a8);
                 HIP_TRY(h, hipGetLastError());
                 return SRBDQP_OK;
             }
         }
-        hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS>), dim3((unsigned)a.B), dim3(S::BT), lds, st, a);
+        hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, WPS, double, 5, BXW>), dim3((unsigned)a.B), dim3(SB::BT), ldsb, st, a);
     }
     HIP_TRY(h, hipGetLastError());
     return SRBDQP_OK;

@@ -69,6 +69,16 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
     return fma(r, fma(-h, r, 0.5), r);
 }
 
+// ... with the second Newton step (1.4e-16 relative): the 6 x 6 wrench blocks E of the general kernel, whose inverse enters T and
+// V at full weight (the assembly parity tests hold both to 1e-11).  Still a fifth of the instructions of 1.0 / sqrt(d).
+__device__ __forceinline__ double fast_rsqrt2(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d * r;
+    r = fma(r, fma(-h, r, 0.5), r);
+    h = 0.5 * d * r;
+    return fma(r, fma(-h, r, 0.5), r);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 16x16 diagonal tile, blocked on the matrix cores: S (SPD, C-layout register tile) -> W = L^-1 (C layout), S = L L'.
 // One wave, nothing leaves the register file.  Row block kb (4 rows) of a C-layout tile is register kb; kept as the

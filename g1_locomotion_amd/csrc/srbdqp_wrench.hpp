@@ -388,7 +388,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     typedef TT v4t __attribute__((ext_vector_type(4)));
     static_assert(sizeof(TT) == 8 || (sizeof(R) == 4 && MODE == 0), "fp32 tiles belong to the fp32 path");
     constexpr int n = S::n, m = S::m, NW = S::NW, NWS = S::NWS, BT = S::BT, LT = S::LT, TS = S::TS, CHMAX = S::CHMAX;
-    static_assert(XW == 0 || (sizeof(TT) == 8 && MODE == 0), "extra set-up waves: the fp64 low-latency instantiation");
+    static_assert(XW == 0 || (sizeof(TT) == 8 && MODE == 0), "extra set-up waves: fp64 tiles, solve mode");
     static_assert((S::o_R % 2) == 0 && (S::o_wb % 2) == 0 && (S::o_tb % 2) == 0 && (S::o_vb % 2) == 0, "16-byte alignment");
     static_assert(S::NT <= 2 * NW || S::WQ >= 1, "");
     const double rho_b = uni(SRBDQP_RHO_OF(a, b));   // (per-QP values are wave-uniform: scalar registers, see uni())
@@ -531,11 +531,21 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     double* T2 = sm + S::o_t2;
     double* MT = sm + S::o_mt;
     double* GV = sm + S::o_gv;
-    for (int k = t; k < n; k += BT) {
+    // Low-latency instantiation (XW = 2): the tables are the two set-up helpers' work -- wave NWS the error vector and the G'v
+    // tables behind it, wave NWS + 1 T1 / T2 and M(j, m) behind them, each chain inside ONE wave (its LDS operations complete in
+    // order: no barrier between the two halves) -- while the step waves compute E, V, Bd, which need none of it; one barrier
+    // joins the three.  Serially (every wave on every table, then E) the two phases took 6.4 k + 8.0 k cycles of a batch-1 solve.
+    constexpr bool TSPLIT = (XW == 2);
+    const bool tab_a = !TSPLIT || w == NWS, tab_b = !TSPLIT || w == NWS + 1;
+    const int tt = TSPLIT ? lane : t;
+    constexpr int TSTR = TSPLIT ? 64 : BT;
+    if (tab_a)
+    for (int k = tt; k < n; k += TSTR) {
         const int i = k / 12, kk = k - 12 * i;
         sm[S::o_eh + k] = SQ[kk] * (free_response<N, S>(a, sm, i, kk) - sm[S::o_xref + i * 13 + kk]);
     }
-    for (int idx = t; idx < 9 * N; idx += BT) {
+    if (tab_b)
+    for (int idx = tt; idx < 9 * N; idx += TSTR) {
         const int mm = idx / 9, pq = idx - 9 * mm, p = pq / 3, q = pq - 3 * p;
         const double* Cm = CP + mm * 9;
         const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2];
@@ -553,11 +563,41 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         T1[idx] = s1;
         T2[idx] = s2;
     }
-    __syncthreads();
+    if constexpr (TSPLIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-local hand-over)
+    else __syncthreads();
     // the 3 torque entries of a step are an O(N) loop of 7 LDS reads, the 6 force entries one of 1 read: the two kinds sit on
     // different waves where the workgroup has more than one (entry by entry over all threads every wave ran both loops)
     constexpr int GT_HL = (64 * ((3 * N + 63) / 64) + 6 * N <= BT) ? 64 * ((3 * N + 63) / 64) : 3 * N;
     static_assert(GT_HL + 6 * N <= BT, "one pass over the G'v tables");
+    [[maybe_unused]] auto gt_tables_wave = [&](const double* vec) {   // the same tables on one wave (XW = 2: helper wave NWS)
+        for (int e0 = lane; e0 < 9 * N; e0 += 64) {
+            if (e0 < 3 * N) {
+                const int j = e0 / 3, comp = e0 - 3 * j;
+                const double* Cj = CP + j * 9;
+                double acc = 0.0;
+                const double c0 = Cj[comp], c1 = Cj[3 + comp], c2 = Cj[6 + comp];
+                const double q0 = SQ[0] * dt2, q1 = SQ[1] * dt2, q2 = SQ[2] * dt2, qw = SQ[6 + comp] * dt;
+#pragma unroll 4
+                for (int i = 0; i < N; ++i) {
+                    const double* Ci = CP + i * 9;
+                    const double* v = vec + 12 * i;
+                    const double on = (i >= j) ? 1.0 : 0.0;
+                    acc = fma(on, (Ci[comp] - c0) * (q0 * v[0]) + (Ci[3 + comp] - c1) * (q1 * v[1]) + (Ci[6 + comp] - c2) * (q2 * v[2]) + qw * v[6 + comp], acc);
+                }
+                GV[9 * j + comp] = acc;
+            } else {
+                const int e = e0 - 3 * N, j = e / 6, comp = 3 + (e - 6 * j);
+                const int kk = (comp < 6) ? comp : 3 + comp;
+                double acc = 0.0;
+#pragma unroll 4
+                for (int i = 0; i < N; ++i) {
+                    const double wgt = (i >= j) ? ((comp < 6) ? (double)(i - j) : 1.0) : 0.0;
+                    acc = fma(wgt, vec[12 * i + kk], acc);
+                }
+                GV[9 * j + comp] = acc;
+            }
+        }
+    };
     auto gt_tables = [&](const double* vec) {
         if (t < 3 * N) {
             const int j = t / 3, comp = t - 3 * j;
@@ -591,11 +631,16 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const double* g = GV + 9 * js;
         return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
     };
-    gt_tables(sm + S::o_eh);
-    mt_tables<N>(CP, T1, T2, SQ, dt2, MT, t, BT);
-    __syncthreads();
+    if constexpr (TSPLIT) {
+        if (tab_a) gt_tables_wave(sm + S::o_eh);
+        if (tab_b) mt_tables<N>(CP, T1, T2, SQ, dt2, MT, lane, 64);
+    } else {
+        gt_tables(sm + S::o_eh);
+        mt_tables<N>(CP, T1, T2, SQ, dt2, MT, t, BT);
+        __syncthreads();
+    }
     SRBDQP_STAMP(a, b, 1);
-    const double qv = active_u ? gt_eval_u() : 0.0;                  // gradient of this lane's variable
+    double qv = 0.0;                                                 // gradient of this lane's variable (needs the G'v tables)
 #ifdef SRBDQP_WRENCH_DEBUG
     if constexpr (MODE == 1) {   // raw LDS image after the tables (diagnostic builds only)
         double* out = a.P_out + (size_t)b * (S::NG * S::NG);
@@ -648,13 +693,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         return active_u ? gt_eval_u() : 0.0;
     };
     double px0 = 0.0, x_init = 0.0;
-    if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0
-        x_init = active_u ? (double)gwu[uvar] / a.s : 0.0;
-        if (stepok) sm[S::o_x0c + uvar] = x_init;
-        __syncthreads();
-        const double gtg = gtg_of_x0c();
-        px0 = active_u ? gtg + a.rs2 * x_init : 0.0;
-    }
+    auto gradient_and_warm_start = [&]() __attribute__((always_inline)) {
+        qv = active_u ? gt_eval_u() : 0.0;
+        if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0
+            x_init = active_u ? (double)gwu[uvar] / a.s : 0.0;
+            if (stepok) sm[S::o_x0c + uvar] = x_init;
+            __syncthreads();
+            const double gtg = gtg_of_x0c();
+            px0 = active_u ? gtg + a.rs2 * x_init : 0.0;
+        }
+    };
+    if constexpr (!TSPLIT) gradient_and_warm_start();   // (XW = 2: behind the barrier that joins the tables and E)
 
     // ================= per-step wrench blocks: E^-1, V, Bd (registers of the step's lanes) =================
     const double dxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + a.rho_fz) * rho_b);
@@ -744,7 +793,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             for (int u2 = 0; u2 < 12; ++u2) bdrow[u2] = BS(0);
         }
     };
-    {
+    if (!TSPLIT || w < NWS) {
         const double* Jj = sm + S::o_J + js * 36;
         const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
         double* ZT = sm + S::o_zt;
@@ -787,7 +836,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
                 for (int k2 = 0; k2 < p; ++k2) d = fma(-Lm[p][k2], Lm[p][k2], d);
                 okE = okE && (d > 0.0);
-                const double inv = 1.0 / sqrt(d);
+                const double inv = (d > 0.0) ? fast_rsqrt2(d) : 0.0;   // (okE reports a non-positive pivot)
                 Lm[p][p] = d * inv;
                 Li[p][p] = inv;
 #pragma unroll
@@ -861,6 +910,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
     }
     __syncthreads();
+    if constexpr (TSPLIT) gradient_and_warm_start();
     if constexpr (MODE == 1) { if (sm[S::o_misc] != 0.0) { if (t == 0) a.ub_out[(size_t)b * (N + 1) + N] = -1.0; return; } }
     if (sm[S::o_misc] != 0.0) {   // degenerate contact geometry: report, return zero forces
         for (int c = t; c < n; c += BT) sm[S::o_xs + c] = 0.0;
@@ -886,7 +936,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     {
         const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
         const double* ZT = sm + S::o_zt;
-        if (sizeof(TT) == 4 && iwr[N] != 0) {   // (fp32 tiles only: in the fp64 instantiations the second copy of the loop gained nothing)
+        if ((sizeof(TT) == 4 || XW > 0) && iwr[N] != 0) {   // (fp32 tiles and the low-latency instantiation: in the fp64 batch instantiations the second copy of the loop gained nothing)
             // every step in wrench coordinates (full double support, configs[2]): step and coordinate of a g row are r / 6 and
             // r % 6, every entry is a table look-up -- no index tables, no 6-vectors (the general loop below spends most of its
             // 38 k cycles on three levels of dependent LDS index reads per entry)
@@ -1335,7 +1385,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         for (int k = 1; k <= a.max_iter + 1 && !done; ++k) {
             WADMM_T(0);
             R* vb = vbuf + (k & 1) * S::VB;
-            const R kw = apply_kinv<R, CHMAX, KREG, VL, (XW > 0)>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
+            const R kw = apply_kinv<R, CHMAX, KREG, VL, (XW > 0 && CHMAX <= 36)>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
                 if (pending) {   // decision of the check made at iteration k - 1 (its maxima were published by this barrier)
                     const float* buf = redf + ((nchk - 1) & 1) * 4 * NWS;
                     float v0 = buf[0], v1 = buf[1], v2 = buf[2], v3 = buf[3];
@@ -1428,7 +1478,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #endif
         }
 #ifdef SRBDQP_PROFILE_WADMM
-        if (a.stamps && t == 0 && a.B == 1) { for (int q_ = 0; q_ < 7; ++q_) a.stamps[16 + q_] = wadmm_s[q_]; }   // (B = 1 probes: second row of the stamp buffer)
+        if (a.stamps && t == 0 && a.B == 1) { for (int q_ = 0; q_ < 7; ++q_) a.stamps[16 + q_] = wadmm_s[q_]; a.stamps[16 + 7] = nchk; }   // (B = 1 probes: second row of the stamp buffer)
 #endif
         if (status < 0) { x = R(0); yA = R(0); yB = R(0); }
         if (a.resid_out && status == 2 && t == 0) {   // for the rho restart (second launch over the capped QPs, srbdqp.hip)

@@ -38,4 +38,4 @@ if s2[:7].any():   # -DSRBDQP_PROFILE_WADMM build: cycles per ADMM iteration by 
     seg = s2[:7] / max(its[-1], 1)
     for nm, v in zip(["w exchange + V w + v publish", "barrier", "check decision + T^-1 v", "t exchange + x~", "fz bpermute", "cone rows + A'", "pre-test / check"], seg):
         print(f"    {nm:42s} {v:7.0f} cyc / iteration")
-    print(f"    sum {seg.sum():.0f}")
+    print(f"    sum {seg.sum():.0f}; full convergence checks in this solve: {int(s2[7])} over {its[-1]} iterations")
