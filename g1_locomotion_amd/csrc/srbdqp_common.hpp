@@ -91,6 +91,17 @@ __device__ __forceinline__ double uni(double v) {
 // M(j, m), j <= m, of the closed-form assembly (derivation: srbdqp_compact.hpp, phase A) at MT[9 (m (m + 1) / 2 + j)]: one step
 // pair = one thread = its 9 entries (the index inversion, the 18 prefix-sum values and the 9 T1 entries are read once per pair;
 // entry by entry over all threads it was 4 x the instructions: 9.8 k -> 3.6 k cycles at N = 20 with three QPs per CU)
+// ... and cut loose from the vector register it was computed in: the compiler otherwise keeps using that copy (a vector operand needs no
+// constant-bus slot), i.e. holds a vector register -- or a scratch slot -- for a uniform constant across the whole kernel
+__device__ __forceinline__ double unis(double v) {
+    // (the builtin is folded away when the compiler can prove its operand uniform -- and the value then stays where the vector ALU left it.  s_nop: a lane read
+    // right behind the fp64 instruction that wrote the register needs a wait state, and the hazard recogniser does not look into inline asm -- without it the
+    // scalar got the register's PREVIOUS contents now and then: the quotient before its v_div_fixup, forces 1e-2 N off)
+    int lo, hi;
+    asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"(__double2loint(v)), "v"(__double2hiint(v)));
+    return __hiloint2double(hi, lo);
+}
+
 template <int N>
 __device__ __forceinline__ void mt_tables(const double* CP, const double* T1, const double* T2, const double* SQ, const double dt2,
                                           double* MT, const int t, const int nthreads) {

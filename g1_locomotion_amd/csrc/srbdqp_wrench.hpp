@@ -78,6 +78,14 @@ struct WrenchSmem {
     static constexpr int o_sq = o_misc + 4;               // 12   sqrt(q_diag)
     static constexpr int o_int = o_sq + 12;               // ints: gsz[N], goff[N + 1], n_g, na, wrench flag[N]
     static constexpr int o_R = o_int + up2((3 * N + 6) / 2 + 1);
+    // ---- phase C (ADMM vectors; element type R <= 8 bytes, offsets in doubles)
+    static constexpr int VB = 2 * CHMAX + 8;              // one v buffer (elements)
+    static constexpr int o_wb = o_R;                      // NW x 64   right-hand sides, wave private
+    static constexpr int o_tb = o_wb + 64 * NW;           // NW x 32   t of the wave's steps, wave private
+    static constexpr int o_vb = o_tb + 32 * NW;           // 2 x VB    v = V w, double buffered
+    static constexpr int o_xs = o_vb + 2 * VB;            // n         full solution (scaled) for the roll-out
+    static constexpr int o_scr = o_xs + n;                // 12N       roll-out scratch
+    static constexpr int endC = o_scr + n + 2;
     // ---- phase A (closed-form assembly)
     static constexpr int o_xref = o_R;                    // 13N
     static constexpr int o_foot = o_xref + up2(N * 13);   // 12N
@@ -88,8 +96,11 @@ struct WrenchSmem {
     static constexpr int o_t2 = o_t1 + up2(9 * N);        // 9N
     static constexpr int o_mt = o_t2 + up2(9 * N);        // 9 NPAIR: M(j, m)
     static constexpr int o_gv = o_mt + up2(9 * NPAIR);    // 9N   G'v tables
-    static constexpr int o_gx = o_gv + up2(9 * N);        // 12N  G x^0 (warm start)
-    static constexpr int o_tf = o_gx + n;                 // 6N
+    // 12N  G x^0 (P x of the warm start, of the refinement).  fp32 tiles: both uses come behind the tile phases (WARM_LATE), so the array lives
+    // in the dead tile region then (behind the parked V rows, in front of the G'v tables) and takes no room in phase A
+    static constexpr bool GX_LATE = TB == 4 && (up2(endC) + 7 * n <= o_gv);
+    static constexpr int o_gx = GX_LATE ? up2(endC) + 6 * n : o_gv + up2(9 * N);
+    static constexpr int o_tf = GX_LATE ? o_gv + up2(9 * N) : o_gx + n;   // 6N
     static constexpr int o_x0c = o_eh;                    // 12N  warm start in the scaled variables (the gradient is done with o_eh by then)
     static constexpr int o_zt = o_tf + 6 * N;             // 6 NG: wrench-space 6-vector of every g coordinate
     static constexpr int o_ei = o_zt + 6 * NG;            // 36N  E^-1 per step
@@ -102,15 +113,12 @@ struct WrenchSmem {
     // rounded copy break the Woodbury identity 100 times worse than rounding V and Bd themselves), written in phase E and kept
     // through phases F / W / I behind the tiles AND behind the phase-A arrays; the rows of V and Bd are formed from it afterwards
     static constexpr int o_e4 = cmax(o_ws + (TB == 4 ? NW * 128 : 0), TB == 4 ? endA : 0);
-    static constexpr int endB = o_e4 + (TB == 4 ? 21 * N : 0);
-    // ---- phase C (ADMM vectors; element type R <= 8 bytes, offsets in doubles)
-    static constexpr int VB = 2 * CHMAX + 8;              // one v buffer (elements)
-    static constexpr int o_wb = o_R;                      // NW x 64   right-hand sides, wave private
-    static constexpr int o_tb = o_wb + 64 * NW;           // NW x 32   t of the wave's steps, wave private
-    static constexpr int o_vb = o_tb + 32 * NW;           // 2 x VB    v = V w, double buffered
-    static constexpr int o_xs = o_vb + 2 * VB;            // n         full solution (scaled) for the roll-out
-    static constexpr int o_scr = o_xs + n;                // 12N       roll-out scratch
-    static constexpr int endC = o_scr + n + 2;
+    // ... and the gradient of every variable (fp32 tiles: 168 registers per lane -- it waited in scratch memory from the tables to x_q)
+    // (only where it costs no occupancy: the fp32-tile kernels are compiled for 3 waves per SIMD = 12 waves per CU)
+    static constexpr int o_qv = o_e4 + (TB == 4 ? 21 * N : 0);
+    static constexpr int wgs_of(int doubles) { return 163840 / (((doubles * 8 + 1279) / 1280) * 1280); }   // (LDS is handed out in blocks of 320 dwords on gfx950)
+    static constexpr bool QV_PARK = TB == 4 && (wgs_of(cmax(endA, o_qv + n / 2)) * NW >= 12 || wgs_of(cmax(endA, o_qv + n / 2)) == wgs_of(cmax(endA, o_qv)));
+    static constexpr int endB = o_qv + (QV_PARK ? n / 2 : 0);   // (n floats: the leading fp32 part; the remainder -- one register -- stays with the lane)
     // fp64 iterations with a half row longer than 60 (N = 24): its last KTAIL entries per lane, entry-major [KTAIL][BT] (the tiles
     // are dead by then and their region is far larger)
     #ifndef SRBDQP_WRENCH_KTAIL36
@@ -118,6 +126,9 @@ struct WrenchSmem {
 #endif
 #ifndef SRBDQP_WRENCH_VLDS
 #define SRBDQP_WRENCH_VLDS 1
+#endif
+#ifndef SRBDQP_WRENCH_JLDS
+#define SRBDQP_WRENCH_JLDS 1
 #endif
 #ifndef SRBDQP_WRENCH_KREG64
 #define SRBDQP_WRENCH_KREG64 56   // entries of the fp64 half row kept in registers when it is longer than 60 (N = 24 mixed gait: 56 -> 1.06 M QP/s with 2 reloads from scratch left in the iteration, 48 -> 1.03 M with none, 40 -> 1.01 M)
@@ -135,9 +146,10 @@ struct WrenchSmem {
     static constexpr int o_vpr = up2(endC);
     static constexpr int o_vpc = o_zt;
     static constexpr bool VPARK = TB == 4 && SRBDQP_WRENCH_VPARK && (o_gv - o_vpr >= 6 * n) && (o_vpc + 6 * n <= o_e4);
+    static_assert(!GX_LATE || o_gx == o_vpr + 6 * n, "fp32 tiles: G x^0 right behind the parked V rows");
     static constexpr int o_end = cmax(endA, cmax(endB, endC2));
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
-    static constexpr int lds_wgs = 163840 / (int)bytes;
+    static constexpr int lds_wgs = wgs_of(o_end);
 };
 
 // diagnostic builds (-DSRBDQP_PROFILE_WADMM): s_memtime stamps inside the ADMM iteration of the general kernel, summed per
@@ -216,10 +228,10 @@ __device__ __forceinline__ double wg_max1(double v, double* red) {
 // WIDE (the low-latency instantiation: one workgroup's worth of registers): every broadcast read of the T^-1 product in flight
 // at once instead of blocks of four (each block was one more LDS round trip in the iteration's chain), and the 6-term
 // products on two accumulators.
-template <typename R, int CHMAX, int KREG = CHMAX, bool VL = false, bool WIDE = false, typename KT, int BDN, class Hook>
+template <typename R, int CHMAX, int KREG = CHMAX, bool VL = false, bool WIDE = false, bool JL = false, typename KT, int BDN, class Hook>
 __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, int sg, int ul, bool active_g, int Rrow, int CH,
                                         const KT (&kin)[CHMAX], const R (&vrow_)[6], const R (&vcol_)[6], const R (&bj)[BDN], int vsoff, int vssel,
-                                        Hook&& hook, const R* ktail = nullptr, int kts = 0, const R* vlds = nullptr, const R* vldc = nullptr WADMM_PARAMS) {
+                                        Hook&& hook, const R* ktail = nullptr, int kts = 0, const R* vlds = nullptr, const R* vldc = nullptr, const double* jl = nullptr WADMM_PARAMS) {
     auto KIN = [&](int c) -> R { return (c < KREG) ? (R)kin[c] : ktail[(c - KREG) * kts]; };
     R vrow[6], vcol[6];
 #pragma unroll
@@ -256,7 +268,12 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
         // order): no barrier needed.  Y' column of the variable: [J[:, u]; e_ax] on a wrench step, the unit vector of its g
         // row on a force-variable step (where the whole term is w - w = 0).
         const R* vs = vb + vsoff;
-        xb = bj[3] * (wv - fma(bj[0], vs[0], fma(bj[1], vs[1], fma(bj[2], vs[2], vb[vssel]))));
+        if constexpr (JL) {   // (the iterations of the fp64 N = 12 instantiation: +1.5 %; N = 8: -2 %, N = 10: nothing)
+              // ... J[:, u] from the persistent strip (jl[0], jl[12], jl[24]) instead of three more registers: they were reloaded from scratch
+            xb = bj[3] * (wv - fma(jl[0], vs[0], fma(jl[12], vs[1], fma(jl[24], vs[2], vb[vssel]))));   // memory every iteration (a force-variable step has bj[3] = 0: its J does not matter)
+        } else {
+            xb = bj[3] * (wv - fma(bj[0], vs[0], fma(bj[1], vs[1], fma(bj[2], vs[2], vb[vssel]))));
+        }
     } else {
         R wg[12];
         {
@@ -329,7 +346,7 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
             acc0 = a01[0]; acc1 = a01[1]; acc2 = a23[0]; acc3 = a23[1];
         } else {
             const R2* s2 = reinterpret_cast<const R2*>(src);
-            constexpr int NV = CHMAX / 2, BL = (WIDE || NV <= 4) ? NV : 4, NB = (NV + BL - 1) / BL;
+            constexpr int NV = CHMAX / 2, BL = (WIDE || NV <= 4) ? NV : ((sizeof(KT) < sizeof(R)) ? 2 : 4), NB = (NV + BL - 1) / BL;   // (fp64 on an fp32 row -- x_q of the fp32-tile kernel, 168 registers: two reads in flight)
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
                 if (blk == 0 || blk * 2 * BL < CH) {
@@ -391,7 +408,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     static_assert(XW == 0 || (sizeof(TT) == 8 && MODE == 0), "extra set-up waves: fp64 tiles, solve mode");
     static_assert((S::o_R % 2) == 0 && (S::o_wb % 2) == 0 && (S::o_tb % 2) == 0 && (S::o_vb % 2) == 0, "16-byte alignment");
     static_assert(S::NT <= 2 * NW || S::WQ >= 1, "");
-    const double rho_b = uni(SRBDQP_RHO_OF(a, b));   // (per-QP values are wave-uniform: scalar registers, see uni())
+    const double rho_b = unis(SRBDQP_RHO_OF(a, b));   // (per-QP values are wave-uniform: scalar registers, see uni())
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     int mcol = lane & 15, kq = lane >> 4;
@@ -526,7 +543,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     } else {
 
     // ================= tables of the closed-form assembly (a6 + a7; srbdqp_compact.hpp has the derivation) =================
-    const double dt = a.dt, dt2 = uni(a.dt * a.dt), dtm = uni(a.dt * a.inv_mass), dt2m = uni(dt2 * a.inv_mass);
+    const double dt = a.dt, dt2 = unis(a.dt * a.dt), dtm = unis(a.dt * a.inv_mass), dt2m = unis(dt2 * a.inv_mass);
     double* T1 = sm + S::o_t1;
     double* T2 = sm + S::o_t2;
     double* MT = sm + S::o_mt;
@@ -627,9 +644,11 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     };
     // (G'v)[u] for this lane's force variable, from the tables
     auto gt_eval_u = [&]() -> double {
-        const double* J = sm + S::o_J + js * 36 + ul;
+        int axl = ax, ull = ul;                                      // (laundered: the factors of the three calls are not worth a register -- in scratch memory -- between them)
+        if constexpr (sizeof(TT) == 4) asm volatile("" : "+v"(axl), "+v"(ull));
+        const double* J = sm + S::o_J + js * 36 + ull;
         const double* g = GV + 9 * js;
-        return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
+        return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + axl] * dt2m * g[3 + axl] + SQ[9 + axl] * dtm * g[6 + axl]);
     };
     if constexpr (TSPLIT) {
         if (tab_a) gt_tables_wave(sm + S::o_eh);
@@ -693,9 +712,12 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         return active_u ? gt_eval_u() : 0.0;
     };
     double px0 = 0.0, x_init = 0.0;
+    // fp32 tiles: P x^0 of a warm start is formed behind the refinement of x_q (which rebuilds the tables it needs anyway) instead of
+    // waiting in two registers -- in scratch memory at the 168-register budget -- across the tile phases
+    constexpr bool WARM_LATE = sizeof(TT) == 4;
     auto gradient_and_warm_start = [&]() __attribute__((always_inline)) {
         qv = active_u ? gt_eval_u() : 0.0;
-        if (a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0
+        if (!WARM_LATE && a.warm_u) {   // P x^0 = G'(G x^0) + R s^2 x^0
             x_init = active_u ? (double)gwu[uvar] / a.s : 0.0;
             if (stepok) sm[S::o_x0c + uvar] = x_init;
             __syncthreads();
@@ -704,10 +726,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
     };
     if constexpr (!TSPLIT) gradient_and_warm_start();   // (XW = 2: behind the barrier that joins the tables and E)
+    [[maybe_unused]] float qv_lo = 0.0f;
+    if constexpr (S::QV_PARK) {   // own entry: read back by the same lane in front of x_q
+        const float qh = (float)qv;
+        qv_lo = (float)(qv - (double)qh);
+        asm volatile("" : "+v"(qv_lo));                              // (formed HERE: left to itself the compiler keeps qv -- in scratch memory -- and forms the remainder at its use)
+        if (stepok) reinterpret_cast<float*>(sm + S::o_qv)[uvar] = qh;
+    }
 
     // ================= per-step wrench blocks: E^-1, V, Bd (registers of the step's lanes) =================
-    const double dxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + a.rho_fz) * rho_b);
-    const double idxy = uni(1.0 / dxy), idz = uni(1.0 / dz);
+    const double dxy = unis(a.rs2 + a.sigma + 2.0 * rho_b), dz = unis(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + a.rho_fz) * rho_b);
+    const double idxy = unis(1.0 / dxy), idz = unis(1.0 / dz);
     // fp32 tiles (3 workgroups per CU, 168 registers): the rows / columns of V and Bd are formed AFTER the factorisation, from
     // the triangle of E^-1 kept in LDS behind the tiles, and held in fp32 from then on.  Formed here they waited in scratch
     // memory across phases F / W / I: 10 GB of HBM traffic per 65,536-QP launch against 0.29 GB of inputs and outputs
@@ -744,13 +773,13 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // itself must not be captured here: a by-reference capture turns its select chains into an indexed scratch array)
     auto form_vbd = [&](const double (&er)[6], const double (&yv)[6]) __attribute__((always_inline)) {
         const double* Jj = sm + S::o_J + js * 36;
-        const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
+        const int fl[4] = {f0, f1, f2, f3};                        // (selects, not factors: the flags as doubles were kept -- spilled -- across the whole kernel)
         // V[rl][6 h + i] = wgt (er[0..2] . J[:, u'] + er[3 + a'])
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int u2 = 6 * h + i;
-            const double flc = (u2 / 3 == 0) ? fl[0] : (u2 / 3 == 1) ? fl[1] : (u2 / 3 == 2) ? fl[2] : fl[3];
-            const double wgt = flc * (((i % 3) < 2) ? idxy : idz);
+            const int flc = (u2 / 3 == 0) ? fl[0] : (u2 / 3 == 1) ? fl[1] : (u2 / 3 == 2) ? fl[2] : fl[3];
+            const double wgt = flc ? (((i % 3) < 2) ? idxy : idz) : 0.0;
             vrow[i] = (VS)(wgt * (er[0] * Jj[u2] + er[1] * Jj[12 + u2] + er[2] * Jj[24 + u2] + er[3 + (i % 3)]));
         }
         const double wu = active_u ? ((ax < 2) ? idxy : idz) : 0.0;
@@ -761,7 +790,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         if constexpr (BD_EXPLICIT && !BD_LAST) {
 #pragma unroll
             for (int u2 = 0; u2 < 12; ++u2) {
-                const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
+                const double wgt2 = fl[u2 / 3] ? (((u2 % 3) < 2) ? idxy : idz) : 0.0;
                 const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
                 bdrow[u2] = (BS)(((u2 == ul) ? wu : 0.0) - wu * wgt2 * dotv);   // D^-1 - D^-1 Y' V (static index: select chain)
             }
@@ -771,11 +800,11 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // less across those two fp64 applications of K^-1)
     [[maybe_unused]] auto form_bd = [&](const double (&yv)[6]) __attribute__((always_inline)) {
         const double* Jj = sm + S::o_J + js * 36;
-        const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
+        const int fl[4] = {f0, f1, f2, f3};
         const double wu = active_u ? ((ax < 2) ? idxy : idz) : 0.0;
 #pragma unroll
         for (int u2 = 0; u2 < 12; ++u2) {
-            const double wgt2 = fl[u2 / 3] * (((u2 % 3) < 2) ? idxy : idz);
+            const double wgt2 = fl[u2 / 3] ? (((u2 % 3) < 2) ? idxy : idz) : 0.0;
             const double dotv = yv[0] * Jj[u2] + yv[1] * Jj[12 + u2] + yv[2] * Jj[24 + u2] + yv[3 + (u2 % 3)];
             bdrow[u2] = (BS)(((u2 == ul) ? wu : 0.0) - wu * wgt2 * dotv);
         }
@@ -795,7 +824,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     };
     if (!TSPLIT || w < NWS) {
         const double* Jj = sm + S::o_J + js * 36;
-        const double fl[4] = {(double)f0, (double)f1, (double)f2, (double)f3};
+        const int fl[4] = {f0, f1, f2, f3};
         double* ZT = sm + S::o_zt;
         double* EI = sm + S::o_ei + 36 * js;
         if (wrench) {
@@ -810,7 +839,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
                 for (int a2 = 0; a2 < 3; ++a2) {
                     const int u2 = 3 * c + a2;
-                    const double wgt = fl[c] * ((a2 < 2) ? idxy : idz);
+                    const double wgt = fl[c] ? ((a2 < 2) ? idxy : idz) : 0.0;
                     const double j0 = Jj[u2], j1 = Jj[12 + u2], j2 = Jj[24 + u2];
                     const double jw[3] = {j0 * wgt, j1 * wgt, j2 * wgt};
 #pragma unroll
@@ -1265,6 +1294,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     R x = R(0), yA = R(0), yB = R(0);
     if (!failed) {
         double xq;
+        if constexpr (S::QV_PARK) qv = stepok ? (double)reinterpret_cast<const float*>(sm + S::o_qv)[uvar] + (double)qv_lo : 0.0;
         {
             double* wbw = sm + S::o_wb + 64 * w;
             double* tbw = sm + S::o_tb + 32 * w;
@@ -1309,6 +1339,21 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 xq = active_u ? xq + dxq : 0.0;
                 __syncthreads();
             }
+            if constexpr (WARM_LATE) {
+                if (a.warm_u) {
+                    if constexpr (sizeof(R) == 4) {   // x_q is only used in the iteration type from here on: one register instead of two across the tables
+                        R xq_r = (R)xq;
+                        asm volatile("" : "+v"(xq_r));
+                        xq = (double)xq_r;
+                    }
+                    x_init = active_u ? (double)gwu[uvar] / a.s : 0.0;
+                    if (stepok) sm[S::o_x0c + uvar] = x_init;
+                    __syncthreads();
+                    const double gtg = gtg_of_x0c();
+                    px0 = active_u ? gtg + a.rs2 * x_init : 0.0;
+                    __syncthreads();
+                }
+            }
         }
         SRBDQP_STAMP(a, b, 7);
 
@@ -1343,6 +1388,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         for (int i = 0; i < 6; ++i) { vr[i] = VPARK ? (R)vpr[i * n] : (R)vrow[i]; vc[i] = VPARK ? (R)vpc[i * n] : (R)vcol[i]; }
         constexpr bool VL = SRBDQP_WRENCH_VLDS && sizeof(R) == 8 && sizeof(TT) == 8 && CHMAX <= 36 && XW == 0;   // (the low-latency instantiation has the registers)
         [[maybe_unused]] const R* vlds = nullptr;
+        [[maybe_unused]] const double* jlds = sm + S::o_J + js * 36 + ul;
         if constexpr (VL) {
             R* vt = reinterpret_cast<R*>(sm + S::o_vl) + t;
 #pragma unroll
@@ -1375,7 +1421,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         R wv = fma(sigma, x, At(fma(rhoA, zA, -yA), fma(rhoB, zB, -yB)));
         __syncthreads();
         // fp32 iterations cannot certify residuals below ~2e-6 (1 + norm): the maxima themselves carry a few ulp of noise
-        const double eps_a = uni((sizeof(R) == 4) ? fmax(a.eps_abs, 2.0e-6) : a.eps_abs), eps_r = uni((sizeof(R) == 4) ? fmax(a.eps_rel, 2.0e-6) : a.eps_rel);
+        const double eps_a = unis((sizeof(R) == 4) ? fmax(a.eps_abs, 2.0e-6) : a.eps_abs), eps_r = unis((sizeof(R) == 4) ? fmax(a.eps_rel, 2.0e-6) : a.eps_rel);
         status = 2; iters = a.max_iter;
         int nchk = 0, ph = 0;
         bool pending = false, vote_ok = true, done = false;
@@ -1385,7 +1431,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         for (int k = 1; k <= a.max_iter + 1 && !done; ++k) {
             WADMM_T(0);
             R* vb = vbuf + (k & 1) * S::VB;
-            const R kw = apply_kinv<R, CHMAX, KREG, VL, (XW > 0 && CHMAX <= 36)>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
+            const R kw = apply_kinv<R, CHMAX, KREG, VL, (XW > 0 && CHMAX <= 36), (VL && sizeof(R) == 8 && CHMAX > 30 && SRBDQP_WRENCH_JLDS != 0)>(wv, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin, vr, vc, bd, vsoff, vssel, [&] {
                 if (pending) {   // decision of the check made at iteration k - 1 (its maxima were published by this barrier)
                     const float* buf = redf + ((nchk - 1) & 1) * 4 * NWS;
                     float v0 = buf[0], v1 = buf[1], v2 = buf[2], v3 = buf[3];
@@ -1407,7 +1453,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                     for (int q = 0; q < NWS; ++q) vsum |= vflag[q];
                     vote_ok = (vsum == 0);
                 }
-            }, ktail, LT, vlds, nullptr WADMM_ARGS);
+            }, ktail, LT, vlds, nullptr, jlds WADMM_ARGS);
             WADMM_T(4);
             if (done || k > a.max_iter) break;
             const bool check = ((ph == 0) && vote_ok) || (k == a.max_iter);
@@ -1488,6 +1534,11 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     }
     SRBDQP_STAMP(a, b, 8);
     __syncthreads();
+    if constexpr (SRBDQP_WRENCH_REROLE && VBD_LATE) {   // the roles the stores below need, derived again instead of waiting in scratch memory across the iterations
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        lane_roles(ln);
+    }
     if (stepok) sm[S::o_xs + uvar] = (double)x;
     if (a.y_out) {
         TIO* yo = reinterpret_cast<TIO*>(a.y_out) + row0 * 20;
