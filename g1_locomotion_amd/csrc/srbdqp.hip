@@ -872,7 +872,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
     KArgs a1 = a;
     a1.max_iter = restart;
     a1.resid_out = slot->resid;
-    if (!a1.y_out) a1.y_out = slot->ybuf;
+    if (!a1.y_out) { a1.y_out = slot->ybuf; a1.y_capped_only = 1; }
     if (!a1.status) a1.status = slot->stbuf;
     if (!lazy) { a1.done_flag = nullptr; a1.done_count = nullptr; }
     rc = launch(h, a1, lst, maxs, lazy ? 0 : 1);
@@ -1313,7 +1313,7 @@ int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, con
         if (restart > 0) {   // two passes over the bucket, as srbdqp_solve_batch_* does (the second one selects its QPs in-kernel)
             KArgs a1 = a;
             a1.max_iter = restart; a1.resid_out = r->d_resid;
-            if (!a1.y_out) a1.y_out = r->d_y;               // (the second pass warm-starts from the first pass's duals)
+            if (!a1.y_out) { a1.y_out = r->d_y; a1.y_capped_only = 1; }   // (the second pass warm-starts from the first pass's duals)
             if (!a1.status) a1.status = r->d_status;
             rc = ragged_launch_bucket(bh, a1, bs, f32);
             if (rc == SRBDQP_OK) {

@@ -51,6 +51,8 @@ struct KArgs {
                              //   that ends at the cap, or null
     const int32_t* count_ptr;   // second pass: number of valid entries of perm[]; workgroups beyond it exit at once
     int32_t iters_base;      // second pass: iterations of the first pass, added to iters[] on output
+    int32_t y_capped_only;   // first pass, y_out = the engine's own buffer (the caller asked for no duals): only a QP that ends at the cap stores them
+                             //   (20 N values per QP for every QP was a quarter of the HBM traffic of a configs[2] solve)
     int32_t qp_span;         // host only: number of QP slots the per-QP workspaces must hold (second pass: original B)
     int32_t* done_flag;      // low-latency completion: GPU-mapped host word that receives done_value once every QP of the
     int32_t* done_count;     //   launch has stored its outputs (done_count: device counter of finished workgroups), or null

@@ -288,7 +288,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
 #endif
     if (status < 0) { x = 0.0; y = 0.0; }                               // a numerical failure returns zero forces, never NaN
     if (active && hp == 0) xs_full[3 * gc + ax] = x;
-    if (a.y_out && has_row) a.y_out[(size_t)b * m + irow] = y;
+    if (a.y_out && has_row && (!a.y_capped_only || status == 2)) a.y_out[(size_t)b * m + irow] = y;
     if (a.resid_out && status == 2 && t == 0) {
         float* ro = a.resid_out + (size_t)b * 4;
         ro[0] = lastv0; ro[1] = lastv1; ro[2] = lastv2; ro[3] = lastv3;
@@ -868,7 +868,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
         for (int c = t; c < n; c += kThreads) sm[S::o_xs + c] = 0.0;
         __syncthreads();
     }
-    if (a.y_out) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
+    if (a.y_out && (!a.y_capped_only || status == 2)) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
         const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
         for (int i = t; i < m; i += kThreads)
             if (failed || sct[i / 5] == 0) a.y_out[(size_t)b * m + i] = 0.0;

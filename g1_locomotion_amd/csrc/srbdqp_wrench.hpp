@@ -1540,7 +1540,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         lane_roles(ln);
     }
     if (stepok) sm[S::o_xs + uvar] = (double)x;
-    if (a.y_out) {
+    if (a.y_out && (!a.y_capped_only || status == 2)) {
         TIO* yo = reinterpret_cast<TIO*>(a.y_out) + row0 * 20;
         if (stepok) {
             const bool on = active_u;
