@@ -865,7 +865,11 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
                 for (int k2 = 0; k2 < p; ++k2) d = fma(-Lm[p][k2], Lm[p][k2], d);
                 okE = okE && (d > 0.0);
-                const double inv = (d > 0.0) ? fast_rsqrt2(d) : 0.0;   // (okE reports a non-positive pivot)
+                // (okE reports a non-positive pivot.  rsq + two Newton steps only in the low-latency instantiation, where it shortens the chain; in the batch
+                // instantiations -- 168 registers, three workgroups interleaved -- the library 1 / sqrt was the faster one: N = 10 double support 15.2 against 14.5 M QP/s)
+                double inv;
+                if constexpr (XW > 0) inv = (d > 0.0) ? fast_rsqrt2(d) : 0.0;
+                else inv = 1.0 / sqrt(d);
                 Lm[p][p] = d * inv;
                 Li[p][p] = inv;
 #pragma unroll
@@ -1486,7 +1490,14 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const R ztA = fma(-mucA, fzt, xt), ztB = fma(-mu, fzt, -xt);
                 const R nuA = fma(rhoA, ztA - zA, yA), nuB = fma(rhoB, ztB - zB, yB);
                 const R zhA = fma(alpha, ztA, oma * zA), zhB = fma(alpha, ztB, oma * zB);
-                const R znA = rmin(rmax(fma(yA, (ax < 2) ? irho : irhoz, zhA), loA), hiA), znB = rmin(rmax(fma(yB, irho, zhB), loB), hiB);
+                R znA, znB;
+                if constexpr (VL) {   // (168 registers: the row classes as selects on scalar bounds -- eight registers of per-lane bounds less in the loop, which reloaded four values per iteration)
+                    const R vA = fma(yA, (ax < 2) ? irho : irhoz, zhA), vB = fma(yB, irho, zhB);
+                    znB = rowB ? rmin(vB, R(0)) : R(0);
+                    znA = rowA ? ((ax < 2) ? rmin(vA, R(0)) : rmin(rmax(vA, (R)a.fzmin_s), (R)a.fzmax_s)) : R(0);
+                } else {
+                    znA = rmin(rmax(fma(yA, (ax < 2) ? irho : irhoz, zhA), loA), hiA); znB = rmin(rmax(fma(yB, irho, zhB), loB), hiB);
+                }
                 yA = fma(rhoA, zhA - znA, yA); yB = fma(rhoB, zhB - znB, yB);
                 zA = znA; zB = znB;
                 axA = fma(alpha, ztA, oma * axA); axB = fma(alpha, ztB, oma * axB);
