@@ -26,6 +26,21 @@ __device__ __forceinline__ double dpp_swap2(double v) {   // value of lane ^ 2 (
     return __hiloint2double(hi, lo);
 }
 
+// value of the next / the previous lane of the WAVE (GFX9's whole-wave DPP shifts, which gfx950 still has: they cross the 16-lane rows; lane 63 / lane 0 read 0).
+// tools/wave_shift_probe.hip: 30 cycles for a dependent shift against 74 for a dependent ds_bpermute on an idle CU -- and no LDS pipeline to queue for.  The
+// three lanes of a contact are neighbours, so the f_z gather and the friction rows' sums of every ADMM iteration are one or two of these instead of a
+// ds_bpermute round trip each.
+__device__ __forceinline__ int wave_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }    // wave_shl:1
+__device__ __forceinline__ int wave_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }    // wave_shr:1
+__device__ __forceinline__ float wave_next(float v) { return __int_as_float(wave_next(__float_as_int(v))); }
+__device__ __forceinline__ float wave_prev(float v) { return __int_as_float(wave_prev(__float_as_int(v))); }
+__device__ __forceinline__ double wave_next(double v) { return __hiloint2double(wave_next(__double2hiint(v)), wave_next(__double2loint(v))); }
+__device__ __forceinline__ double wave_prev(double v) { return __hiloint2double(wave_prev(__double2hiint(v)), wave_prev(__double2loint(v))); }
+// f_z of the lane's contact (lanes base + {0, 1, 2} = fx, fy, fz; ax = lane - base)
+template <typename T> __device__ __forceinline__ T contact_fz(T v, int ax) { const T n1 = wave_next(v), n2 = wave_next(n1); return (ax == 0) ? n2 : ((ax == 1) ? n1 : v); }
+// (value of the fx lane) + (value of the fy lane), for the fz lane of the contact (other lanes: not used)
+template <typename T> __device__ __forceinline__ T contact_sum_xy(T v) { const T p1 = wave_prev(v), p2 = wave_prev(p1); return p2 + p1; }
+
 __device__ __forceinline__ double bperm_f64(double v, int src_lane) {   // value of lane src_lane
     const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));

@@ -63,8 +63,8 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
     // A'(wA, wB) for the variable of this lane; (A v)_slot for the two slots
     auto At = [&](double wA, double wB) -> double {
         const double ssum = wA + wB;
-        const double s01 = bperm_f64(ssum, base), s23 = bperm_f64(ssum, base + 1);
-        return (ax < 2) ? wA - wB : fma(-mu, s01 + s23, wA);
+        const double sxy = contact_sum_xy(ssum);                     // (outside the select: a cross-lane read must run with the source lanes enabled)
+        return (ax < 2) ? wA - wB : fma(-mu, sxy, wA);
     };
 
     int status = -1, iters = 0;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
         double cpx = active ? sm[S::o_px0 + lane] : 0.0, spxA = 0.0, spxB = 0.0;
         double yA = (rowA && a.warm_y) ? a.warm_y[(size_t)b * m + irowA] : 0.0;
         double yB = (rowB && a.warm_y) ? a.warm_y[(size_t)b * m + irowB] : 0.0;
-        const double fz0 = bperm_f64(x, base + 2);
+        const double fz0 = contact_fz(x, ax);
         double axA = rowA ? fma(-mucA, fz0, x) : 0.0, axB = rowB ? fma(-mu, fz0, -x) : 0.0;     // (A x)_slot by recursion
         double zA = fmin(fmax(axA, loA), hiA), zB = fmin(fmax(axB, loB), hiB);
         const float qnf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg((float)fabs(qv))), 63));
@@ -109,7 +109,7 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
             }
             const double acc0 = acc4[0], acc1 = acc4[1], acc2 = acc4[2], acc3 = acc4[3];
             const double xt = (acc0 + acc1) + (acc2 + acc3);
-            const double fzt = bperm_f64(xt, base + 2);
+            const double fzt = contact_fz(xt, ax);
             const double ztA = fma(-mucA, fzt, xt), ztB = fma(-mu, fzt, -xt);
             // rows (two slots), relaxation, projection, dual update
             const double nuA = fma(rhoA, ztA - zA, yA), nuB = fma(rhoB, ztB - zB, yB);

@@ -1411,14 +1411,14 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const R mucA = (ax < 2) ? mu : R(0);
         auto At = [&](R wA, R wB) -> R {
             const R ssum = wA + wB;
-            const R s01 = bperm(ssum, cbase), s23 = bperm(ssum, cbase + 1);
-            return (ax < 2) ? wA - wB : fma(-mu, s01 + s23, wA);
+            const R sxy = contact_sum_xy(ssum);                       // (the lanes of a contact are neighbours: wave shifts, srbdqp_admm.hpp; outside the select:
+            return (ax < 2) ? wA - wB : fma(-mu, sxy, wA);            //  a cross-lane read must run with the source lanes enabled)
         };
         x = (R)x_init;
         R cpx = (R)(px0 + qv), spxA = R(0), spxB = R(0);             // c = P x + q = cpx - A' spx
         yA = (rowA && a.warm_y) ? (R)gwy[irowA] : R(0);
         yB = (rowB && a.warm_y) ? (R)gwy[irowB] : R(0);
-        const R fz0 = bperm(x, cbase + 2);
+        const R fz0 = contact_fz(x, ax);
         R axA = rowA ? fma(-mucA, fz0, x) : R(0), axB = rowB ? fma(-mu, fz0, -x) : R(0);
         R zA = rmin(rmax(axA, loA), hiA), zB = rmin(rmax(axB, loB), hiB);
         const float qnf = uni((float)wg_max1<NWS>(fabs(qv), sm + S::o_red + 24));
@@ -1463,7 +1463,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             const bool check = ((ph == 0) && vote_ok) || (k == a.max_iter);
             const bool pretest = (ph == a.check_every - 1);
             const R xt = active_u ? xqr + kw : R(0);
-            const R fzt = bperm(xt, cbase + 2);
+            const R fzt = contact_fz(xt, ax);
             WADMM_T(5);
             R atw;
             if constexpr (sizeof(R) == 4) {
