@@ -41,6 +41,25 @@ template <typename T> __device__ __forceinline__ T contact_fz(T v, int ax) { con
 // (value of the fx lane) + (value of the fy lane), for the fz lane of the contact (other lanes: not used)
 template <typename T> __device__ __forceinline__ T contact_sum_xy(T v) { const T p1 = wave_prev(v), p2 = wave_prev(p1); return p2 + p1; }
 
+// The four 16-lane rows of a register, each broadcast to all four rows: ch[c] of lane l = v of lane 16 c + (l & 15).  gfx950's row swaps
+// (v_permlane32_swap: rows 2, 3 of the first operand <-> rows 0, 1 of the second; v_permlane16_swap: odd rows of the first <-> even rows of the second) on
+// copies of the value: [R0 R1 R0 R1], [R2 R3 R2 R3], then [R0 x 4], [R1 x 4], [R2 x 4], [R3 x 4] -- three swaps and no LDS operation per dword, against
+// four ds_bpermute (tools/permlane_probe.hip: 96 against 112 cycles for a dependent round on an idle CU; the LDS pipeline of a CU with 8 resident QPs is the busier one).
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void row_chunks(int v, int (&ch)[4]) {
+    const v2u_t ab = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    const v2u_t p = __builtin_amdgcn_permlane16_swap(ab[0], ab[0], false, false);
+    const v2u_t q = __builtin_amdgcn_permlane16_swap(ab[1], ab[1], false, false);
+    ch[0] = (int)p[0]; ch[1] = (int)p[1]; ch[2] = (int)q[0]; ch[3] = (int)q[1];
+}
+__device__ __forceinline__ void row_chunks(double v, double (&ch)[4]) {
+    int lo[4], hi[4];
+    row_chunks(__double2loint(v), lo);
+    row_chunks(__double2hiint(v), hi);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ch[c] = __hiloint2double(hi[c], lo[c]);
+}
+
 __device__ __forceinline__ double bperm_f64(double v, int src_lane) {   // value of lane src_lane
     const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));

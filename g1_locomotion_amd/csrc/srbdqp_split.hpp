@@ -98,14 +98,12 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
             {
                 constexpr int NCH = (KS + 15) / 16;
                 static_assert(NCH <= 4, "one K^-1 row per lane of one wave");
-                double ch[NCH];
-                const int li = lane & 15;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) ch[c] = bperm_f64(rhs, 16 * c + li);
+                double ch[4];
+                row_chunks(rhs, ch);
                 RowBcastChunk<KS, 0>::run(acc4, ch[0], kin);
-                if constexpr (NCH > 1) RowBcastChunk<KS, 1>::run(acc4, ch[NCH > 1 ? 1 : 0], kin);
-                if constexpr (NCH > 2) RowBcastChunk<KS, 2>::run(acc4, ch[NCH > 2 ? 2 : 0], kin);
-                if constexpr (NCH > 3) RowBcastChunk<KS, 3>::run(acc4, ch[NCH > 3 ? 3 : 0], kin);
+                if constexpr (NCH > 1) RowBcastChunk<KS, 1>::run(acc4, ch[1], kin);
+                if constexpr (NCH > 2) RowBcastChunk<KS, 2>::run(acc4, ch[2], kin);
+                if constexpr (NCH > 3) RowBcastChunk<KS, 3>::run(acc4, ch[3], kin);
             }
             const double acc0 = acc4[0], acc1 = acc4[1], acc2 = acc4[2], acc3 = acc4[3];
             const double xt = (acc0 + acc1) + (acc2 + acc3);
