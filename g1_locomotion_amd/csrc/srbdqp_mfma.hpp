@@ -85,7 +85,7 @@ __device__ __forceinline__ double fast_rsqrt2(double d) {
 // UPPER factor U = L', register kb is at once the A operand (A[i][k] = L[i][4kb+k]) and the B operand
 // (B[k][j] = U[4kb+k][j]) of the rank-4 products, so per block the work is
 //   - 10 v_readlane pairs broadcast the 4x4 diagonal block; every lane factors it and inverts the factor (4 rsqrt),
-//   - U_kb = L_kk^-1 S_kb              one MFMA (L_kk^-1 embedded in rows 4kb..4kb+3 of the A operand),
+//   - U_kb = L_kk^-1 S_kb              one MFMA (L_kk^-1 repeated in every row block of the A operand; accumulator register kb is the result),
 //   - S   -= U_kb' U_kb                one MFMA (trailing update of the whole tile),
 //   - W_kb = L_kk^-1 R_kb, R -= L[:,kb] W_kb   two MFMAs (block forward substitution L W = I riding along),
 // 14 MFMAs and ~350 other instructions per tile (a row-by-row LDL' elimination with v_readlane broadcasts, the first
@@ -124,7 +124,7 @@ __device__ __forceinline__ void diag16_block(v4d& s, v4d& rr, v4d& w, double& pm
     const double c2 = (k == 0) ? x02 : (k == 1) ? x12 : x22;            // li = 2
     const double c3 = (k == 0) ? x03 : (k == 1) ? x13 : (k == 2) ? x23 : x33;
     double a = (li == 0) ? c0 : (li == 1) ? c1 : (li == 2) ? c2 : c3;
-    a = ((col >> 2) == KB && k <= li) ? a : 0.0;
+    a = (k <= li) ? a : 0.0;   // (the same 4 x 4 block in every row block of the operand: only accumulator register KB -- rows 4 KB .. 4 KB + 3 -- of the two products is read)
     const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
     double u = mfma_f64(a, sk, zero)[KB];                               // U_kb = L_kk^-1 S_kb
     u = (col >= 4 * KB) ? u : 0.0;                                      // columns left of the block: exact zeros
