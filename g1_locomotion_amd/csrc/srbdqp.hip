@@ -169,6 +169,7 @@ constexpr int kSplitMinBatch = 512;
 // mixed gait 13.9 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
 constexpr int kWrenchMinBatch = 768;      // re-measured at the end of round 2 (mixed gait, N = 10): 512 QPs 4.43 M QP/s compact / 4.17 M general,
                                           // 1024 QPs 6.12 M / 7.57 M -- up to two QPs per CU the 4-wave kernel's shorter set-up wins
+constexpr int kTail1MaxBatch = 8;              // staged calls of up to this many QPs on <= 2 stance contacts per step: the 4-wave set-up + one-wave iteration kernel
 constexpr int kStagedWrenchMinVars = 60;   // staged call: presolved variables (3 per stance contact) above which the wrench-space kernel's low-latency
                                           // instantiation wins (B = 1, N = 10: mixed gait, 72 variables, 74 us compact / 69 us; double support, 120, 107 / 69)
 constexpr int kWrenchMinBatchN20 = 256;   // N = 20: one workgroup per CU on the compact kernel, two on the general one
@@ -308,6 +309,18 @@ int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
         if (rc != SRBDQP_OK) return rc;
         hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, false, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), lds, st, a);
         return SRBDQP_OK;
+    }
+    if constexpr (MAXS == 2 && srbdqp::SplitWs<N, MAXS>::supported) {
+        // staged batch-1 path (completion word): four waves for the set-up, then the one-wave iteration on wave 0 (srbdqp_compact.hpp, TAIL1) --
+        // compiled for one workgroup's worth of registers.  tools/latency_patterns.py, tools/batch1_kernel_probe.py
+        if (a.done_flag && a.B <= kTail1MaxBatch && !(h->cfg.flags & SRBDQP_FLAG_NO_LAT)) {
+            int rc1 = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, false, false, true>, lds);
+            if (rc1 != SRBDQP_OK) return rc1;
+            static const std::string nml = nm + "_lat";
+            h->kname = nml.c_str();
+            hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, false, false, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), lds, st, a);
+            return SRBDQP_OK;
+        }
     }
     int rc = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS>, lds);
     if (rc != SRBDQP_OK) return rc;

@@ -342,7 +342,15 @@ __device__ __forceinline__ void dump_presolved(const KArgs& a, int b, int n_eff,
 
 // One QP (index b) on one 256-thread workgroup; sm = the workgroup's dynamic LDS (CompactSmem<N, MAXS>::bytes).
 // Every exit is workgroup-uniform and leaves no state in LDS that a later call would rely on.
-template <int N, int MAXS, bool SPLIT = false, bool DUMP = false>
+template <int N, int MAXS> struct SplitWs;
+template <int N, int MAXS>
+__device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS],
+                                                     double* xs_full, int& status_out, int& iters_out);   // srbdqp_split.hpp
+
+// TAIL1 (the staged batch-1 instantiation, compiled for one workgroup's worth of registers): the four waves set the problem up, then wave 0 alone runs the
+// one-wave iteration (a K^-1 row per lane, no LDS operation and no barrier in the loop: 0.36 us per iteration against 0.52 for the 4-wave loop at batch 1,
+// tools/batch1_kernel_probe.py) while the others wait at the barrier in front of the roll-out, which all four share again.
+template <int N, int MAXS, bool SPLIT = false, bool DUMP = false, bool TAIL1 = false>
 __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* sm) {
     using S = CompactSmem<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m;
@@ -837,6 +845,55 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
         return;
     } else {
 
+    if constexpr (TAIL1) {
+        using W1 = SplitWs<N, MAXS>;
+        constexpr int KS1 = W1::KS;
+        double kin1[KS1];
+        if (w == 0) {   // the K^-1 row of lane's variable, whole
+            const bool rowok = lane < n_eff;
+            const int rr = rowok ? lane : 0;
+#pragma unroll
+            for (int c = 0; c < KS1; ++c) {
+                const bool ok = rowok && (c < n_eff);
+                const int cs = ok ? c : 0;
+                const int lo = (rr <= cs) ? rr : cs, hi = (rr <= cs) ? cs : rr;
+                const int row = lo & 15, col = hi & 15;
+                const double v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
+                kin1[c] = ok ? v : 0.0;
+            }
+        }
+        const bool failed = sm[S::o_misc] != 0.0;
+        __syncthreads();   // tiles are dead; region R becomes the solution vector and the roll-out's scratch
+        SRBDQP_STAMP(a, b, 9);
+        int status = -1, iters = 0;
+        int* fin = reinterpret_cast<int*>(sm + S::o_red);
+        if (!failed) {
+            if (w == 0) {
+                admm_wave_iterations<N, MAXS>(a, b, rho_b, sm, kin1, sm + S::o_xs, status, iters);
+                if (lane == 0) { fin[0] = status; fin[1] = iters; }
+            }
+            __syncthreads();
+            status = fin[0]; iters = fin[1];
+        } else {
+            for (int c = t; c < n; c += kThreads) sm[S::o_xs + c] = 0.0;
+            __syncthreads();
+        }
+        if (a.y_out && (!a.y_capped_only || status == 2)) {
+            const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
+            for (int i = t; i < m; i += kThreads)
+                if (failed || sct[i / 5] == 0) a.y_out[(size_t)b * m + i] = 0.0;
+        }
+        if (t == 0) {
+            if (a.status) a.status[b] = status;
+            if (a.iters) a.iters[b] = iters + a.iters_base;
+        }
+        SRBDQP_STAMP(a, b, 10);
+        rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+        signal_done(a);
+        SRBDQP_STAMP(a, b, 11);
+        if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();
+        return;
+    }
     // K^-1 row fragments in the compact contact-local mapping
     constexpr int LPR = S::LPR;
     const int CH = 2 * ((n_eff + 2 * LPR - 1) / (2 * LPR));
@@ -887,8 +944,8 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
     }   // !SPLIT
 }
 
-template <int N, int MAXS, bool SPLIT = false, bool DUMP = false>
-__global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) void srbdqp_compact_kernel(KArgs a) {
+template <int N, int MAXS, bool SPLIT = false, bool DUMP = false, bool TAIL1 = false>
+__global__ __launch_bounds__(kThreads, (TAIL1 ? 1 : CompactSmem<N, MAXS>::waves_per_simd)) void srbdqp_compact_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if ((int)blockIdx.x >= a.B) return;
     const int b = SRBDQP_QP_INDEX(a);
@@ -896,7 +953,7 @@ __global__ __launch_bounds__(kThreads, (CompactSmem<N, MAXS>::waves_per_simd)) v
         signal_done(a);
         return;
     }
-    compact_qp<N, MAXS, SPLIT, DUMP>(a, b, sm);
+    compact_qp<N, MAXS, SPLIT, DUMP, TAIL1>(a, b, sm);
 }
 
 template <int N, int MAXS>

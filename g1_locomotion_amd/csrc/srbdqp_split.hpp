@@ -26,18 +26,17 @@ struct SplitSmem {
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
 };
 
-// ADMM iterations + roll-out of one QP on one wave.  sm: the persistent strip at [0, S::o_R) and SplitSmem's vectors behind
-// it; kin: the K^-1 row of this lane (zeros for lanes >= n_eff).
+// The ADMM iterations of one QP on ONE wave (wave-local: no barrier inside; the caller's waves other than this one may wait at one).  sm: the persistent
+// strip at [0, S::o_R); kin: the K^-1 row of this lane (zeros for lanes >= n_eff); xs_full: n doubles that receive the solution in the full variable order
+// (zeros elsewhere).  Used by the one-wave kernels and by the 4-wave kernel's batch-1 instantiation (srbdqp_compact.hpp, TAIL1).
 template <int N, int MAXS>
-__device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS]) {
+__device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS],
+                                                     double* xs_full, int& status_out, int& iters_out) {
     using S = CompactSmem<N, MAXS>;
     using W = SplitWs<N, MAXS>;
-    using L = SplitSmem<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m, KS = W::KS;
-    const int lane = threadIdx.x;
-    double* xs_full = sm + L::o_xs;
-    for (int i = lane; i < n; i += 64) xs_full[i] = 0.0;
-    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < n; i += 64) xs_full[i] = 0.0;                 // (one wave: its LDS operations complete in order)
     const int* icnt = reinterpret_cast<const int*>(sm + S::o_int);
     const int* imisc = icnt + 2 * N;
     const uint8_t* act = reinterpret_cast<const uint8_t*>(imisc + 8);
@@ -152,13 +151,27 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
         }
         if (status < 0) { x = 0.0; yA = 0.0; yB = 0.0; }                    // a numerical failure returns zero forces, never NaN
         if (active) xs_full[3 * gc + ax] = x;
-        if (a.y_out) {
+        if (a.y_out && (!a.y_capped_only || status == 2)) {
             if (rowA) a.y_out[(size_t)b * m + irowA] = yA;
             if (rowB) a.y_out[(size_t)b * m + irowB] = yB;
         }
     }
+    status_out = status; iters_out = iters;
+}
+
+// ADMM iterations + roll-out of one QP on one wave (the one-wave kernels).  sm: the persistent strip at [0, S::o_R) and SplitSmem's vectors behind it.
+template <int N, int MAXS>
+__device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS]) {
+    using S = CompactSmem<N, MAXS>;
+    using L = SplitSmem<N, MAXS>;
+    constexpr int m = Dims<N>::m;
+    const int lane = threadIdx.x;
+    double* xs_full = sm + L::o_xs;
+    const bool failed = sm[S::o_misc] != 0.0;
+    int status = -1, iters = 0;
+    admm_wave_iterations<N, MAXS>(a, b, rho_b, sm, kin, xs_full, status, iters);
     __syncthreads();
-    if (a.y_out) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
+    if (a.y_out && (!a.y_capped_only || status == 2)) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
         const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
         for (int i = lane; i < m; i += 64)
             if (failed || sct[i / 5] == 0) a.y_out[(size_t)b * m + i] = 0.0;
