@@ -314,11 +314,13 @@ int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
         // staged batch-1 path (completion word): four waves for the set-up, then the one-wave iteration on wave 0 (srbdqp_compact.hpp, TAIL1) --
         // compiled for one workgroup's worth of registers.  tools/latency_patterns.py, tools/batch1_kernel_probe.py
         if (a.done_flag && a.B <= kTail1MaxBatch && !(h->cfg.flags & SRBDQP_FLAG_NO_LAT)) {
-            int rc1 = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, false, false, true>, lds);
+            constexpr size_t lds1 = srbdqp::CompactTraits<N, MAXS>::lds_bytes_tail1;
+            static_assert(lds1 <= 163840 && srbdqp::SplitWs<N, MAXS>::KS <= 64, "TAIL1: K^-1 rows behind the kernel's own LDS");
+            int rc1 = set_lds_once(h, &srbdqp::srbdqp_compact_kernel<N, MAXS, false, false, true>, lds1);
             if (rc1 != SRBDQP_OK) return rc1;
             static const std::string nml = nm + "_lat";
             h->kname = nml.c_str();
-            hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, false, false, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), lds, st, a);
+            hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, false, false, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), lds1, st, a);
             return SRBDQP_OK;
         }
     }

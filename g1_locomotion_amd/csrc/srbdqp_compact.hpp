@@ -848,22 +848,35 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
     if constexpr (TAIL1) {
         using W1 = SplitWs<N, MAXS>;
         constexpr int KS1 = W1::KS;
-        double kin1[KS1];
-        if (w == 0) {   // the K^-1 row of lane's variable, whole
+        // K^-1 from the swizzled upper-triangular tile store to plain rows behind the kernel's own LDS (KS1 x (KS1 + 2) doubles, part of the launch's dynamic
+        // size): every wave moves 16 columns of every row, then wave 0 reads its lanes' rows with 16-byte loads.  (One wave pulling 64 entries per lane through
+        // the tile indexing took 5.1 k cycles of a 98 k-cycle solve.)
+        constexpr int RS1 = KS1 + 2;
+        static_assert(KS1 % 4 == 0 && KS1 <= 64, "TAIL1: a quarter of the columns per wave, one row per lane");
+        double* full = sm + S::o_end;
+        {
             const bool rowok = lane < n_eff;
             const int rr = rowok ? lane : 0;
+            constexpr int CW = KS1 / 4;                                 // columns per wave
 #pragma unroll
-            for (int c = 0; c < KS1; ++c) {
+            for (int cc = 0; cc < CW; ++cc) {
+                const int c = CW * w + cc;
                 const bool ok = rowok && (c < n_eff);
                 const int cs = ok ? c : 0;
                 const int lo = (rr <= cs) ? rr : cs, hi = (rr <= cs) ? cs : rr;
                 const int row = lo & 15, col = hi & 15;
                 const double v = T[tile_id(lo >> 4, hi >> 4) * 256 + row * 16 + (col ^ row)];
-                kin1[c] = ok ? v : 0.0;
+                full[lane * RS1 + c] = ok ? v : 0.0;
             }
         }
         const bool failed = sm[S::o_misc] != 0.0;
         __syncthreads();   // tiles are dead; region R becomes the solution vector and the roll-out's scratch
+        double kin1[KS1];
+        if (w == 0) {
+            const double2* src = reinterpret_cast<const double2*>(full + lane * RS1);
+#pragma unroll
+            for (int c = 0; c < KS1 / 2; ++c) { const double2 v = src[c]; kin1[2 * c] = v.x; kin1[2 * c + 1] = v.y; }
+        }
         SRBDQP_STAMP(a, b, 9);
         int status = -1, iters = 0;
         int* fin = reinterpret_cast<int*>(sm + S::o_red);
@@ -960,6 +973,7 @@ template <int N, int MAXS>
 struct CompactTraits {
     static constexpr bool supported = (3 * MAXS * N <= 128);
     static constexpr size_t lds_bytes = CompactSmem<N, MAXS>::bytes;
+    static constexpr size_t lds_bytes_tail1 = lds_bytes + (size_t)64 * 66 * sizeof(double);   // + K^-1 as plain rows (TAIL1)
 };
 
 }  // namespace srbdqp
