@@ -462,6 +462,35 @@ def test_two_phase_call_equals_the_one_shot_call(torch_first, built_lib, N, sche
         assert status[b] == o["status"] and np.abs(u[b] - o["u"]).max() <= TOL_TWIN_N
 
 
+@pytest.mark.parametrize("N,schedule,suffix", [(10, "single", "compact_f64_n10_s2_lat"), (8, "single", "compact_f64_n8_s2_lat"), (4, "single", "compact_f64_n4_s2_lat"),
+                                               (10, "double", "wrench_f64_n10_lat"), (10, "mixed", "wrench_f64_n10_lat"), (8, "double", "wrench_f64_n8_lat")])
+def test_staged_batch1_low_latency_instantiations(torch_first, built_lib, N, schedule, suffix):
+    """The staged call (what MPC.update() uses) one QP at a time: <= 2 stance contacts per step run the 4-wave set-up + one-wave iteration kernel, anything
+    else the low-latency instantiation of the general kernel (the reference's own call pattern is full double support, run_simulation.py:100-101).  Each QP
+    against the oracle twin (status, iterations, forces, predicted states) and against the batch kernels on the same inputs; SRBDQP_FLAG_NO_LAT switches both
+    instantiations off."""
+    from g1_locomotion_amd import BatchMPC, _lib
+    B = 12
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=4200 + N, schedule=schedule)
+    p = orc.params_for(N)
+    with BatchMPC(horizon=N, rho_restart_iter=-1) as eng, BatchMPC(horizon=N, rho_restart_iter=-1, flags=_lib.FLAG_NO_LAT) as plain:
+        batch = eng.solve(x0, xr, ft, ct)
+        st, st2 = eng.stage(), plain.stage()
+        for b in range(B):
+            for s_ in (st, st2):
+                s_["x0"][0] = x0[b]; s_["x_ref"][0] = xr[b]; s_["foot"][0] = ft[b].reshape(N, 12); s_["contact"][0] = ct[b].reshape(N, 4)
+            eng.solve_staged(1, want_x=True)
+            plain.solve_staged(1, want_x=True)
+            assert eng.kernel_name() == suffix, eng.kernel_name()
+            assert not plain.kernel_name().endswith("_lat"), plain.kernel_name()
+            o = orc.update(p, x0[b], xr[b], ft[b], ct[b])
+            assert int(st["status"][0]) == o["status"] == int(st2["status"][0]) == int(batch["status"][b])
+            assert abs(int(st["iters"][0]) - o["iters"]) <= p.check_every and abs(int(st2["iters"][0]) - o["iters"]) <= p.check_every
+            assert np.abs(st["u"][0] - o["u"]).max() <= TOL_TWIN_N and np.abs(st["x"][0] - o["x"]).max() <= 1e-4
+            assert np.abs(st["u"][0] - st2["u"][0]).max() <= TOL_TWIN_N and np.abs(st["u"][0] - batch["u"][b]).max() <= TOL_TWIN_N
+            assert (st["u"][0].reshape(N, 4, 3)[ct[b].reshape(N, 4) == 0] == 0.0).all()           # swing contacts: exactly zero
+
+
 def test_two_phase_call_limits_and_pcom(torch_first, built_lib):
     """Outside its instantiations (more than 64 presolved variables) the two-phase call refuses loudly; with a CoM horizon
     (use_pcom) it still equals the one-shot call."""
