@@ -292,6 +292,19 @@ int launch_wave(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     return SRBDQP_OK;
 }
 
+// one staged QP whose inputs still sit in the library's own staging arrays: they ride in the kernel-argument segment (srbdqp_common.hpp StagedIn)
+template <int N>
+bool staged_inline_inputs(const srbdqp_handle* h, const KArgs& a, srbdqp::StagedIn<N>& in) {
+    if (!(h->staged_call && a.B == 1 && a.x0 == h->stage_d.x0 && a.xref == h->stage_d.x_ref && a.foot == h->stage_d.foot && a.contact == h->stage_d.contact) ||
+        a.perm || a.row_off || a.resid_in || (a.pcom && a.pcom != h->stage_d.pcom)) return false;
+    std::memcpy(in.x0, h->stage_h.x0, sizeof(in.x0));
+    std::memcpy(in.xref, h->stage_h.x_ref, sizeof(in.xref));
+    std::memcpy(in.foot, h->stage_h.foot, sizeof(in.foot));
+    std::memcpy(in.contact, h->stage_h.contact, sizeof(in.contact));
+    if (a.pcom) std::memcpy(in.pcom, h->stage_h.pcom, sizeof(in.pcom));
+    return true;
+}
+
 template <int N, int MAXS>
 int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     if constexpr (srbdqp::Setup1Smem<N, MAXS>::supported) {
@@ -320,6 +333,15 @@ int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
             if (rc1 != SRBDQP_OK) return rc1;
             static const std::string nml = nm + "_lat";
             h->kname = nml.c_str();
+            srbdqp::StagedIn<N> in;
+            if (!a.count_ptr && staged_inline_inputs<N>(h, a, in)) {
+                rc1 = set_lds_once(h, &srbdqp::srbdqp_compact_kernel_in<N, MAXS>, lds1);
+                if (rc1 != SRBDQP_OK) return rc1;
+                KArgs ai = a;
+                ai.inline_in = 1;
+                hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel_in<N, MAXS>), dim3(1), dim3(srbdqp::kThreads), lds1, st, ai, in);
+                return SRBDQP_OK;
+            }
             hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel<N, MAXS, false, false, true>), dim3((unsigned)a.B), dim3(srbdqp::kThreads), lds1, st, a);
             return SRBDQP_OK;
         }
@@ -387,6 +409,18 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
                 if (rcl != SRBDQP_OK) return rcl;
                 static const std::string nml = nm + "_lat";
                 h->kname = nml.c_str();
+                if constexpr (std::is_same<TIO, double>::value) {
+                    srbdqp::StagedIn<N> in;
+                    if (!a.count_ptr && !a.tile_sel && staged_inline_inputs<N>(h, a, in)) {
+                        rcl = set_lds_once(h, &srbdqp::srbdqp_wrench_kernel_in<N, XW>, ldsl);
+                        if (rcl != SRBDQP_OK) return rcl;
+                        KArgs ai = a;
+                        ai.inline_in = 1;
+                        hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel_in<N, XW>), dim3(1), dim3(SL::BT), ldsl, st, ai, in);
+                        HIP_TRY(h, hipGetLastError());
+                        return SRBDQP_OK;
+                    }
+                }
                 hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel<N, R, TIO, 0, 1, double, 5, XW>), dim3((unsigned)a.B), dim3(SL::BT), ldsl, st, a);
                 HIP_TRY(h, hipGetLastError());
                 return SRBDQP_OK;

@@ -7,6 +7,7 @@
 // The reference implementation of these steps is the absent submodule g1_mpc (see oracle/srbd_oracle.py header);
 // the conventions come from its call sites g1_mujoco_sim/src/run_simulation.py:73-111.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -51,6 +52,7 @@ struct KArgs {
                              //   that ends at the cap, or null
     const int32_t* count_ptr;   // second pass: number of valid entries of perm[]; workgroups beyond it exit at once
     int32_t iters_base;      // second pass: iterations of the first pass, added to iters[] on output
+    int32_t inline_in;       // the *_in kernels: the inputs of the one staged QP follow KArgs in the kernel-argument segment (StagedIn, below)
     int32_t y_capped_only;   // first pass, y_out = the engine's own buffer (the caller asked for no duals): only a QP that ends at the cap stores them
                              //   (20 N values per QP for every QP was a quarter of the HBM traffic of a configs[2] solve)
     int32_t qp_span;         // host only: number of QP slots the per-QP workspaces must hold (second pass: original B)
@@ -66,6 +68,27 @@ struct KArgs {
     double rho, rho_eq, sigma, alpha, eps_abs, eps_rel;
     double rho_fz;           // penalty of a stance contact's normal-force row relative to rho (srbdqp_config.rho_fz_scale, resolved)
 };
+
+// The inputs of ONE staged QP passed by value behind KArgs (the batch-1 kernels): the kernel-argument segment is fast memory for the GPU -- a first-touch read
+// costs ~430 cycles there against ~2900 from the GPU-mapped pinned staging arrays (tools/kernarg_probe.hip) --, and the runtime copies the 2.4 KB at launch for
+// less than the round trip it saves.  The input stage of the kernel reads from its own argument segment then (staged_in_base()).
+template <int N>
+struct StagedIn {
+    double x0[13];
+    double xref[13 * N];
+    double foot[12 * N];
+    double pcom[3 * N];
+    uint8_t contact[4 * N];
+    uint8_t pad[(8 - (4 * N) % 8) % 8];
+};
+// base of the StagedIn behind KArgs in this kernel's argument segment, or null (KArgs::inline_in: set by the host for the *_in kernels only).  No copy of KArgs
+// is made for this: a modified copy passed on by reference lands on the stack (496 bytes of scratch per lane, every field access a scratch load: +8 us per call).
+template <int N>
+__device__ __forceinline__ const char* staged_in_base(const KArgs& a) {
+    static_assert(sizeof(KArgs) % 8 == 0, "StagedIn follows KArgs without padding");
+    if constexpr (sizeof(KArgs) + sizeof(StagedIn<N>) > 4096) return nullptr;        // (the long horizons have no *_in kernel: the segment holds 4 KB)
+    else return a.inline_in ? (const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(KArgs) : nullptr;
+}
 
 // QP index of this workgroup
 #define SRBDQP_QP_INDEX(a) ((a).perm ? (a).perm[blockIdx.x] : (int)blockIdx.x)
@@ -172,17 +195,18 @@ template <int N, class L>
 __device__ void load_and_linearise(const KArgs& a, int b, double* sm) {
     using S = L;
     const int t = threadIdx.x;
-    const double* gx0 = a.x0 + (size_t)b * 13;
-    const double* gxr = a.xref + (size_t)b * N * 13;
-    const double* gft = a.foot + (size_t)b * N * 12;
-    const uint8_t* gct = a.contact + (size_t)b * N * 4;
+    const char* kin_ = staged_in_base<N>(a);
+    const double* gx0 = kin_ ? reinterpret_cast<const double*>(kin_ + offsetof(StagedIn<N>, x0)) : a.x0 + (size_t)b * 13;
+    const double* gxr = kin_ ? reinterpret_cast<const double*>(kin_ + offsetof(StagedIn<N>, xref)) : a.xref + (size_t)b * N * 13;
+    const double* gft = kin_ ? reinterpret_cast<const double*>(kin_ + offsetof(StagedIn<N>, foot)) : a.foot + (size_t)b * N * 12;
+    const uint8_t* gct = kin_ ? reinterpret_cast<const uint8_t*>(kin_ + offsetof(StagedIn<N>, contact)) : a.contact + (size_t)b * N * 4;
     uint8_t* sct = reinterpret_cast<uint8_t*>(sm + S::o_ct);
     // Every global load is issued before the first LDS store, branch-free (clamped indices), so that they travel as
     // ONE batch: on the staged batch-1 path the inputs sit in GPU-mapped host memory and each dependent round is a PCIe
     // round trip of 1.2 us (tools/pcie_probe.hip) -- five conditional load -> store blocks cost five of them.
     constexpr int RX = (N * 13 + kThreads - 1) / kThreads, RF = (N * 12 + kThreads - 1) / kThreads;
     static_assert(N * 4 <= kThreads, "one thread per contact flag");
-    const double* gpc = a.pcom ? a.pcom + (size_t)b * N * 3 : gx0;          // !pcom: a valid address, value unused
+    const double* gpc = a.pcom ? (kin_ ? reinterpret_cast<const double*>(kin_ + offsetof(StagedIn<N>, pcom)) : a.pcom + (size_t)b * N * 3) : gx0;   // !pcom: a valid address, value unused
     const double v_x0 = gx0[t < 13 ? t : 0];
     const uint8_t v_ct = gct[t < N * 4 ? t : 0];
     const double v_pc = gpc[(a.pcom && t < N * 3) ? t : 0];

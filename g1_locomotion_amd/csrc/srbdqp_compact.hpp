@@ -969,6 +969,14 @@ __global__ __launch_bounds__(kThreads, (TAIL1 ? 1 : CompactSmem<N, MAXS>::waves_
     compact_qp<N, MAXS, SPLIT, DUMP, TAIL1>(a, b, sm);
 }
 
+// ... the batch-1 instantiation with the QP's inputs in the kernel-argument segment (StagedIn, srbdqp_common.hpp)
+template <int N, int MAXS>
+__global__ __launch_bounds__(kThreads, 1) void srbdqp_compact_kernel_in(KArgs a, StagedIn<N> in) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    (void)in;                                            // (read through staged_in_base(): a.inline_in is set)
+    compact_qp<N, MAXS, false, false, true>(a, 0, sm);
+}
+
 template <int N, int MAXS>
 struct CompactTraits {
     static constexpr bool supported = (3 * MAXS * N <= 128);

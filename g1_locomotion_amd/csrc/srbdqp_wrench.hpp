@@ -428,13 +428,14 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // ================= load (coalesced, one batch of loads) + linearise (a5) =================
     SRBDQP_STAMP(a, b, 0);
     {
-        const TIO* gx0 = reinterpret_cast<const TIO*>(a.x0) + (size_t)b * 13;
-        const TIO* gxr = reinterpret_cast<const TIO*>(a.xref) + row0 * 13;
-        const TIO* gft = reinterpret_cast<const TIO*>(a.foot) + row0 * 12;
-        const uint8_t* gct = a.contact + row0 * 4;
+        const char* kin_ = (sizeof(TIO) == 8) ? staged_in_base<N>(a) : nullptr;     // (one staged QP: its inputs in the kernel-argument segment)
+        const TIO* gx0 = kin_ ? reinterpret_cast<const TIO*>(kin_ + offsetof(StagedIn<N>, x0)) : reinterpret_cast<const TIO*>(a.x0) + (size_t)b * 13;
+        const TIO* gxr = kin_ ? reinterpret_cast<const TIO*>(kin_ + offsetof(StagedIn<N>, xref)) : reinterpret_cast<const TIO*>(a.xref) + row0 * 13;
+        const TIO* gft = kin_ ? reinterpret_cast<const TIO*>(kin_ + offsetof(StagedIn<N>, foot)) : reinterpret_cast<const TIO*>(a.foot) + row0 * 12;
+        const uint8_t* gct = kin_ ? reinterpret_cast<const uint8_t*>(kin_ + offsetof(StagedIn<N>, contact)) : a.contact + row0 * 4;
         constexpr int RX = (N * 13 + BT - 1) / BT, RF = (N * 12 + BT - 1) / BT;
         static_assert(N * 4 <= BT && N * 3 <= BT, "one thread per contact flag / pcom entry");
-        const TIO* gpc = a.pcom ? reinterpret_cast<const TIO*>(a.pcom) + (size_t)b * N * 3 : gx0;
+        const TIO* gpc = a.pcom ? (kin_ ? reinterpret_cast<const TIO*>(kin_ + offsetof(StagedIn<N>, pcom)) : reinterpret_cast<const TIO*>(a.pcom) + (size_t)b * N * 3) : gx0;
         const TIO v_x0 = gx0[t < 13 ? t : 0];
         const uint8_t v_ct = gct[t < N * 4 ? t : 0];
         const TIO v_pc = gpc[(a.pcom && t < N * 3) ? t : 0];
@@ -1647,6 +1648,15 @@ __global__ __launch_bounds__((WrenchSmem<N, 8, SPW, XW>::BT), WPS) void srbdqp_w
     if ((!a.count_ptr || (int)blockIdx.x < *a.count_ptr) && !SRBDQP_RESTART_SKIP(a, SRBDQP_QP_INDEX(a)))
         wrench_qp<N, R, TIO, MODE, TT, SPW, XW>(a, SRBDQP_QP_INDEX(a), sm);
     signal_done(a);   // staged path: every workgroup of the launch reports once, with or without work
+}
+
+// ... the low-latency instantiation with the QP's inputs in the kernel-argument segment (StagedIn, srbdqp_common.hpp): one staged QP, first pass
+template <int N, int XW>
+__global__ __launch_bounds__((WrenchSmem<N, 8, 5, XW>::BT), 1) void srbdqp_wrench_kernel_in(KArgs a, StagedIn<N> in) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    (void)in;                                            // (read through staged_in_base(): a.inline_in is set)
+    wrench_qp<N, double, double, 0, double, 5, XW>(a, 0, sm);
+    signal_done(a);
 }
 
 }  // namespace srbdqp
