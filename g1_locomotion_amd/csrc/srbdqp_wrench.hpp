@@ -960,7 +960,11 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     int ta[TS], tb[TS];
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
-        const int id = NW * s + w;
+        // (low-latency instantiation: wave 0 owns tile (0, 0) ONLY -- it inverts it beside the other waves' assembly, below -- and the other NW - 1 waves
+        // share the rest; with 10 tiles on 4 waves nobody holds more than before)
+        constexpr bool LATK = XW > 0 && N <= 10;                       // (N = 24 has set-up helper waves too, in its batch instantiation)
+        static_assert(!LATK || (NW - 1) * TS >= S::NTT - 1, "low-latency instantiation: tiles on NW - 1 waves");
+        const int id = LATK ? ((w == 0) ? (s == 0 ? 0 : NTT) : 1 + (NW - 1) * s + (w - 1)) : NW * s + w;
         int bb = 0;
         while (((bb + 1) * (bb + 2)) / 2 <= id) ++bb;
         tb[s] = (id < NTT) ? bb : -1;
@@ -1036,6 +1040,19 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             }
         }
     }
+    // Low-latency instantiation: tile (0, 0) needs nothing from the other tiles, so its owner inverts it HERE, while the other waves still assemble theirs (it has one
+    // tile less to assemble, above): the first of the factorisation's serial diagonal inversions (3.3 k cycles) leaves the chain.  The inverse waits in registers:
+    // the tile store overlays the tables the other waves are still reading.
+    [[maybe_unused]] v4d winv0 = (v4d){0.0, 0.0, 0.0, 0.0};
+    [[maybe_unused]] bool pre0 = false;
+    if constexpr (XW > 0 && N <= 10 && sizeof(TT) == 8 && MODE == 0) {
+        if (ta[0] == 0 && tb[0] == 0) {                              // (wave-uniform)
+            bool ok0;
+            winv0 = diag16_invert_mfma(acc[0], lane, ok0);
+            if (!ok0 && lane == 0) sm[S::o_misc] = 1.0;
+            pre0 = true;
+        }
+    }
     SRBDQP_STAMP(a, b, 3);
     __syncthreads();
     if constexpr (MODE == 1) {   // assembly dump (tests): T dense [NG][NG], then q[12N], V rows / Bd rows per lane, goff
@@ -1091,8 +1108,10 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
                     for (int q = 0; q < 4; ++q) dd[q] = (double)wsx[(gj + 4 * q) * 16 + cj];
                 }
-                bool ok;
-                const v4d winv = diag16_invert_mfma(dd, lane_j, ok);
+                bool ok = true;
+                v4d winv;
+                if (XW > 0 && j == 0 && pre0) winv = winv0;          // (inverted beside the assembly)
+                else winv = diag16_invert_mfma(dd, lane_j, ok);
                 {
                     const int cj = lane_j & 15, gj = lane_j >> 4;
 #pragma unroll
