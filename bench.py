@@ -102,11 +102,13 @@ def parse_args(argv=None):
     ap.add_argument("--same-batch", action="store_true", help="every step solves the same batch (round-1 behaviour; A/B)")
     ap.add_argument("--max-iter", type=int, default=0, help="override srbdqp_config.max_iter (0 = library default)")
     ap.add_argument("--rho-restart", type=int, default=0, help="override srbdqp_config.rho_restart_iter (0 = library default)")
+    ap.add_argument("--rho-restart-count", type=int, default=0, help="override srbdqp_config.rho_restart_count (0 = library default)")
     ap.add_argument("--rho", type=float, default=0.0, help="override srbdqp_config.rho (0 = library default)")
     ap.add_argument("--rho-fz-scale", type=float, default=0.0, help="override srbdqp_config.rho_fz_scale (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the value_plain / value_stale_hint variants and the configs[2] / configs[4] legs")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / configs[4] legs only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (tests: gloo)")
     ap.add_argument("--stub-solve", action="store_true", help="tests of the launcher path only: no GPU, the solve is a stub")
     return ap.parse_args(argv)
@@ -137,6 +139,18 @@ def self_launch(args, argv):
 
 def _auto_rho(N):
     return 0.7
+
+
+def _resolved_restart(N, it, cnt, max_iter, kname):
+    """what rho_restart_iter / rho_restart_count = 0 mean for this solve (srbdqp.h; srbdqp.hip restart_iter_of)"""
+    wave = kname.startswith("wave_")
+    auto = it == 0
+    if auto:
+        it = (100 if N <= 16 else 125) if N > 10 else (55 if wave else 0)
+    if it <= 0 or it >= max_iter:
+        return {"every": 0, "count": 0, "how": "off"}
+    cnt = (cnt if cnt > 0 else (2 if auto else 1)) if wave else 1
+    return {"every": it, "count": cnt, "how": "in place, inside the one-wave kernel" if wave else "a second launch over the same grid"}
 
 
 def _auto_rho_fz(N):
@@ -173,6 +187,7 @@ class Leg:
             kw = {}
             if args.max_iter > 0: kw["max_iter"] = args.max_iter
             if args.rho_restart != 0: kw["rho_restart_iter"] = args.rho_restart
+            if args.rho_restart_count != 0: kw["rho_restart_count"] = args.rho_restart_count
             if args.rho > 0: kw["rho"] = args.rho
             if args.rho_fz_scale > 0: kw["rho_fz_scale"] = args.rho_fz_scale
             self.eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=cfg["maxs"], **kw)
@@ -455,6 +470,19 @@ def main(argv=None):
         extra["value_variants_note"] = ("value: %d streams + longest-first hint = the same batch's previous iteration counts; value_plain: 1 stream, no hint "
                                         "(strictly serial steps, natural QP order); value_stale_hint: %d streams, hint = the counts of a DIFFERENT "
                                         "batch (uncorrelated: a wrong hint only reorders work)" % (S, S))
+        if args.rho_restart == 0 and kname.startswith("wave_"):
+            # what the rho restart in place costs and buys: the same steps with it switched off (plain fixed-rho ADMM, the algorithm of rounds 1-2)
+            import copy
+            args_off = copy.copy(args); args_off.rho_restart = -1
+            leg_off = Leg(cid, B, args_off, rank, local_rank, dev, torch, nb, max_streams=S)
+            for i in range(2 * leg_off.NO):
+                leg_off.step(i, S=S, hint="none" if i < leg_off.NO else hint)
+            sync()
+            el_off = timed(leg_off, base, steps, False, S, hint)
+            it_off, solved_off, _ = leg_off.stats(SOLVED)
+            leg_off.close()
+            extra["without_rho_restart"] = {"value": B * steps / el_off, "solved_frac": solved_off, "admm_mean_iters": it_off,
+                                            "note": "the same steps with rho_restart_iter = -1; value / solved_frac above are with the default (srbdqp.h rho_restart_iter)"}
 
     if rank == 0:
         total_qp = world * B * steps
@@ -477,7 +505,8 @@ def main(argv=None):
             c = leg.eng.cfg
             out["config"].update({"eps_abs": max(c.eps_abs, 2e-6) if f32 else c.eps_abs, "eps_rel": max(c.eps_rel, 2e-6) if f32 else c.eps_rel,
                                   "rho": _auto_rho(N) if c.rho == 0 else c.rho, "rho_fz_scale": _auto_rho_fz(N) if c.rho_fz_scale == 0 else c.rho_fz_scale,
-                                  "max_iter": int(c.max_iter), "rho_restart_iter": int(c.rho_restart_iter),
+                                  "max_iter": int(c.max_iter), "rho_restart_iter": int(c.rho_restart_iter), "rho_restart_count": int(c.rho_restart_count),
+                                  "rho_restart_resolved": _resolved_restart(N, int(c.rho_restart_iter), int(c.rho_restart_count), int(c.max_iter), kname),
                                   "set_up_dtype": "f64" if not f32 else "f64 assembly, f32 tiles (f64 tiles for QPs with a step of <= 2 stance contacts)"})
         if elapsed_other is not None:
             key = "value_without_allgather" if use_ag else "value_with_allgather"
@@ -491,7 +520,7 @@ def main(argv=None):
         host_batch0 = leg.host_batches[0] if cid != 4 else None
         leg.close()
         leg = None
-        if world == 1 and not stub and cid == 1 and not args.no_also:
+        if world == 1 and not stub and cid == 1 and not args.no_also and not args.no_other_configs:
             out["also"] = also_legs(args, rank, local_rank, dev, torch, SOLVED)
         if world == 1 and not args.no_cpu_baseline and not stub and cid != 4:
             out["cpu_baseline"] = cpu_baseline(cid, N, host_batch0)
@@ -641,7 +670,8 @@ def cpu_baseline(config, N, batch):
     import srbd_oracle as orc
     import c_oracle
     x0, xr, ft, ct = batch
-    p = orc.params_for(N, rho_restart_iter=0 if N <= 10 else (100 if N <= 16 else 125))    # as the engine runs the config by default
+    r_iter, r_count = orc.default_restart(N, one_wave=CONFIGS[config]["maxs"] <= 2 and x0.shape[0] >= 512)
+    p = orc.params_for(N, rho_restart_iter=r_iter, rho_restart_count=r_count)    # as the engine runs the config by default
     cores = _cpu_share()
     # sized for ~10-30 s of CPU work: N = 10 -> 4096 QPs x 24 (0.15 ms per QP and thread), N = 20 -> 1024 QPs x 2 (dense
     # 240-variable factor: several ms per QP and thread)

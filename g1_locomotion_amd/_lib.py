@@ -53,7 +53,7 @@ class Config(C.Structure):
     """struct srbdqp_config (include/srbdqp.h)."""
     _fields_ = [
         ("struct_size", C.c_int32), ("horizon", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
-        ("kernel", C.c_int32), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("max_contacts_per_step", C.c_int32), ("rho_restart_iter", C.c_int32), ("reserved0", C.c_int32),
+        ("kernel", C.c_int32), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("max_contacts_per_step", C.c_int32), ("rho_restart_iter", C.c_int32), ("rho_restart_count", C.c_int32),
         ("dt", C.c_double), ("mass", C.c_double), ("inertia", C.c_double * 3), ("mu", C.c_double),
         ("fz_min", C.c_double), ("fz_max", C.c_double), ("q_diag", C.c_double * NX), ("r_diag", C.c_double),
         ("force_scale", C.c_double), ("rho", C.c_double), ("rho_eq_scale", C.c_double), ("sigma", C.c_double),

@@ -194,6 +194,14 @@ inline bool uses_wrench(const srbdqp_handle* h, int maxs, int B) {
     return B >= kWrenchMinBatch || (h->staged_call && N >= 8 && h->staged_neff > kStagedWrenchMinVars);
 }
 
+// does a solve of B QPs on this handle run on the one-wave kernel (launch_wave)?  launch_compact() and the restart plan (solve_device_impl) ask this.
+inline bool uses_wave(const srbdqp_handle* h, int maxs, int B, bool stamps, bool signalled) {
+    const int N = h->cfg.horizon, k = h->cfg.kernel;
+    if (N > 10 || !(N == 4 || maxs <= 2) || uses_wrench(h, maxs, B)) return false;     // (<= 64 presolved variables: Setup1Smem::supported)
+    const bool want = k == SRBDQP_KERNEL_WAVE || (k == SRBDQP_KERNEL_AUTO && B >= kSplitMinBatch);
+    return want && (!stamps || k == SRBDQP_KERNEL_WAVE) && !signalled;
+}
+
 // KERNEL_SPLIT (A/B): the one-wave set-up and the one-wave ADMM as two kernels with the hand-over through HBM.
 
 template <int N, int MAXS>
@@ -287,6 +295,11 @@ int launch_wave(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     static const std::string nm = "wave_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
     if (a.mode == 1) hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, true, true>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
+    else if (a.restart_every > 0) {   // the rho restart in place: (x, y) of a pass wait in [3][64] doubles behind the kernel's own LDS
+        constexpr size_t ldsr = lds1 + 3 * 64 * sizeof(double);
+        static_assert(8 * ((ldsr + 1279) / 1280) * 1280 <= 163840, "eight QPs per CU");
+        hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, true, false, false, true>), dim3((unsigned)a.B), dim3(64), ldsr, st, a);
+    }
     else hipLaunchKernelGGL((srbdqp::srbdqp_setup1_kernel<N, MAXS, true>), dim3((unsigned)a.B), dim3(64), lds1, st, a);
     HIP_TRY(h, hipGetLastError());
     return SRBDQP_OK;
@@ -308,8 +321,7 @@ bool staged_inline_inputs(const srbdqp_handle* h, const KArgs& a, srbdqp::Staged
 template <int N, int MAXS>
 int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     if constexpr (srbdqp::Setup1Smem<N, MAXS>::supported) {
-        const bool want = h->cfg.kernel == SRBDQP_KERNEL_WAVE || (h->cfg.kernel == SRBDQP_KERNEL_AUTO && a.B >= kSplitMinBatch);
-        if (want && (!a.stamps || h->cfg.kernel == SRBDQP_KERNEL_WAVE) && !a.done_flag) return launch_wave<N, MAXS>(h, a, st);
+        if (uses_wave(h, MAXS, a.B, a.stamps != nullptr, a.done_flag != nullptr)) return launch_wave<N, MAXS>(h, a, st);
     }
     if constexpr (srbdqp::SplitWs<N, MAXS>::supported) {
         if (h->cfg.kernel == SRBDQP_KERNEL_SPLIT && a.mode == 0 && !a.stamps && !a.done_flag) return launch_split<N, MAXS>(h, a, st);
@@ -517,18 +529,28 @@ struct Carver {
     }
 };
 
-// Iteration at which a solve of this handle re-balances rho (0 = never).  srbdqp_config.rho_restart_iter: > 0 that
-// iteration, < 0 off, 0 = automatic: 100 (125 above N = 16) at N > 10 on every kernel -- the long horizons have a 1 - 3 % tail (round 3, N = 20 double
-// support with the (0.7, 4) penalties: 17 % of the QPs run past 80 iterations, 8 % past 100, 3 % past 125 -- an earlier restart sends too many through a second set-up: 80
-// instead of 125 cost configs[2] 10 % for 99.90 % instead of 99.89 % solved)
-// of slow QPs (N = 20 single support: 98.4 % solved without, 99.3 % with) and at their 3 - 20 ms steps the second launch costs
-// 3 - 5 % -- off at N <= 10 (the batch kernels run 0.16 ms steps, where a second launch costs 15 %: DESIGN.md).
-inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B) {
+// Iteration at which a solve of this handle re-balances rho (0 = never), and how many times it may (*count).  srbdqp_config.rho_restart_iter: > 0 that
+// iteration, < 0 off, 0 = automatic:
+//  * N > 10, every kernel: 100 (125 above N = 16), once, as a second launch -- the long horizons have a 1 - 3 % tail of slow QPs (N = 20 single support: 98.4 %
+//    solved without, 99.3 % with; round 3, N = 20 double support with the (0.7, 4) penalties: 17 % of the QPs run past 80 iterations, 8 % past 100, 3 % past 125 --
+//    an earlier restart sends too many through a second set-up: 80 instead of 125 cost configs[2] 10 % for 99.90 % instead of 99.89 % solved) and at their 3 - 20 ms
+//    steps the second launch costs 3 - 5 %;
+//  * N <= 10 on the one-wave kernel (wave = true): every 55 iterations, up to twice, IN PLACE (srbdqp_setup1.hpp RST) -- 99.3 % -> 99.93 % of the configs[1] QPs solved
+//    inside the same 250-iteration cap, at fewer iterations in total (34.8 -> 33.8) and 3 % of the throughput.  Measured on the device (configs[1], 4 x 4096 QPs;
+//    M QP/s, solved, duration of one isolated launch): off 30.6, 0.9929, 0.19 ms; 80 x 1 30.2, 0.9981, 0.21; 65 x 2 30.0, 0.9991, 0.24; 55 x 2 29.6, 0.9993, 0.24;
+//    70 x 3 29.2, 0.9996, 0.27; 60 x 3 29.9 (another box), 0.9998; 50 x 3 29.5, 0.9999 -- every restarted QP repeats two thirds of a set-up, which is most of a
+//    solve at these sizes, and the slowest QP of a launch now carries up to two of them (a launch alone on the device lasts as long as its slowest QP:
+//    without the longest-first hint the step rate drops by a fifth);
+//  * the other N <= 10 solves: off (the batch kernels run 0.16 ms steps, where a second launch costs 15 %: DESIGN.md).
+inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B, bool wave = false, int* count = nullptr) {
     const srbdqp_config& c = h->cfg;
     const int rk = resolve_kernel(c);
+    if (count) *count = 1;
     if (rk != SRBDQP_KERNEL_COMPACT && rk != SRBDQP_KERNEL_WRENCH) return 0;   // v0 / v1 have no restart
     int r = c.rho_restart_iter;
-    if (r == 0) r = (c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : 0;
+    const bool automatic = r == 0;
+    if (automatic) r = (c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : (wave ? 55 : 0);
+    if (count && wave) *count = c.rho_restart_count > 0 ? c.rho_restart_count : (automatic ? 2 : 1);
     return (r > 0 && r < c.max_iter) ? r : 0;
 }
 
@@ -595,7 +617,7 @@ int srbdqp_default_config(srbdqp_config* c) {
     c->force_scale = 100.0;
     c->rho = 0.0; c->rho_eq_scale = 1.0e3; c->sigma = 1.0e-6; c->alpha = 1.6;
     c->eps_abs = 1.0e-6; c->eps_rel = 1.0e-6;
-    c->rho_restart_iter = 0; c->reserved0 = 0;
+    c->rho_restart_iter = 0; c->rho_restart_count = 0;
     c->rho_fz_scale = 0.0;
     return SRBDQP_OK;
 }
@@ -908,8 +930,11 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
         a.perm = slot->perm;
     }
     int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
-    const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h, maxs, B);
-    if (!restart) return launch(h, a, lst, maxs);
+    const bool wave = uses_wave(h, maxs, B, a.stamps != nullptr, a.done_flag != nullptr);
+    int rcount = 1;
+    const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h, maxs, B, wave, &rcount);
+    if (restart && wave) { a.restart_every = restart; a.restart_max = rcount; }   // the one-wave kernel restarts in place
+    if (!restart || wave) return launch(h, a, lst, maxs);
 
     // ---- two passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those
     auto* slot = stream_slot(h, lst);

@@ -52,6 +52,8 @@ struct KArgs {
                              //   that ends at the cap, or null
     const int32_t* count_ptr;   // second pass: number of valid entries of perm[]; workgroups beyond it exit at once
     int32_t iters_base;      // second pass: iterations of the first pass, added to iters[] on output
+    int32_t restart_every;   // one-wave kernel, restart in place (srbdqp_setup1.hpp RST): re-balance rho every this many iterations ...
+    int32_t restart_max;     //   ... at most this many times
     int32_t inline_in;       // the *_in kernels: the inputs of the one staged QP follow KArgs in the kernel-argument segment (StagedIn, below)
     int32_t y_capped_only;   // first pass, y_out = the engine's own buffer (the caller asked for no duals): only a QP that ends at the cap stores them
                              //   (20 N values per QP for every QP was a quarter of the HBM traffic of a configs[2] solve)

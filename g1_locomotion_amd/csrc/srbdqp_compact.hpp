@@ -343,9 +343,10 @@ __device__ __forceinline__ void dump_presolved(const KArgs& a, int b, int n_eff,
 // One QP (index b) on one 256-thread workgroup; sm = the workgroup's dynamic LDS (CompactSmem<N, MAXS>::bytes).
 // Every exit is workgroup-uniform and leaves no state in LDS that a later call would rely on.
 template <int N, int MAXS> struct SplitWs;
-template <int N, int MAXS>
+struct WaveRestart;
+template <int N, int MAXS, bool RST>
 __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS],
-                                                     double* xs_full, int& status_out, int& iters_out);   // srbdqp_split.hpp
+                                                     double* xs_full, int& status_out, int& iters_out, WaveRestart* rs);   // srbdqp_split.hpp
 
 // TAIL1 (the staged batch-1 instantiation, compiled for one workgroup's worth of registers): the four waves set the problem up, then wave 0 alone runs the
 // one-wave iteration (a K^-1 row per lane, no LDS operation and no barrier in the loop: 0.36 us per iteration against 0.52 for the 4-wave loop at batch 1,
@@ -882,7 +883,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
         int* fin = reinterpret_cast<int*>(sm + S::o_red);
         if (!failed) {
             if (w == 0) {
-                admm_wave_iterations<N, MAXS>(a, b, rho_b, sm, kin1, sm + S::o_xs, status, iters);
+                admm_wave_iterations<N, MAXS, false>(a, b, rho_b, sm, kin1, sm + S::o_xs, status, iters, nullptr);
                 if (lane == 0) { fin[0] = status; fin[1] = iters; }
             }
             __syncthreads();

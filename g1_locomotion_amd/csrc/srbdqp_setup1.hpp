@@ -65,22 +65,26 @@ struct Setup1Smem {
 //                nothing but the inputs and the outputs touches HBM.
 // PHI (split only): also store dq/dx0 for the two-phase call (srbdqp_prepare_staged_f64): q is affine in x0, so 13 more
 //                passes of the gradient tables with x0 = e_k and x_ref = 0 give its 13 columns.
-template <int N, int MAXS, bool FUSED, bool DUMP = false, bool PHI = false>
-__global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
-    static_assert(!(PHI && FUSED), "dq/dx0 is a hand-over of the split pipeline");
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+// RST (fused only): the rho restart IN PLACE.  A QP that has not converged after a.restart_every iterations re-balances its rho (OSQP's rule from the maxima of its
+//                last check, each time from the rho of the pass that ended), repeats the part of the set-up that depends on rho -- the tables of the K assembly,
+//                K, its factorisation and inverse, P x of the point it continues from; the inputs, J and the gradient stay -- and continues from its own (x, y), at most a.restart_max times; the
+//                cap a.max_iter is on the total.  What a second launch over the capped QPs does for the other kernels (srbdqp.hip), without the launches: 4 % of
+//                the configs[1] QPs pass the first mark, 1 % the second.  The body is compiled TWICE for this: the first pass as straight-line code (RP = 1: the
+//                code of the kernel without restart), the continued passes as a loop behind it (RP = 2) -- ONE copy inside a loop has hipcc hoist the body's
+//                lane-index arithmetic, fp64 constants and literal materialisations in front of the loop and keep them in registers through the whole body
+//                (256 VGPRs + 228 bytes of scratch against 224 + 0, -7 % on every QP); this way only the restarted QPs run the loop's code.
+//                The (x, y) of a pass wait in 1.5 KB of LDS behind the kernel's own.  oracle: SrbdParams.rho_restart_iter / rho_restart_count.
+// One pass of the body.  RP: 0 = the whole solve of a kernel without restart; 1 = first pass of the restart kernel; 2 = a continued pass.  Returns true if another
+// pass follows (rho_b, rs_pass, rs_done updated).
+template <int N, int MAXS, bool FUSED, bool DUMP, bool PHI, int RP>
+__device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double* sm, double& rho_b, int& rs_pass, int& rs_done) {
     using S = CompactSmem<N, MAXS>;
     using W = SplitWs<N, MAXS>;
     using L1 = Setup1Smem<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m, NT = S::NT;
-    static_assert(L1::supported, "one wave holds all tiles: at most 4 x 4 tiles");
-    static_assert(4 * N <= 64, "one ballot compacts the contact flags");
-    if ((int)blockIdx.x >= a.B) return;
-    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) return;
-    const int b = SRBDQP_QP_INDEX(a);
-    if (SRBDQP_RESTART_SKIP(a, b)) return;
-    const double rho_b = SRBDQP_RHO_OF(a, b);
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;
+    if constexpr (RP == 2) asm volatile("" : "+v"(lane));   // (inside the loop of the continued passes: an opaque value in every trip, or its arithmetic is hoisted too)
+    [[maybe_unused]] double* const park = sm + L1::o_end;   // RP > 0: [3][64] behind the kernel's own LDS
     int mcol = lane & 15, kq = lane >> 4;
     double* ws = FUSED ? nullptr : a.ws + (size_t)b * W::doubles;
     int* icnt = reinterpret_cast<int*>(sm + S::o_int);
@@ -93,7 +97,13 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     // ================= load + linearise (a5) =================
     WSTAMP(a, b, 0);
     WSTAMP_RT(a, b, 12);
-    {
+    if constexpr (RP == 2) {   // the strip (contact lists, T, J, x0, q) is in place; the prefix sums were overwritten by the K^-1 staging
+        if (lane < 9) {
+            double acc = 0.0;
+            for (int k = 0; k < N; ++k) { acc += sm[S::o_tm + k * 9 + lane]; sm[L1::o_cp + k * 9 + lane] = acc; }
+        }
+        __syncthreads();
+    } else {
         const double* gx0 = a.x0 + (size_t)b * 13;
         const double* gxr = a.xref + (size_t)b * N * 13;
         const double* gft = a.foot + (size_t)b * N * 12;
@@ -161,8 +171,8 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     const int n_eff = 3 * na;
     double* xs0 = sm + L1::o_mt;                             // scratch vectors of the early exit (n + 12N doubles; M is not built)
     static_assert(L1::o_end - L1::o_mt >= n + 12 * N, "early-exit scratch");
-    if (imisc[1] != 0 || na == 0) {   // bound violated (status -2) or nothing to solve (all forces 0): finished here
-        if constexpr (DUMP) { if (lane == 0) a.ub_out[(size_t)b * m] = (imisc[1] != 0) ? -1.0 : 0.0; return; }   // assembly dump: nothing to show
+    if (RP != 2 && (imisc[1] != 0 || na == 0)) {   // bound violated (status -2) or nothing to solve (all forces 0): finished here
+        if constexpr (DUMP) { if (lane == 0) a.ub_out[(size_t)b * m] = (imisc[1] != 0) ? -1.0 : 0.0; return false; }   // assembly dump: nothing to show
         for (int c = lane; c < n; c += 64) xs0[c] = 0.0;
         if (a.y_out) for (int i = lane; i < m; i += 64) a.y_out[(size_t)b * m + i] = 0.0;
         if (lane == 0) {
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         }
         __syncthreads();
         rollout_and_store<N, S, 64>(a, b, sm, xs0, xs0 + n);
-        return;
+        return false;
     }
 
     WSTAMP(a, b, 1);
@@ -182,9 +192,11 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     double* T2 = sm + L1::o_t2;
     double* MT = sm + L1::o_mt;
     double* GV = sm + L1::o_gv;
-    for (int k = lane; k < n; k += 64) {
-        const int i = k / 12, kk = k - 12 * i;
-        sm[L1::o_eh + k] = SQ[kk] * (free_response<N, L1>(a, sm, i, kk) - sm[L1::o_xref + i * 13 + kk]);
+    if constexpr (RP != 2) {
+        for (int k = lane; k < n; k += 64) {
+            const int i = k / 12, kk = k - 12 * i;
+            sm[L1::o_eh + k] = SQ[kk] * (free_response<N, L1>(a, sm, i, kk) - sm[L1::o_xref + i * 13 + kk]);
+        }
     }
     // T2(m) is symmetric: one lane per (m, p <= q) -- 6 N entries, one round of the wave at N = 10 instead of two -- which also forms
     // both T1 entries of its pair
@@ -243,15 +255,15 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         const double* g = GV + 9 * j;
         return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
     };
-    gt_tables(sm + L1::o_eh);
+    if constexpr (RP != 2) gt_tables(sm + L1::o_eh);
     mt_tables<N>(CP, T1, T2, SQ, dt2, MT, lane, 64);
     __syncthreads();
     WSTAMP(a, b, 2);
-    for (int c = lane; c < n_eff; c += 64) sm[S::o_q + c] = gt_eval(c);
-    if (a.warm_u) {
+    if constexpr (RP != 2) for (int c = lane; c < n_eff; c += 64) sm[S::o_q + c] = gt_eval(c);      // (a continued pass: q stays)
+    if (RP == 2 || a.warm_u) {   // P x^0 through the tables; a continued pass: of the x the pass before left (in newtons, one per lane), as a second launch would
         double* TF = sm + L1::o_tf;
         for (int c = lane; c < n_eff; c += 64)
-            sm[L1::o_x0c + c] = a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)] / a.s;
+            sm[L1::o_x0c + c] = (RP == 2 ? park[c] : a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)]) / a.s;
         __syncthreads();
         for (int tt = lane; tt < 6 * N; tt += 64) {
             const int j = tt / 6, comp = tt - 6 * j;
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) put(16 * ta + kq + 4 * q, 16 * tb + mcol, Kt[ta][tb][q]);
         });
-        return;
+        return false;
     }
 
     // A-operand form of a C-layout tile X (operand[r] at lane (i, k') = X[i][4r + k']): through the wave-private tile
@@ -547,10 +559,51 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
         WSTAMP(a, b, 8);
         WSTAMP(a, b, 9);
         static_assert(L1::o_end >= SplitSmem<N, MAXS>::o_end, "the ADMM body's vectors live in this kernel's LDS");
-        admm_wave_body<N, MAXS>(a, b, rho_b, sm, kin);
+        if constexpr (RP == 0) {
+            admm_wave_body<N, MAXS>(a, b, rho_b, sm, kin);
+        } else {
+            WaveRestart rs;
+            const int left = a.max_iter - rs_done;                                   // the cap is on the total
+            rs.pass = rs_pass;
+            rs.more = rs_pass < a.restart_max && a.restart_every < left;
+            rs.kcap = rs.more ? a.restart_every : left;
+            rs.park = park;
+            int status = -1, iters = 0;
+            admm_wave_iterations<N, MAXS, true>(a, b, rho_b, sm, kin, sm + SplitSmem<N, MAXS>::o_xs, status, iters, &rs);
+            rs_done += iters;
+            if (status == 2 && rs.more) {   // (wave-uniform) at the mark, not converged: another pass
+                rho_b = restart_rho_of(rho_b, rs.v);
+                ++rs_pass;
+                __syncthreads();
+                return true;
+            }
+            admm_wave_finish<N, MAXS>(a, b, sm, status, rs_done);
+        }
         WSTAMP(a, b, 10);
         WSTAMP(a, b, 11);
         WSTAMP_RT(a, b, 13);
+    }
+    return false;
+}
+
+template <int N, int MAXS, bool FUSED, bool DUMP = false, bool PHI = false, bool RST = false>
+__global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
+    static_assert(!(PHI && FUSED), "dq/dx0 is a hand-over of the split pipeline");
+    static_assert(!RST || (FUSED && !DUMP), "the restart in place belongs to the fused solve");
+    static_assert(Setup1Smem<N, MAXS>::supported, "one wave holds all tiles: at most 4 x 4 tiles");
+    static_assert(4 * N <= 64, "one ballot compacts the contact flags");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x >= a.B) return;
+    if (a.count_ptr && (int)blockIdx.x >= *a.count_ptr) return;
+    const int b = SRBDQP_QP_INDEX(a);
+    if (SRBDQP_RESTART_SKIP(a, b)) return;
+    double rho_b = SRBDQP_RHO_OF(a, b);
+    int rs_pass = 0, rs_done = 0;
+    if constexpr (!RST) {
+        setup1_pass<N, MAXS, FUSED, DUMP, PHI, 0>(a, b, sm, rho_b, rs_pass, rs_done);
+    } else {
+        bool again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 1>(a, b, sm, rho_b, rs_pass, rs_done);
+        while (again) again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 2>(a, b, sm, rho_b, rs_pass, rs_done);
     }
 }
 

@@ -29,13 +29,24 @@ struct SplitSmem {
 // The ADMM iterations of one QP on ONE wave (wave-local: no barrier inside; the caller's waves other than this one may wait at one).  sm: the persistent
 // strip at [0, S::o_R); kin: the K^-1 row of this lane (zeros for lanes >= n_eff); xs_full: n doubles that receive the solution in the full variable order
 // (zeros elsewhere).  Used by the one-wave kernels and by the 4-wave kernel's batch-1 instantiation (srbdqp_compact.hpp, TAIL1).
-template <int N, int MAXS>
+// In-kernel rho restart of the one-wave kernel (srbdqp_setup1.hpp, RST): the pass this call is, what it may run, where a pass that ends at its cap leaves
+// (x in newtons, y) for the next one, and the maxima of its last full check for the re-balancing rule.
+struct WaveRestart {
+    int pass = 0;            // 0 = first pass (warm start from the caller's arrays, if any); > 0: from park[]
+    int kcap = 0;            // iterations this pass may run
+    bool more = false;       // another pass may follow: a QP that ends at kcap parks its (x, y) and stores no duals
+    double* park = nullptr;  // LDS [3][64]: x (newtons), y of slot A, y of slot B, per lane
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+};
+
+template <int N, int MAXS, bool RST>
 __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS],
-                                                     double* xs_full, int& status_out, int& iters_out) {
+                                                     double* xs_full, int& status_out, int& iters_out, WaveRestart* rs) {
     using S = CompactSmem<N, MAXS>;
     using W = SplitWs<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m, KS = W::KS;
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    if constexpr (RST) asm volatile("" : "+v"(lane));                   // (inside the restart loop: an opaque value in every trip, see srbdqp_setup1.hpp)
     for (int i = lane; i < n; i += 64) xs_full[i] = 0.0;                 // (one wave: its LDS operations complete in order)
     const int* icnt = reinterpret_cast<const int*>(sm + S::o_int);
     const int* imisc = icnt + 2 * N;
@@ -73,20 +84,29 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, doub
         double cpx = active ? sm[S::o_px0 + lane] : 0.0, spxA = 0.0, spxB = 0.0;
         double yA = (rowA && a.warm_y) ? a.warm_y[(size_t)b * m + irowA] : 0.0;
         double yB = (rowB && a.warm_y) ? a.warm_y[(size_t)b * m + irowB] : 0.0;
+        int kmax = a.max_iter;
+        if constexpr (RST) {
+            kmax = rs->kcap;
+            if (rs->pass > 0) {   // (wave-uniform) continue the pass before: the forces re-read in newtons, as a second launch would
+                x = active ? rs->park[lane] / a.s : 0.0;
+                yA = rowA ? rs->park[64 + lane] : 0.0;
+                yB = rowB ? rs->park[128 + lane] : 0.0;
+            }
+        }
         const double fz0 = contact_fz(x, ax);
         double axA = rowA ? fma(-mucA, fz0, x) : 0.0, axB = rowB ? fma(-mu, fz0, -x) : 0.0;     // (A x)_slot by recursion
         double zA = fmin(fmax(axA, loA), hiA), zB = fmin(fmax(axB, loB), hiB);
         const float qnf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg((float)fabs(qv))), 63));
         double rhs = sigma * x - qv + At(rhoA * zA - yA, rhoB * zB - yB);     // (inactive lanes: 0)
-        status = 2; iters = a.max_iter;
+        status = 2; iters = kmax;
         double e_prim_last = kInf * 1.0e10;
         bool vote_ok = true;
         int ph = 0;
         float lastv0 = 0.0f, lastv1 = 0.0f, lastv2 = 0.0f, lastv3 = 0.0f;   // maxima of the last full check (restart rule)
-        for (int k = 1; k <= a.max_iter; ++k) {
+        for (int k = 1; k <= kmax; ++k) {
             if (++ph == a.check_every) ph = 0;
             const bool at_mark = (ph == 0);
-            const bool check = (at_mark && vote_ok) || (k == a.max_iter);
+            const bool check = (at_mark && vote_ok) || (k == kmax);
             const bool pretest = (ph == a.check_every - 1);
             // x~ = K^-1 rhs, a K^-1 row per lane.  The right-hand side never leaves the register file's neighbourhood: every 16-lane
             // row fetches the four 16-value chunks of the vector with ds_bpermute (8 instructions), then each term is one
@@ -151,7 +171,13 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, doub
         }
         if (status < 0) { x = 0.0; yA = 0.0; yB = 0.0; }                    // a numerical failure returns zero forces, never NaN
         if (active) xs_full[3 * gc + ax] = x;
-        if (a.y_out && (!a.y_capped_only || status == 2)) {
+        bool parked = false;
+        if constexpr (RST) {
+            rs->v[0] = lastv0; rs->v[1] = lastv1; rs->v[2] = lastv2; rs->v[3] = lastv3;
+            parked = status == 2 && rs->more;
+            if (parked) { rs->park[lane] = a.s * x; rs->park[64 + lane] = yA; rs->park[128 + lane] = yB; }
+        }
+        if (a.y_out && (!a.y_capped_only || status == 2) && !parked) {
             if (rowA) a.y_out[(size_t)b * m + irowA] = yA;
             if (rowB) a.y_out[(size_t)b * m + irowB] = yB;
         }
@@ -159,17 +185,15 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, doub
     status_out = status; iters_out = iters;
 }
 
-// ADMM iterations + roll-out of one QP on one wave (the one-wave kernels).  sm: the persistent strip at [0, S::o_R) and SplitSmem's vectors behind it.
+// What follows the iterations of the one-wave kernels: the duals of the eliminated rows, status, iteration count, roll-out
 template <int N, int MAXS>
-__device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS]) {
+__device__ __forceinline__ void admm_wave_finish(const KArgs& a, int b, double* sm, int status, int iters) {
     using S = CompactSmem<N, MAXS>;
     using L = SplitSmem<N, MAXS>;
     constexpr int m = Dims<N>::m;
     const int lane = threadIdx.x;
     double* xs_full = sm + L::o_xs;
     const bool failed = sm[S::o_misc] != 0.0;
-    int status = -1, iters = 0;
-    admm_wave_iterations<N, MAXS>(a, b, rho_b, sm, kin, xs_full, status, iters);
     __syncthreads();
     if (a.y_out && (!a.y_capped_only || status == 2)) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
         const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
@@ -181,6 +205,14 @@ __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho
         if (a.iters) a.iters[b] = iters + a.iters_base;
     }
     rollout_and_store<N, S, 64>(a, b, sm, xs_full, sm + L::o_scr);
+}
+
+// ADMM iterations + roll-out of one QP on one wave (the one-wave kernels).  sm: the persistent strip at [0, S::o_R) and SplitSmem's vectors behind it.
+template <int N, int MAXS>
+__device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS]) {
+    int status = -1, iters = 0;
+    admm_wave_iterations<N, MAXS, false>(a, b, rho_b, sm, kin, sm + SplitSmem<N, MAXS>::o_xs, status, iters, nullptr);
+    admm_wave_finish<N, MAXS>(a, b, sm, status, iters);
 }
 
 template <int N, int MAXS>

@@ -82,14 +82,18 @@ typedef struct srbdqp_config {
     int32_t max_contacts_per_step; /* bound on stance contact points per horizon step: 1..4; 0 = decide per call
                                     * (host-buffer API scans the contact flags, device API assumes 4).  A bound of
                                     * <= 2 selects the smaller, higher-occupancy kernel instantiation. */
-    int32_t rho_restart_iter;     /* one OSQP-style re-balancing of rho: a QP that has not converged after this many
+    int32_t rho_restart_iter;     /* OSQP-style re-balancing of rho: a QP that has not converged after this many
                                    * iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual))
                                    * (clipped to [rho/10, 5 rho]) and continues from its own (x, y) until max_iter
-                                   * iterations in total; iters[] counts both passes.  < 0 or >= max_iter = off; 0 (default) =
-                                   * automatic: 100 (125 above N = 16) at N > 10, off at N <= 10.  Runs as
-                                   * a second launch over the same grid: the workgroup of a QP the first pass left at its
-                                   * cap continues it, every other one leaves at once (every capped QP is continued). */
-    int32_t reserved0;
+                                   * iterations in total; iters[] counts every pass.  < 0 or >= max_iter = off; 0 (default) =
+                                   * automatic: 100 (125 above N = 16) at N > 10; 55 where the one-wave kernel runs the solve
+                                   * (N <= 10, at most 2 stance contacts per step, batches of 512 QPs and more), which restarts
+                                   * in place; off for the other N <= 10 solves.  Everywhere else the restart is a second launch
+                                   * over the same grid: the workgroup of a QP the first pass left at its cap continues it, every
+                                   * other one leaves at once (every capped QP is continued). */
+    int32_t rho_restart_count;    /* at most this many re-balancings, one every rho_restart_iter iterations, each from the rho of
+                                   * the pass before it (honoured by the one-wave kernel; every other kernel re-balances once).
+                                   * 0 (default) = automatic: 2 with the automatic rho_restart_iter of the one-wave kernel, else 1 */
     double dt;                    /* run_simulation.py:169 */
     double mass;                  /* wbid.py:291 model.getMass() */
     double inertia[3];            /* wbid.py:261-266 torso inertia diagonal */

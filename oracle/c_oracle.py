@@ -17,13 +17,14 @@ class CParams(C.Structure):
                 ("fz_min", C.c_double), ("fz_max", C.c_double), ("q_diag", C.c_double * 13), ("r_diag", C.c_double),
                 ("force_scale", C.c_double), ("rho", C.c_double), ("rho_eq_scale", C.c_double), ("sigma", C.c_double),
                 ("alpha", C.c_double), ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("rho_fz_scale", C.c_double),
-                ("max_iter", C.c_int), ("check_every", C.c_int), ("rho_restart_iter", C.c_int), ("eliminate_swing", C.c_int)]
+                ("max_iter", C.c_int), ("check_every", C.c_int), ("rho_restart_iter", C.c_int), ("eliminate_swing", C.c_int),
+                ("rho_restart_count", C.c_int)]
 
 
 def _params(p: orc.SrbdParams) -> CParams:
     c = CParams()
     for k in ("dt", "mass", "mu", "fz_min", "fz_max", "r_diag", "force_scale", "rho", "rho_eq_scale", "sigma", "alpha",
-              "eps_abs", "eps_rel", "rho_fz_scale", "max_iter", "check_every", "rho_restart_iter", "eliminate_swing"):
+              "eps_abs", "eps_rel", "rho_fz_scale", "max_iter", "check_every", "rho_restart_iter", "eliminate_swing", "rho_restart_count"):
         setattr(c, k, getattr(p, k))
     for i in range(3):
         c.inertia[i] = p.inertia[i]

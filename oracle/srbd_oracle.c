@@ -31,8 +31,9 @@ typedef struct {
     double rho, rho_eq_scale, sigma, alpha, eps_abs, eps_rel;
     double rho_fz_scale;   /* penalty of a stance contact's normal-force row relative to rho (srbd_oracle.py SrbdParams) */
     int max_iter, check_every;
-    int rho_restart_iter;  /* presolved path: one OSQP-style re-balancing of rho after this many iterations (0 = off) */
+    int rho_restart_iter;  /* presolved path: OSQP-style re-balancing of rho after this many iterations (0 = off) */
     int eliminate_swing;   /* presolve: drop the variables/rows of swing contacts (kernel v2); 0 = clamp via bounds */
+    int rho_restart_count; /* at most this many re-balancings, one every rho_restart_iter iterations (<= 1: one) */
 } srbd_oracle_params;
 
 static void matmul(const double* A, const double* B, double* C, int m, int k, int n) {
@@ -186,8 +187,12 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
     double qn = 0.0, e_prim_last = INFINITY, last_rp = 0, last_np = 0, last_rd = 0, last_nd = 0;
     int status = 2, iters = 0, vote_ok = 1, iters_base = 0;
     const int restart = (p->eliminate_swing && p->rho_restart_iter > 0 && p->rho_restart_iter < p->max_iter) ? p->rho_restart_iter : 0;
-    for (int pass = 0; pass < 2; ++pass) {
-    const int cap = (pass == 0 && restart) ? restart : p->max_iter - iters_base;   /* the cap is on the total */
+    /* up to rho_restart_count re-balancings, one every `restart` iterations (each from the rho of the pass before it); the last pass runs to the cap */
+    const int npass = restart ? 1 + (p->rho_restart_count > 1 ? p->rho_restart_count : 1) : 1;
+    double rho_cur = p->rho;
+    for (int pass = 0; pass < npass; ++pass) {
+    const int left = p->max_iter - iters_base;                                      /* the cap is on the total */
+    const int cap = (pass + 1 < npass && restart < left) ? restart : left;
     for (int i = 0; i < nr; ++i) for (int j = 0; j < nr; ++j) K[(size_t)i * nr + j] = P[(size_t)VIDX(i) * n + VIDX(j)];
     for (int e_ = 0; e_ < nc; ++e_) {
         const int r0 = 5 * e_, c0 = 3 * e_;
@@ -314,13 +319,14 @@ int srbd_oracle_solve(const srbd_oracle_params* p, int N, const double* x0, cons
             if (rp <= ep && rd <= ed) { status = 1; iters = k; break; }
         }
     }
-    if (!(pass == 0 && restart && status == 2)) break;
+    if (!(pass + 1 < npass && status == 2 && iters_base + cap < p->max_iter)) break;
     {   /* OSQP's re-balancing from the fp32 maxima of the last check (srbd_oracle.py restart_rho) */
         const double num = last_rp / fmax(last_np, 1e-30), den = last_rd / fmax(last_nd, 1e-30);
-        double r1 = p->rho;
-        if (num > 0.0 && den > 0.0 && num <= INF && den <= INF) r1 = fmin(fmax(p->rho * sqrt(num / den), p->rho * 0.1), p->rho * 5.0);
+        double r1 = rho_cur;
+        if (num > 0.0 && den > 0.0 && num <= INF && den <= INF) r1 = fmin(fmax(rho_cur * sqrt(num / den), rho_cur * 0.1), rho_cur * 5.0);
+        rho_cur = r1;
         for (int i = 0; i < mr; ++i) rho[i] = (i % 5 == 4) ? r1 * p->rho_fz_scale : r1;   /* (restart: presolved path only, every row a stance row) */
-        iters_base = restart;
+        iters_base += cap;
     }
     }   /* pass */
     iters += iters_base;

@@ -84,6 +84,10 @@ class SrbdParams:
     # continues from its own (x, y) until max_iter iterations in total.  0 (or >= max_iter) = off = the default (100 solves
     # 99.9 % instead of 99.4 % of the config-2 QPs; on the GPU the second pass costs ~20 % of the batch throughput).
     rho_restart_iter: int = 0
+    # ... and at most this many of them, one every rho_restart_iter iterations, each from the rho of the pass before it (the clip is per step); the last pass runs
+    # to max_iter.  Round 3: three re-balancings 50 iterations apart solve 99.99 % of the N = 10 single-support QPs inside the 250-iteration cap, one solves
+    # 99.78 %, none 99.22 % (the one-wave kernel does them in place; every other kernel re-balances once, as a second launch).
+    rho_restart_count: int = 1
     # presolve: variables of swing contacts (force clamped to 0) are eliminated before the ADMM (kernel v2);
     # False = keep all 12N variables and clamp through the bounds (kernel v0/v1)
     eliminate_swing: bool = True
@@ -368,6 +372,15 @@ def auto_rho_fz_scale(N: int) -> float:
     return 4.0
 
 
+def default_restart(N: int, one_wave: bool = False):
+    """(rho_restart_iter, rho_restart_count) the engine picks by default (srbdqp.hip restart_iter_of): N > 10: one re-balancing after 100 (125 above N = 16)
+    iterations; N <= 10: two, 55 iterations apart, where the one-wave kernel runs the solve (at most 2 stance contacts per step, batches of 512 QPs and
+    more), none elsewhere."""
+    if N > 10:
+        return (100 if N <= 16 else 125), 1
+    return (55, 2) if one_wave else (0, 1)
+
+
 def params_for(N: int, **kw) -> SrbdParams:
     """SrbdParams as the engine runs horizon N by default (rho = auto_rho(N), rho_fz_scale = auto_rho_fz_scale(N) unless given)."""
     kw.setdefault("rho", auto_rho(N))
@@ -617,7 +630,7 @@ def presolve(qp, contact_hor):
 
 
 def restart_rho(p: SrbdParams, info):
-    """OSQP's rho update from the fp32 maxima of the last check, in double: rho sqrt((r_p/n_p)/(r_d/n_d)), clipped."""
+    """OSQP's rho update from the fp32 maxima of the last check, in double: rho sqrt((r_p/n_p)/(r_d/n_d)), clipped (p.rho = the rho of the pass that ended)."""
     num = float(info["r_prim"]) / max(float(info["n_prim"]), 1e-30)
     den = float(info["r_dual"]) / max(float(info["n_dual"]), 1e-30)
     if not (num > 0.0 and den > 0.0 and np.isfinite(num) and np.isfinite(den)):
@@ -630,15 +643,19 @@ def solve_with_restart(p: SrbdParams, P, q, A, l, u, x_init=None, y_init=None, d
     Returns (x, z, y, iters, status); iters counts both passes."""
     if p.rho_restart_iter <= 0 or p.rho_restart_iter >= p.max_iter:   # off, or the cap comes first
         return admm_solve(p, P, q, A, l, u, x_init, y_init, dtype=dtype)
-    info = {}
-    x, z, y, it, st = admm_solve(replace(p, max_iter=p.rho_restart_iter), P, q, A, l, u, x_init, y_init, dtype=dtype, info=info)
-    if st != STATUS_MAX_ITER:
-        return x, z, y, it, st
     s = dtype(p.force_scale)
-    xw = (x * s) / s          # the second pass re-reads the first pass's forces in newtons
-    x, z, y, it2, st = admm_solve(replace(p, rho=restart_rho(p, info), max_iter=p.max_iter - p.rho_restart_iter), P, q, A, l, u, xw, y,
-                                  dtype=dtype)          # the cap is on the total
-    return x, z, y, p.rho_restart_iter + it2, st
+    x, y, done, pc = x_init, y_init, 0, p
+    for k in range(max(int(p.rho_restart_count), 1) + 1):
+        left = p.max_iter - done                                   # the cap is on the total
+        cap = p.rho_restart_iter if (k < max(int(p.rho_restart_count), 1) and p.rho_restart_iter < left) else left
+        info = {}
+        x, z, y, it, st = admm_solve(replace(pc, max_iter=cap), P, q, A, l, u, x, y, dtype=dtype, info=info)
+        done += it
+        if st != STATUS_MAX_ITER or cap == left:
+            break
+        x = (x * s) / s                                            # the next pass re-reads the forces in newtons
+        pc = replace(pc, rho=restart_rho(pc, info))
+    return x, z, y, done, st
 
 
 def update(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None, warm=None, dtype=np.float64):
