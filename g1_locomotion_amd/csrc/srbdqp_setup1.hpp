@@ -207,13 +207,19 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
         const double* Cm = CP + mm * 9;
         const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2];
         double s1 = 0.0, s1t = 0.0, s2 = 0.0;
-        for (int i = mm; i < N; ++i) {
+        // (all N steps, the ones before m adding exact zeros: a loop from m has a trip count per lane, is not unrolled, and every trip waits for its own eight LDS
+        // reads -- ten round trips; this way the reads of all trips are in flight together)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
             const double* Ci = CP + i * 9;
-            s1 += Ci[pq] - Cm[pq];
-            s1t += Ci[qp] - Cm[qp];
+            const bool on = i >= mm;
+            const double a1 = Ci[pq] - Cm[pq], a1t = Ci[qp] - Cm[qp];
             const double d0p = Ci[p] - Cm[p], d1p = Ci[3 + p] - Cm[3 + p], d2p = Ci[6 + p] - Cm[6 + p];
             const double d0q = Ci[q] - Cm[q], d1q = Ci[3 + q] - Cm[3 + q], d2q = Ci[6 + q] - Cm[6 + q];
-            s2 += (w0 * d0p) * d0q + (w1 * d1p) * d1q + (w2 * d2p) * d2q;
+            const double a2 = (w0 * d0p) * d0q + (w1 * d1p) * d1q + (w2 * d2p) * d2q;
+            s1 += on ? a1 : 0.0;
+            s1t += on ? a1t : 0.0;
+            s2 += on ? a2 : 0.0;
         }
         T1[9 * mm + pq] = s1;
         T1[9 * mm + qp] = s1t;
@@ -228,11 +234,13 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
             const int j = e / 3, comp = e - 3 * j;
             const double* Cj = CP + j * 9;
             double acc = 0.0;
-            for (int i = j; i < N; ++i) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {   // (steps before j add exact zeros: see T1 / T2 above)
                 const double* Ci = CP + i * 9;
                 const double* v = vec + 12 * i;
-                acc += dt2 * ((Ci[comp] - Cj[comp]) * (SQ[0] * v[0]) + (Ci[3 + comp] - Cj[3 + comp]) * (SQ[1] * v[1]) +
-                              (Ci[6 + comp] - Cj[6 + comp]) * (SQ[2] * v[2])) + dt * (SQ[6 + comp] * v[6 + comp]);
+                const double term = dt2 * ((Ci[comp] - Cj[comp]) * (SQ[0] * v[0]) + (Ci[3 + comp] - Cj[3 + comp]) * (SQ[1] * v[1]) +
+                                           (Ci[6 + comp] - Cj[6 + comp]) * (SQ[2] * v[2])) + dt * (SQ[6 + comp] * v[6 + comp]);
+                acc += (i >= j) ? term : 0.0;
             }
             GV[9 * j + comp] = acc;
         }
@@ -241,10 +249,12 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
             if (e < 0) continue;
             const int j = e / 6, comp = 3 + (e - 6 * j);
             double acc = 0.0;
-            if (comp < 6) {
-                for (int i = j; i < N; ++i) acc += (double)(i - j) * vec[12 * i + comp];
-            } else {
-                for (int i = j; i < N; ++i) acc += vec[12 * i + 3 + comp];
+            const int off = (comp < 6) ? comp : 3 + comp;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double v = vec[12 * i + off];
+                const double term = (comp < 6) ? (double)(i - j) * v : v;
+                acc += (i >= j) ? term : 0.0;
             }
             GV[9 * j + comp] = acc;
         }
