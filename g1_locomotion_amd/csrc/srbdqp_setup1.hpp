@@ -53,7 +53,9 @@ struct Setup1Smem {
     static constexpr int o_scr = o_xref;
     static constexpr int endIn = o_pcom + up2(N * 3);
     static constexpr int endIn2 = (endIn > o_scr + 258) ? endIn : o_scr + 258;   // the tile + the spare slot of the K assembly
-    static constexpr int o_end = (endIn2 > o_cp + S::NT * 256) ? endIn2 : o_cp + S::NT * 256;   // K^-1 block-column staging (wave kernel)
+    static constexpr int kStgRow = 18;                    // row stride of the K^-1 staging tiles (16 + 2: the 16-byte row reads of 16 lanes hit 64 different banks)
+    static constexpr int kStgTile = 16 * kStgRow;
+    static constexpr int o_end = (endIn2 > o_cp + S::NT * kStgTile) ? endIn2 : o_cp + S::NT * kStgTile;   // K^-1 block-column staging (wave kernel)
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr bool supported = SplitWs<N, MAXS>::supported && S::NT <= 4;
     static_assert(n + 6 * N <= o_end - o_eh || true, "");
@@ -529,9 +531,10 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
     } else {
         // one K^-1 row per lane: for every block column cb all NT blocks (g, cb) are produced directly in C layout
         // ((g, cb) with g > cb is the same product with the operands swapped -- no transposes), staged as NT row-major
-        // tiles in the dead phase-A arrays, and lane (g, i) pulls row i of tile g with 16-byte reads
+        // tiles in the dead phase-A arrays, and lane (g, i) pulls row i of tile g with 16-byte reads (rows 18 doubles apart: with 16 the sixteen lanes of a
+        // read pass hit two banks, an 8-way conflict on every one of the 32 reads)
         double* stg = sm + L1::o_cp;
-        static_assert(L1::o_end - L1::o_cp >= NT * 256, "staging of one block column of K^-1");
+        static_assert(L1::o_end - L1::o_cp >= NT * L1::kStgTile, "staging of one block column of K^-1");
         const int grp = lane >> 4;
 #pragma unroll
         for (int cb = 0; cb < NT; ++cb) {
@@ -547,10 +550,10 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
                     for (int r = 0; r < 4; ++r) o = mfma_f64(wkg[r], wkc[r], o);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) stg[g * 256 + (kq + 4 * q) * 16 + mcol] = o[q];
+                for (int q = 0; q < 4; ++q) stg[g * L1::kStgTile + (kq + 4 * q) * L1::kStgRow + mcol] = o[q];
             }
             asm volatile("" ::: "memory");
-            const double2* rowp = reinterpret_cast<const double2*>(stg + grp * 256 + mcol * 16);
+            const double2* rowp = reinterpret_cast<const double2*>(stg + grp * L1::kStgTile + mcol * L1::kStgRow);
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 if (16 * cb + 2 * h + 1 < W::KS + 1) {
