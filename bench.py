@@ -141,12 +141,12 @@ def _auto_rho(N):
     return 0.7
 
 
-def _resolved_restart(N, it, cnt, max_iter, kname):
+def _resolved_restart(N, B, it, cnt, max_iter, kname):
     """what rho_restart_iter / rho_restart_count = 0 mean for this solve (srbdqp.h; srbdqp.hip restart_iter_of)"""
     wave = kname.startswith("wave_")
     auto = it == 0
     if auto:
-        it = (100 if N <= 16 else 125) if N > 10 else (55 if wave else 0)
+        it = (100 if N <= 16 else 125) if N > 10 else (55 if (wave and B >= 4096) else 0)
     if it <= 0 or it >= max_iter:
         return {"every": 0, "count": 0, "how": "off"}
     cnt = (cnt if cnt > 0 else (2 if auto else 1)) if wave else 1
@@ -470,7 +470,7 @@ def main(argv=None):
         extra["value_variants_note"] = ("value: %d streams + longest-first hint = the same batch's previous iteration counts; value_plain: 1 stream, no hint "
                                         "(strictly serial steps, natural QP order); value_stale_hint: %d streams, hint = the counts of a DIFFERENT "
                                         "batch (uncorrelated: a wrong hint only reorders work)" % (S, S))
-        if args.rho_restart == 0 and kname.startswith("wave_"):
+        if args.rho_restart == 0 and kname.startswith("wave_") and B >= 4096:
             # what the rho restart in place costs and buys: the same steps with it switched off (plain fixed-rho ADMM, the algorithm of rounds 1-2)
             import copy
             args_off = copy.copy(args); args_off.rho_restart = -1
@@ -506,7 +506,7 @@ def main(argv=None):
             out["config"].update({"eps_abs": max(c.eps_abs, 2e-6) if f32 else c.eps_abs, "eps_rel": max(c.eps_rel, 2e-6) if f32 else c.eps_rel,
                                   "rho": _auto_rho(N) if c.rho == 0 else c.rho, "rho_fz_scale": _auto_rho_fz(N) if c.rho_fz_scale == 0 else c.rho_fz_scale,
                                   "max_iter": int(c.max_iter), "rho_restart_iter": int(c.rho_restart_iter), "rho_restart_count": int(c.rho_restart_count),
-                                  "rho_restart_resolved": _resolved_restart(N, int(c.rho_restart_iter), int(c.rho_restart_count), int(c.max_iter), kname),
+                                  "rho_restart_resolved": _resolved_restart(N, B, int(c.rho_restart_iter), int(c.rho_restart_count), int(c.max_iter), kname),
                                   "set_up_dtype": "f64" if not f32 else "f64 assembly, f32 tiles (f64 tiles for QPs with a step of <= 2 stance contacts)"})
         if elapsed_other is not None:
             key = "value_without_allgather" if use_ag else "value_with_allgather"
@@ -670,7 +670,7 @@ def cpu_baseline(config, N, batch):
     import srbd_oracle as orc
     import c_oracle
     x0, xr, ft, ct = batch
-    r_iter, r_count = orc.default_restart(N, one_wave=CONFIGS[config]["maxs"] <= 2 and x0.shape[0] >= 512)
+    r_iter, r_count = orc.default_restart(N, one_wave=CONFIGS[config]["maxs"] <= 2 and x0.shape[0] >= 4096)
     p = orc.params_for(N, rho_restart_iter=r_iter, rho_restart_count=r_count)    # as the engine runs the config by default
     cores = _cpu_share()
     # sized for ~10-30 s of CPU work: N = 10 -> 4096 QPs x 24 (0.15 ms per QP and thread), N = 20 -> 1024 QPs x 2 (dense

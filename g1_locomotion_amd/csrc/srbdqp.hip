@@ -169,6 +169,7 @@ constexpr int kSplitMinBatch = 512;
 // mixed gait 13.9 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
 constexpr int kWrenchMinBatch = 768;      // re-measured at the end of round 2 (mixed gait, N = 10): 512 QPs 4.43 M QP/s compact / 4.17 M general,
                                           // 1024 QPs 6.12 M / 7.57 M -- up to two QPs per CU the 4-wave kernel's shorter set-up wins
+constexpr int kRestartMinBatch = 4096;         // the one-wave kernel's automatic rho restart in place: batches that fill the chip twice over (restart_iter_of)
 constexpr int kTail1MaxBatch = 8;              // staged calls of up to this many QPs on <= 2 stance contacts per step: the 4-wave set-up + one-wave iteration kernel
 constexpr int kStagedWrenchMinVars = 60;   // staged call: presolved variables (3 per stance contact) above which the wrench-space kernel's low-latency
                                           // instantiation wins (B = 1, N = 10: mixed gait, 72 variables, 74 us compact / 69 us; double support, 120, 107 / 69)
@@ -541,6 +542,8 @@ struct Carver {
 //    70 x 3 29.2, 0.9996, 0.27; 60 x 3 29.9 (another box), 0.9998; 50 x 3 29.5, 0.9999 -- every restarted QP repeats two thirds of a set-up, which is most of a
 //    solve at these sizes, and the slowest QP of a launch now carries up to two of them (a launch alone on the device lasts as long as its slowest QP:
 //    without the longest-first hint the step rate drops by a fifth);
+//    automatic for batches of 4096 QPs and more only: a restarted QP is a chain of up to 250 iterations and three set-ups (0.24 ms alone on the device), and a
+//    call cannot end before its slowest QP -- 512 QPs per call: 7.2 -> 5.2 M QP/s with the restart on; an explicit rho_restart_iter applies at every batch size;
 //  * the other N <= 10 solves: off (the batch kernels run 0.16 ms steps, where a second launch costs 15 %: DESIGN.md).
 inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B, bool wave = false, int* count = nullptr) {
     const srbdqp_config& c = h->cfg;
@@ -549,7 +552,7 @@ inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B, bool wave = 
     if (rk != SRBDQP_KERNEL_COMPACT && rk != SRBDQP_KERNEL_WRENCH) return 0;   // v0 / v1 have no restart
     int r = c.rho_restart_iter;
     const bool automatic = r == 0;
-    if (automatic) r = (c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : (wave ? 55 : 0);
+    if (automatic) r = (c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : ((wave && B >= kRestartMinBatch) ? 55 : 0);
     if (count && wave) *count = c.rho_restart_count > 0 ? c.rho_restart_count : (automatic ? 2 : 1);
     return (r > 0 && r < c.max_iter) ? r : 0;
 }

@@ -86,8 +86,8 @@ typedef struct srbdqp_config {
                                    * iterations is re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual))
                                    * (clipped to [rho/10, 5 rho]) and continues from its own (x, y) until max_iter
                                    * iterations in total; iters[] counts every pass.  < 0 or >= max_iter = off; 0 (default) =
-                                   * automatic: 100 (125 above N = 16) at N > 10; 55 where the one-wave kernel runs the solve
-                                   * (N <= 10, at most 2 stance contacts per step, batches of 512 QPs and more), which restarts
+                                   * automatic: 100 (125 above N = 16) at N > 10; 55 where the one-wave kernel runs the solve of a large batch
+                                   * (N <= 10, at most 2 stance contacts per step, batches of 4096 QPs and more), which restarts
                                    * in place; off for the other N <= 10 solves.  Everywhere else the restart is a second launch
                                    * over the same grid: the workgroup of a QP the first pass left at its cap continues it, every
                                    * other one leaves at once (every capped QP is continued). */

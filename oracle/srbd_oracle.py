@@ -374,8 +374,8 @@ def auto_rho_fz_scale(N: int) -> float:
 
 def default_restart(N: int, one_wave: bool = False):
     """(rho_restart_iter, rho_restart_count) the engine picks by default (srbdqp.hip restart_iter_of): N > 10: one re-balancing after 100 (125 above N = 16)
-    iterations; N <= 10: two, 55 iterations apart, where the one-wave kernel runs the solve (at most 2 stance contacts per step, batches of 512 QPs and
-    more), none elsewhere."""
+    iterations; N <= 10: two, 55 iterations apart, where the one-wave kernel runs the solve of a large batch (one_wave: at most 2 stance contacts per step and
+    4096 QPs or more per call), none elsewhere."""
     if N > 10:
         return (100 if N <= 16 else 125), 1
     return (55, 2) if one_wave else (0, 1)

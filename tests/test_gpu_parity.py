@@ -437,7 +437,7 @@ def test_restart_in_place_from_a_warm_start(torch_first, built_lib):
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=77, schedule="single")
     r_iter, r_count = orc.default_restart(N, one_wave=True)
     p = orc.params_for(N, rho_restart_iter=r_iter, rho_restart_count=r_count)
-    with BatchMPC(horizon=N, max_contacts_per_step=2) as eng:
+    with BatchMPC(horizon=N, max_contacts_per_step=2, rho_restart_iter=r_iter, rho_restart_count=r_count) as eng:   # (explicit: automatic from 4096 QPs per call)
         first = eng.solve(x0, xr, ft, ct, want_y=True)
         wu, wy = np.roll(first["u"].reshape(B, -1), 1, axis=0), np.roll(first["y"], 1, axis=0)
         out = eng.solve(x0, xr, ft, ct, warm_u=wu, warm_y=wy)
