@@ -390,20 +390,26 @@ def test_rho_restart_matches_the_oracle(torch_first, built_lib, kernel):
         assert np.abs(out["u"][b].reshape(-1) - xs * p.force_scale).max() <= TOL_EXACT_N
 
 
-@pytest.mark.parametrize("N,every,count", [(10, 0, 0), (10, 40, 4), (8, 0, 0), (4, 50, 2)])
-def test_one_wave_kernel_restarts_in_place(torch_first, built_lib, N, every, count):
+@pytest.mark.parametrize("N,every,count,schedule", [(10, 0, 0, "single"), (10, 40, 4, "single"), (8, 0, 0, "single"), (4, 50, 2, "single"),
+                                                    (4, 25, 3, "double")])     # (the last: 4 contacts per step, EVERY QP past the first mark)
+def test_one_wave_kernel_restarts_in_place(torch_first, built_lib, N, every, count, schedule):
     """The one-wave kernel re-balances rho IN PLACE (srbdqp_setup1.hpp RST): every rho_restart_iter iterations, up to rho_restart_count times, each time
     from the rho of the pass that ended, inside the same cap on the total.  By default (0, 0 -> 55, 2) wherever that kernel runs the solve: 99.3 % -> 99.9 % of the
     configs[1] QPs solved.  Same rule in both oracles; the restarted QPs end within the exact-optimum tolerance."""
     import c_oracle
     from g1_locomotion_amd import BatchMPC
     B = 4096
-    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=1000, schedule="single")
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=1000, schedule=schedule)
     p = orc.params_for(N, rho_restart_iter=every or 55, rho_restart_count=count or 2)
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     plain = c_oracle.solve_batch(orc.params_for(N), x0, xr, ft, ct, nthreads=8)
     kw = {} if every == 0 else dict(rho_restart_iter=every, rho_restart_count=count)
-    with BatchMPC(horizon=N, max_contacts_per_step=2, **kw) as eng:
+    from g1_locomotion_amd import _lib
+    if schedule != "single":   # (4 contacts per step: AUTO sends batches of this size to the general kernel)
+        kw.update(kernel=_lib.KERNEL_WAVE, max_contacts_per_step=4)
+    else:
+        kw.update(max_contacts_per_step=2)
+    with BatchMPC(horizon=N, **kw) as eng:
         out = eng.solve(x0, xr, ft, ct)
         assert eng.kernel_name().startswith("wave_"), eng.kernel_name()
     solved = (out["status"] == orc.STATUS_SOLVED).mean()
