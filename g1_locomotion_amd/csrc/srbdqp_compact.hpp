@@ -121,6 +121,9 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     constexpr int n = Dims<N>::n, m = Dims<N>::m;
     constexpr int LPR = S::LPR;
     constexpr int RB = LPR * CHMAX + 8;                // one rhs buffer
+    // chunk stride of the rhs vector: the LPR = 4 lanes of a row read their chunks with 16-byte reads CH doubles apart -- at CH = 16 (N = 10, 20 stance contacts)
+    // two of the four sit on the same banks; 18 apart they do not (the 8 spare doubles of the buffer hold the extra 3 x 2)
+    const int CHS = (LPR == 4 && (CH & 15) == 0 && LPR * (CH + 2) <= RB) ? CH + 2 : CH;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int lr = lane / LPR, hp = lane % LPR;        // row slot in the wave, part of the row this lane multiplies
     const int h = hp & 1;
@@ -132,6 +135,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     const int base = 3 * LPR * cg;
     const int gc = active ? act[e] : 0;                // original contact index 4 k + ci
     const int r = active ? 3 * e + ax : 0;             // compact variable
+    const int rpos = (r / CH) * CHS + (r % CH);        // ... and its slot in the chunked rhs vector
     const bool has_row = active && prim && (ax < 2 || h == 0);
     const int j = (ax < 2) ? 2 * ax + h : 4;
     const int irow = 5 * gc + j;                       // original row index (for warm_y / y_out)
@@ -171,7 +175,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     block_max<1>(qn, sm + S::o_red);                    // its barriers also order the zero fill above
     {
         const double rhs0 = sigma * x - qv + At(rowm * (rho * z - y));
-        if (active && hp == 0) rhsbuf[r] = rhs0;
+        if (active && hp == 0) rhsbuf[rpos] = rhs0;
     }
     if (t < 4) reinterpret_cast<int*>(redf + 32)[t] = 0;
     __syncthreads();
@@ -216,7 +220,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                 // round trip EVERY iteration).  Columns past CH read the zero padding and meet kin = 0.
                 constexpr int NV = CHMAX / 2, BL = (NV <= 8) ? NV : 8, NBMAX = (NV + BL - 1) / BL;   // 8 ds_read_b128 in flight
                 double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-                const double2* rv = reinterpret_cast<const double2*>(rb + CH * hp);
+                const double2* rv = reinterpret_cast<const double2*>(rb + CHS * hp);
 #pragma unroll
                 for (int blk = 0; blk < NBMAX; ++blk) {
                     if (blk == 0 || blk * 2 * BL < CH) {                       // wave-uniform
@@ -250,7 +254,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
             const double atw = At(rho * z - y);
             cpx = alpha * (sigma * (x - xt) - qv) + oma * cpx;
             x = alpha * xt + oma * x;
-            if (active && hp == 0) wb[r] = sigma * x - qv + atw;
+            if (active && hp == 0) wb[rpos] = sigma * x - qv + atw;
             ADMM_T(tp3);
             if (pretest) {   // one ballot instead of a reduction: does any row still violate the last e_prim?
                 const unsigned long long bad = __ballot(has_row && !(fabs(axr - z) <= e_prim_last));
