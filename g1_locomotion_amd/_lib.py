@@ -32,7 +32,7 @@ EXPORTS = (
     "srbdqp_assemble_f64", "srbdqp_assemble_wrench_f64",
     "srbdqp_ragged_create", "srbdqp_ragged_destroy", "srbdqp_ragged_last_error", "srbdqp_solve_ragged_device_f64", "srbdqp_solve_ragged_f64",
     "srbdqp_solve_ragged_device_f32", "srbdqp_solve_ragged_f32", "srbdqp_solve_ragged_warm_device_f64", "srbdqp_solve_ragged_warm_device_f32",
-    "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
+    "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_update_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
     "srbdqp_mpc_inputs_f64", "srbdqp_mpc_inputs_device_f64",
@@ -152,6 +152,8 @@ def load():
     lib.srbdqp_stage_ptrs.restype = C.c_int
     lib.srbdqp_solve_staged_f64.argtypes = [H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.srbdqp_solve_staged_f64.restype = C.c_int
+    lib.srbdqp_update_f64.argtypes = [H, dp, dp, dp, u8p, dp, dp, dp, dp, i32p, i32p]
+    lib.srbdqp_update_f64.restype = C.c_int
     lib.srbdqp_prepare_staged_f64.argtypes = [H, C.c_int32, C.c_int32]
     lib.srbdqp_prepare_staged_f64.restype = C.c_int
     lib.srbdqp_solve_prepared_f64.argtypes = [H, C.c_int32, C.c_int32, C.c_int32]
@@ -184,8 +186,23 @@ def load():
     return lib
 
 
+_raw = None
+
+
+def load_raw():
+    """A second ctypes view of the same library whose functions carry NO argtypes: a call with pre-built c_void_p arguments skips the
+    per-argument conversion (0.37 us instead of 0.82 us for srbdqp_update_f64's eleven arguments).  Only for call sites that bind
+    every argument once as a ctypes object -- MPC.update(); an int passed here would be truncated to 32 bits."""
+    global _raw
+    if _raw is None:
+        load()
+        _raw = C.CDLL(LIB_PATH)
+    return _raw
+
+
 def default_config() -> Config:
     cfg = Config()
+    cfg.struct_size = C.sizeof(Config)        # the library checks it BEFORE it writes (include/srbdqp.h)
     rc = load().srbdqp_default_config(C.byref(cfg))
     if rc != OK:
         raise SrbdqpError(f"srbdqp_default_config failed ({rc})")

@@ -67,6 +67,7 @@ struct srbdqp_handle {
     bool staged_call = false;      // inside srbdqp_solve_staged_f64 (with or without the completion word)
     int staged_neff = 0;           // ... with the largest number of presolved variables (3 x stance contacts) among its QPs
     bool lazy_restart = false;     // staged path: run only the first pass; the host starts the second one if a status asks for it
+    bool lazy_pending = false;     // ... and the last solve really was such a first pass: last_args are its arguments
     int32_t prepared_B = 0; int prepared_maxs = 4; bool prepared_pcom = false;   // two-phase call: a set-up is pending
     KArgs last_args;               // arguments of that first pass (for the lazily started second pass)
     // kernels whose dynamic-LDS limit has been raised on this handle's device (function attributes are per device, and a
@@ -192,7 +193,8 @@ inline bool uses_wrench(const srbdqp_handle* h, int maxs, int B) {
     // wrench-space problem is 60 x 60 against the 120 x 120 dense K of the compact kernel (round 3, tools/latency_patterns.py:
     // B = 1 double support p50 82 us against 112 us)
     if (h->cfg.kernel != SRBDQP_KERNEL_AUTO || maxs <= 2 || h->stamps) return false;
-    return B >= kWrenchMinBatch || (h->staged_call && N >= 8 && h->staged_neff > kStagedWrenchMinVars);
+    // (the low-latency instantiation is one workgroup per CU, tuned and measured at B = 1: the same bound as the compact kernel's TAIL1 path)
+    return B >= kWrenchMinBatch || (h->staged_call && B <= kTail1MaxBatch && N >= 8 && h->staged_neff > kStagedWrenchMinVars);
 }
 
 // does a solve of B QPs on this handle run on the one-wave kernel (launch_wave)?  launch_compact() and the restart plan (solve_device_impl) ask this.
@@ -414,7 +416,7 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
             // staged batch-1 path (completion word): the low-latency instantiation -- two extra waves for the set-up (tables, T
             // assembly, tile phases) that end before the iterations, one workgroup's worth of registers (no scratch, V in
             // registers, every broadcast read of the T^-1 product in flight).  tools/latency_patterns.py
-            if (a.done_flag && !(h->cfg.flags & SRBDQP_FLAG_NO_LAT)) {
+            if (a.done_flag && a.B <= kTail1MaxBatch && !(h->cfg.flags & SRBDQP_FLAG_NO_LAT)) {
                 constexpr int XW = (N >= 8) ? 2 : 1;
                 using SL = srbdqp::WrenchSmem<N, 8, 5, XW>;
                 constexpr size_t ldsl = SL::bytes;
@@ -601,6 +603,9 @@ const char* srbdqp_version(void) { return "srbdqp 0.1 (gfx950, fp64)"; }
 
 int srbdqp_default_config(srbdqp_config* c) {
     if (!c) return SRBDQP_E_INVALID;
+    // the caller says how large ITS struct is: a binding built against an older header (a shorter struct) is refused here instead of
+    // being written past its end
+    if (c->struct_size != (int32_t)sizeof(srbdqp_config)) { g_create_err = "srbdqp_default_config: set cfg->struct_size = sizeof(srbdqp_config) before the call (ABI check)"; return SRBDQP_E_INVALID; }
     std::memset(c, 0, sizeof(*c));
     c->struct_size = (int32_t)sizeof(srbdqp_config);
     c->horizon = 10;
@@ -780,7 +785,8 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     if (rc != SRBDQP_OK) return rc;
     rc = wait_done();
     if (rc != SRBDQP_OK) return rc;
-    if (restart_iter_of(h, maxs, B) && !h->stamps) {
+    if (h->lazy_pending) {          // the solve above was the first pass of a two-pass solve (not: restarted in place, or no restart at all)
+        h->lazy_pending = false;
         bool capped = false;
         for (int32_t q = 0; q < B; ++q) capped |= (h->stage_h.status[q] == SRBDQP_MAX_ITER);
         if (capped) {
@@ -791,6 +797,28 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
         }
     }
     return rc;
+}
+
+int srbdqp_update_f64(srbdqp_handle* h, const double* x0, const double* x_ref, const double* foot, const uint8_t* contact,
+                      const double* pcom, double* u0_out, double* u_out, double* x_out, int32_t* status, int32_t* iters) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (!x0 || !x_ref || !foot || !contact || !u0_out) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
+    const size_t N = (size_t)h->cfg.horizon;
+    const srbdqp_stage& s = h->stage_h;
+    // into the pinned, GPU-mapped staging arrays (2.4 KB at N = 10; an argument that IS the staging array is left where it is)
+    if (x0 != s.x0) std::memcpy(s.x0, x0, 13 * sizeof(double));
+    if (x_ref != s.x_ref) std::memcpy(s.x_ref, x_ref, N * 13 * sizeof(double));
+    if (foot != s.foot) std::memcpy(s.foot, foot, N * 12 * sizeof(double));
+    if (contact != s.contact) std::memcpy(s.contact, contact, N * 4);
+    if (pcom && pcom != s.pcom) std::memcpy(s.pcom, pcom, N * 3 * sizeof(double));
+    const int rc = srbdqp_solve_staged_f64(h, 1, pcom != nullptr, 0, x_out != nullptr, 0);
+    if (rc != SRBDQP_OK) return rc;
+    if (u0_out != s.u) std::memcpy(u0_out, s.u, 12 * sizeof(double));
+    if (u_out && u_out != s.u) std::memcpy(u_out, s.u, N * 12 * sizeof(double));
+    if (x_out && x_out != s.x) std::memcpy(x_out, s.x, (N + 1) * 13 * sizeof(double));
+    if (status) *status = s.status[0];
+    if (iters) *iters = s.iters[0];
+    return SRBDQP_OK;
 }
 
 namespace {
@@ -933,6 +961,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
         a.perm = slot->perm;
     }
     int maxs = h->maxs_override ? h->maxs_override : (h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 4);
+    h->lazy_pending = false;
     const bool wave = uses_wave(h, maxs, B, a.stamps != nullptr, a.done_flag != nullptr);
     int rcount = 1;
     const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h, maxs, B, wave, &rcount);
@@ -953,7 +982,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
     if (!a1.status) a1.status = slot->stbuf;
     if (!lazy) { a1.done_flag = nullptr; a1.done_count = nullptr; }
     rc = launch(h, a1, lst, maxs, lazy ? 0 : 1);
-    if (lazy) h->last_args = a1;
+    if (lazy) { h->last_args = a1; h->lazy_pending = (rc == SRBDQP_OK); }
     if (rc != SRBDQP_OK || lazy) return rc;
     return srbdqp_restart_pass(h, a1, lst, maxs, a.done_flag != nullptr);
 }
@@ -1128,6 +1157,7 @@ int srbdqp_assemble_f64(srbdqp_handle* h, int32_t B, const double* x0, const dou
         std::fill(qq, qq + n, 0.0);
         if (nad < 0.0) { h->err = "a QP of the batch violates max_contacts_per_step"; return SRBDQP_E_INVALID; }
         const int na = (int)nad, ne = 3 * na;
+        if (na == 0) { mp[12 * N] = -srbdqp::kInf; mp[12 * N + 1] = 0.0; }   // flight phase: the kernel leaves before it dumps the friction-row bounds
         for (int r = 0; r < ne; ++r) {
             const int vr = 3 * (int)mp[r / 3] + r % 3;
             qq[vr] = qc[r];

@@ -113,7 +113,9 @@ typedef struct srbdqp_config {
 
 typedef struct srbdqp_handle srbdqp_handle;
 
-/* Fill *cfg with the defaults (N=10, dt=0.04, G1 constants, ADMM constants). */
+/* Fill *cfg with the defaults (N=10, dt=0.04, G1 constants, ADMM constants).  cfg->struct_size must hold sizeof(srbdqp_config) of
+ * the CALLER's build on entry (ABI check): a binding made against an older, shorter struct gets SRBDQP_E_INVALID back and nothing is
+ * written (srbdqp_last_error(NULL) says why). */
 int srbdqp_default_config(srbdqp_config* cfg);
 
 /* ~ MPC(dt) + MPC.init_matrices() (run_simulation.py:169-170): allocate stream + workspace. */
@@ -266,6 +268,19 @@ typedef struct srbdqp_stage {
 } srbdqp_stage;
 int srbdqp_stage_ptrs(srbdqp_handle* h, srbdqp_stage* out);
 int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32_t use_warm, int32_t want_x, int32_t want_y);
+
+/* ~ MPC.update(contact_horizon, c_horizon, p_com_horizon, x_current, one_rollout) -> (u_opt0, x_opt1) for ONE robot at control rate
+ * (run_simulation.py:106,111) in ONE call: copies the inputs into the staging arrays, launches the batch-1 kernel, spins on its
+ * completion word and copies the results out.  What a binding of the reference's duck-typed object binds for its update() method.
+ *   x0 [13]   x_ref [N][13]   foot [N][12]   contact [N][4]   pcom [N][3] or NULL (-> x_ref[:, 3:6])       HOST pointers
+ *   u0_out [12]      u_opt0: the first step's forces, newtons (run_simulation.py:111)
+ *   u_out  [N][12]   the whole plan, may be NULL
+ *   x_out  [N+1][13] the roll-out (row 1 = x_opt1[1], the next state), may be NULL
+ *   status, iters    solver outcome of this QP (SRBDQP_SOLVED, ...), may be NULL
+ * An argument that IS the matching array of srbdqp_stage_ptrs() is used in place (no copy): that is how g1_locomotion_amd/mpc.py
+ * calls it, with every argument bound once.  Returns SRBDQP_OK whenever the solve ran; the QP's own outcome is *status. */
+int srbdqp_update_f64(srbdqp_handle* h, const double* x0, const double* x_ref, const double* foot, const uint8_t* contact,
+                      const double* pcom, double* u0_out, double* u_out, double* x_out, int32_t* status, int32_t* iters);
 
 /* Two-phase form of the staged call, for control loops that know the contact schedule, the contact-point positions and the
  * reference horizon BEFORE the state estimate arrives.  K (and its factorisation) depends on neither x0 nor x_ref's non-yaw

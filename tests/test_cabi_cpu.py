@@ -113,3 +113,52 @@ def test_mpc_object_keeps_the_reference_surface():
     MPC.x_ref_hor[0:, 3:6] = [5.26790425e-02, 7.44339342e-05, 5.97983255e-01]
     for name in ("init_matrices", "update", "solve"):
         assert callable(getattr(MPC, name))
+
+
+def _stub():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ctypes_stub", os.path.join(ROOT, "examples", "ctypes_stub.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_documented_ctypes_stub_matches_the_library(built_lib):
+    """INTEGRATION.md section 2 shows examples/ctypes_stub.py verbatim: its struct must be the library's struct, field for field, and
+    the document must really contain the file."""
+    from g1_locomotion_amd import _lib
+    stub = _stub()
+    lib = stub.load()
+    cfg = stub.default_config(lib)
+    assert C.sizeof(stub.Config) == cfg.struct_size == C.sizeof(_lib.Config)
+    assert [(n, t) for n, t in stub.Config._fields_] == [(n, t) for n, t in _lib.Config._fields_]
+    full = _lib.default_config()
+    assert bytes(cfg) == bytes(full)
+    # the header's struct, field by field, in order
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "srbdqp.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct srbdqp_config \{(.*?)\} srbdqp_config;", hdr, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            for part in decl.split(None, 1)[1].split(","):
+                names.append(re.match(r"\s*(\w+)", part).group(1))
+    assert names == [n for n, _ in stub.Config._fields_]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(ROOT, "examples", "ctypes_stub.py")).read()
+    assert src.strip() in doc, "INTEGRATION.md section 2 no longer shows examples/ctypes_stub.py verbatim"
+
+
+def test_default_config_refuses_a_struct_of_another_size(built_lib):
+    """A binding built against an older header passes a shorter struct: nothing may be written past it."""
+    from g1_locomotion_amd import _lib
+    buf = (C.c_char * (C.sizeof(_lib.Config) + 64))()
+    C.memset(buf, 0x5A, len(buf))
+    cfg = C.cast(buf, C.POINTER(_lib.Config))
+    for claimed in (C.sizeof(_lib.Config) - 8, 0, 8, C.sizeof(_lib.Config) + 8):
+        cfg.contents.struct_size = claimed
+        assert built_lib.srbdqp_default_config(cfg) == _lib.E_INVALID
+        assert bytes(buf)[4:] == b"\x5a" * (len(buf) - 4), "srbdqp_default_config wrote into a struct it refused"
+    cfg.contents.struct_size = C.sizeof(_lib.Config)
+    assert built_lib.srbdqp_default_config(cfg) == _lib.OK
+    assert bytes(buf)[C.sizeof(_lib.Config):] == b"\x5a" * 64

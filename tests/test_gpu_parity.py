@@ -783,3 +783,154 @@ def test_ragged_f32_and_warm_start_entry_points(torch_first, built_lib):
     o64 = ref64.solve_packed(Nq, x0, xr, ft, ct)
     ref64.close()
     np.testing.assert_array_equal(o64["u"], u.cpu().numpy())
+
+
+GOLDEN_CASES = [("n10_single_a", 10), ("n10_single_b", 10), ("n10_double", 10), ("n10_mixed", 10), ("n8_mixed", 8), ("n4_single", 4)]
+
+
+@pytest.mark.parametrize("path", ["staged", "batch", "wave", "wrench"])
+@pytest.mark.parametrize("name,N", GOLDEN_CASES)
+def test_committed_golden_fixtures_gate_the_kernels(torch_first, built_lib, name, N, path):
+    """tests/golden/srbd_qp_golden.npz (inputs -> exact optimum u*, made by tests/golden/make_golden.py) through the HIP path itself: the
+    staged batch-1 call (MPC.update), the host-buffer batch call, the one-wave batch kernel and the general kernel.  Forces against the
+    frozen exact optimum and the frozen ADMM twin, KKT residuals of the returned primal / dual pair."""
+    import os
+    from g1_locomotion_amd import _lib, mpc
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "srbd_qp_golden.npz"))
+    x0, xr, ft, ct = (gold[f"{name}/{k}"] for k in ("x0", "x_ref", "foot", "contact"))
+    u_exact, u_admm, it_admm = gold[f"{name}/u_exact"], gold[f"{name}/u_admm"], int(gold[f"{name}/iters_admm"])
+    p = orc.SrbdParams()
+    capped = it_admm >= p.max_iter                                   # n10_mixed: the twin itself ends at the cap, 0.055 N from the optimum
+    if path == "staged":
+        M = mpc.MPC(dt=0.04, horizon=N, strict=False)
+        M.init_matrices()
+        M.x_ref_hor[:] = xr
+        u0, xo = M.update(list(ct), list(ft), xr[:, 3:6].copy(), x_current=x0.reshape(13, 1))
+        u, x, status, iters, y = M.u_opt, M.x_opt, M.status, M.iters, None
+        assert np.array_equal(u0.reshape(-1), u[0]) and np.array_equal(xo, x)
+        M.close()
+    else:
+        if path == "wave" and not (name.startswith("n10_single") or N == 4):
+            pytest.skip("the one-wave kernel holds at most 64 presolved variables")
+        kid = {"batch": _lib.KERNEL_AUTO, "wave": _lib.KERNEL_WAVE, "wrench": _lib.KERNEL_WRENCH}[path]
+        with _engine(N, kernel=kid) as eng:
+            out = eng.solve(x0[None], xr[None], ft[None], ct[None], want_y=True)
+            assert eng.kernel_name().startswith({"batch": "compact_", "wave": "wave_", "wrench": "wrench_"}[path]), eng.kernel_name()
+        u, x, status, iters, y = out["u"][0], out["x"][0], int(out["status"][0]), int(out["iters"][0]), out["y"][0]
+    assert status == (orc.STATUS_MAX_ITER if capped else orc.STATUS_SOLVED)
+    assert abs(iters - it_admm) <= p.check_every, (iters, it_admm)
+    assert np.abs(u - u_admm).max() <= (TOL_TWIN_N if not capped else 2e-2)
+    assert np.abs(u - u_exact).max() <= (TOL_EXACT_N if not capped else 0.1)
+    assert np.abs(x - gold[f"{name}/x_exact"]).max() <= (1e-4 if not capped else 1e-3)
+    if y is not None:
+        qp = orc.build_qp(p, x0, xr, ft, ct)
+        red, vi, ri = orc.presolve(qp, ct)
+        kr = orc.kkt_residuals(red["P"], red["q"], red["A"], red["l"], red["u"], u.reshape(-1)[vi] / p.force_scale, y[ri])
+        assert kr["primal"] <= (1e-4 if not capped else 1e-2) and kr["stationarity"] <= 1e-3 * max(1.0, np.abs(qp["q"]).max()), kr
+
+
+def test_documented_ctypes_stub_solves_a_qp(torch_first, built_lib):
+    """examples/ctypes_stub.py (verbatim) against the oracle: the reference's own call pattern, one QP."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ctypes_stub", os.path.join(root, "examples", "ctypes_stub.py"))
+    stub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stub)
+    N = 10
+    x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=56, schedule="double"))
+    M = stub.MPC(dt=0.04)
+    M.init_matrices()
+    ref = orc.update(orc.SrbdParams(), x0, xr, ft, ct, pcom_hor=xr[:, 3:6])
+    for pc in (xr[:, 3:6].copy(), None):
+        u0, x1 = M.update([np.array([1, 1, 1, 1])] * N, list(ft), pc, x0.reshape(13, 1), xr)
+        assert M.status == ref["status"] == orc.STATUS_SOLVED and abs(M.iters - ref["iters"]) <= 5
+        assert u0.shape == (12, 1) and x1.shape == (N + 1, 13)
+        assert np.abs(u0.reshape(-1) - ref["u"][0]).max() <= TOL_TWIN_N and np.abs(x1 - ref["x"]).max() <= 1e-5
+    M.close()
+
+
+def test_mpc_update_fast_path_equals_the_general_path(torch_first, built_lib):
+    """MPC.update() binds srbdqp_update_f64 once and gathers straight into the staging arrays; lists of per-step arrays (the reference's
+    call, run_simulation.py:94-101), whole arrays and irregular inputs (nested lists -> the general path) must all give the same QP."""
+    from g1_locomotion_amd import mpc
+    N = 10
+    x0s, xrs, fts, cts = orc.synthetic_batch(6, N, seed=57, schedule="mixed")
+    M = mpc.MPC(dt=0.04)
+    M.init_matrices()
+    for b in range(6):
+        x0, xr, ft, ct = x0s[b], xrs[b], fts[b], cts[b]
+        M.x_ref_hor[:] = xr
+        M.x0[:] = x0.reshape(13, 1)
+        ref = orc.update(orc.SrbdParams(), x0, xr, ft, ct, pcom_hor=xr[:, 3:6])
+        got = []
+        for contact_h, c_h, pc, xc in ((list(ct.astype(np.int64)), list(ft), xr[:, 3:6].copy(), M.x0),      # the reference's form
+                                      (ct, ft, xr[:, 3:6], None),                                          # arrays, x_current defaulted
+                                      (ct.tolist(), ft.tolist(), xr[:, 3:6].tolist(), x0.tolist()),        # nested lists: general path
+                                      (list(ct), list(ft), None, x0.reshape(13, 1))):                      # no CoM horizon: x_ref[:, 3:6]
+            u0, x1 = M.update(contact_h, c_h, pc, x_current=xc, one_rollout=True)
+            assert u0.shape == (12, 1) and x1.shape == (N + 1, 13) and M.status == ref["status"]
+            got.append((u0.copy(), x1.copy(), M.iters))
+            assert np.array_equal(M.u_opt[0], u0.reshape(-1)) and np.array_equal(M.x_opt, x1)
+            u0b, x1b = M.update(contact_h, c_h, pc, x_current=xc, one_rollout=False)
+            assert x1b.shape == (2, 13) and np.array_equal(x1b, x1[:2]) and np.array_equal(u0b, u0)
+        for u0, x1, it in got[1:]:
+            assert np.array_equal(u0, got[0][0]) and np.array_equal(x1, got[0][1]) and it == got[0][2]
+        assert np.abs(got[0][0].reshape(-1) - ref["u"][0]).max() <= TOL_TWIN_N
+    M.close()
+
+
+def test_staged_call_after_an_in_place_restart_does_not_replay_a_stale_second_pass(torch_first, built_lib):
+    """Advisor finding (round 3): a staged NO_SPIN call of >= 512 QPs with an explicit rho_restart_iter lands on the one-wave kernel, which
+    restarts in place; the host must not start a second pass from the arguments of an EARLIER lazy staged call on the same handle."""
+    from g1_locomotion_amd import BatchMPC, _lib
+    import c_oracle
+    N = 10
+    x0, xr, ft, ct = orc.synthetic_batch(600, N, seed=1000, schedule="single")
+    p = orc.params_for(N, rho_restart_iter=60, rho_restart_count=1)
+    ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=4)
+    assert (ref["iters"] > 60).sum() >= 2                      # the restart really happens in this batch
+    with BatchMPC(horizon=N, kernel=_lib.KERNEL_WAVE, flags=_lib.FLAG_NO_SPIN, rho_restart_iter=60, rho_restart_count=1, max_contacts_per_step=2) as eng:
+        # staging capacity is small: raise it by going through the host-buffer API for the big batch, and use the staged call with
+        # its capacity for the lazy two-pass solve that leaves last_args behind
+        st = eng.stage()
+        cap = st["capacity"]
+        hard = np.argsort(-ref["iters"])[:cap]
+        for k, b in enumerate(hard):
+            st["x0"][k] = x0[b]; st["x_ref"][k] = xr[b]; st["foot"][k] = ft[b]; st["contact"][k] = ct[b]
+        eng.solve_staged(cap, want_x=True)                      # wave kernel forced: restarts in place, nothing lazy may be pending
+        assert eng.kernel_name().startswith("wave_")
+        first = (st["u"][:cap].copy(), st["iters"][:cap].copy(), st["status"][:cap].copy())
+        assert np.array_equal(first[2], ref["status"][hard]) and np.abs(first[1] - ref["iters"][hard]).max() <= 5
+        assert first[1].max() <= p.max_iter
+        assert np.abs(first[0] - ref["u"][hard]).max() <= 5e-3
+    # the same through a handle that HAS a stale lazy first pass behind it (4-wave kernel, two-pass restart), then the wave kernel
+    with BatchMPC(horizon=N, flags=_lib.FLAG_NO_SPIN, rho_restart_iter=60, rho_restart_count=1) as eng:
+        st = eng.stage()
+        cap = st["capacity"]
+        hard = np.argsort(-ref["iters"])[:cap]
+        for k, b in enumerate(hard):
+            st["x0"][k] = x0[b]; st["x_ref"][k] = xr[b]; st["foot"][k] = ft[b]; st["contact"][k] = ct[b]
+        eng.solve_staged(cap, want_x=True)                      # compact kernel: lazy first pass + host-started second pass
+        assert eng.kernel_name().startswith("compact_")
+        a = (st["u"][:cap].copy(), st["iters"][:cap].copy(), st["status"][:cap].copy())
+        eng.solve_staged(2, want_x=True)                        # again, fewer QPs: must not replay the 16-QP pass
+        assert np.array_equal(st["iters"][:2], a[1][:2]) and np.array_equal(st["u"][:2], a[0][:2])
+        assert np.array_equal(a[2], ref["status"][hard]) and np.abs(a[1] - ref["iters"][hard]).max() <= 5
+
+
+@pytest.mark.parametrize("kernel", ["compact", "wave"])
+def test_assembly_of_a_flight_phase_qp(torch_first, built_lib, kernel):
+    """A QP without a stance contact leaves the dump kernels before they write the friction-row bounds: the host must still report the
+    rows the oracle assembles (-inf <= friction rows <= 0, 0 <= fz <= 0), not the memset zeros (advisor finding, round 3)."""
+    from g1_locomotion_amd import _lib
+    N, B = 10, 3
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=101, schedule="single")
+    ct[1] = 0
+    with _engine(N, kernel=_lib.KERNEL_WAVE if kernel == "wave" else _lib.KERNEL_COMPACT) as eng:
+        got = eng.assemble(x0, xr, ft, ct)
+    p = orc.params_for(N)
+    for b in range(B):
+        qp = orc.build_qp(p, x0[b], xr[b], ft[b], ct[b])
+        np.testing.assert_array_equal(got["l"][b], qp["l"])
+        np.testing.assert_array_equal(got["u"][b], qp["u"])
+    assert np.all(got["P"][1] == 0.0) and np.all(got["q"][1] == 0.0)

@@ -86,10 +86,13 @@ def test_golden_vectors_are_reproduced(gold, name, N):
     tw = orc.update(p, x0, xr, ft, ct)
     assert tw["iters"] == int(gold[f"{name}/iters_admm"])
     assert np.abs(tw["u"] - gold[f"{name}/u_admm"]).max() < 1e-7
-    if tw["status"] == orc.STATUS_SOLVED:      # (n10_mixed ends at the 250-iteration cap, flagged MAX_ITER: held to its frozen iterate only)
-        assert np.abs(tw["u"] - gold[f"{name}/u_exact"]).max() < 5e-2      # ADMM at eps 1e-6 vs exact optimum [N]
+    # distance of the ADMM result from the exact optimum [N]: 5e-3 for the solved cases (measured 1e-4 ... 2.8e-3 with the (0.7, 4) penalties:
+    # a later penalty retune cannot drift past that unnoticed; the GPU tests allow 5e-2), 0.1 for the one case that ends at the 250-iteration
+    # cap (n10_mixed, flagged MAX_ITER: 0.055 N)
+    if tw["status"] == orc.STATUS_SOLVED:
+        assert np.abs(tw["u"] - gold[f"{name}/u_exact"]).max() < 5e-3
     else:
-        assert tw["status"] == orc.STATUS_MAX_ITER and np.abs(tw["u"] - gold[f"{name}/u_exact"]).max() < 0.5
+        assert tw["status"] == orc.STATUS_MAX_ITER and np.abs(tw["u"] - gold[f"{name}/u_exact"]).max() < 0.1
 
 
 @pytest.mark.parametrize("name,N", CASES)
