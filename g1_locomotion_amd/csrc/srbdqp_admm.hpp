@@ -71,24 +71,44 @@ __device__ __forceinline__ double bperm_f64(double v, int src_lane) {   // value
 // broadcast ds_read_b128s + v_fmac_f64) on a 64 x 64 row-per-lane product, tools/dpp_probe.hip: 545 against 781 cycles per
 // product for one wave alone, 666 against 1082 with 8 waves per CU -- the broadcast reads of 8 resident QPs keep the CU's LDS
 // pipeline busier than its vector ALUs.
-// (The first use of a chunk carries two wait states in front: a VGPR written by a vector instruction must not be read through DPP
-// by the next one, and the hazard recogniser cannot see into inline asm -- the compiler may have just moved the chunk into place.)
-template <int J>
-__device__ __forceinline__ void fmac_row_bcast(double& acc, double chunk, double k) {
-    if constexpr (J == 0)
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(chunk), "v"(k), "n"(J));
+// The terms of one 16-value chunk are ONE asm block: the chunk register is read through DPP by every term, a VGPR written by a vector
+// instruction must not be read through DPP by the next one (two wait states), and the hazard recogniser cannot see into inline asm.  As
+// separate asm statements only the first term carried the s_nop, and nothing kept the register allocator from copying or
+// rematerialising `chunk` between two of the others (a v_mov feeding straight into a DPP read: the product silently uses stale data --
+// unis() in srbdqp_common.hpp documents the same hazard moving forces by 1e-2 N).  Inside one block the operands are pinned for all
+// terms and one s_nop covers them (advisor finding, round 3).
+#define SRBDQP_FD(A, K, J) "v_fmac_f64_dpp %" #A ", %4, %" #K " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+#define SRBDQP_FD4(K0, K1, K2, K3, J0, J1, J2, J3) SRBDQP_FD(0, K0, J0) SRBDQP_FD(1, K1, J1) SRBDQP_FD(2, K2, J2) SRBDQP_FD(3, K3, J3)
+// acc[j & 3] += k[j] * bcast_j(ch) for j = 0 .. CNT - 1 (CNT a multiple of 4, at most 16)
+template <int CNT>
+__device__ __forceinline__ void fmac_row_bcast_block(double (&acc)[4], double ch, const double* k) {
+    static_assert(CNT == 4 || CNT == 8 || CNT == 12 || CNT == 16, "whole groups of four terms");
+    if constexpr (CNT == 4)
+        asm volatile("s_nop 1\n\t" SRBDQP_FD4(5, 6, 7, 8, 0, 1, 2, 3)
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(ch), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+    else if constexpr (CNT == 8)
+        asm volatile("s_nop 1\n\t" SRBDQP_FD4(5, 6, 7, 8, 0, 1, 2, 3) SRBDQP_FD4(9, 10, 11, 12, 4, 5, 6, 7)
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                     : "v"(ch), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
+    else if constexpr (CNT == 12)
+        asm volatile("s_nop 1\n\t" SRBDQP_FD4(5, 6, 7, 8, 0, 1, 2, 3) SRBDQP_FD4(9, 10, 11, 12, 4, 5, 6, 7) SRBDQP_FD4(13, 14, 15, 16, 8, 9, 10, 11)
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                     : "v"(ch), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]),
+                       "v"(k[11]));
     else
-        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(chunk), "v"(k), "n"(J));
+        asm volatile("s_nop 1\n\t" SRBDQP_FD4(5, 6, 7, 8, 0, 1, 2, 3) SRBDQP_FD4(9, 10, 11, 12, 4, 5, 6, 7) SRBDQP_FD4(13, 14, 15, 16, 8, 9, 10, 11)
+                     SRBDQP_FD4(17, 18, 19, 20, 12, 13, 14, 15)
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                     : "v"(ch), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]),
+                       "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]), "v"(k[15]));
 }
-// acc[j & 3] += kin[16 C + j] * bcast_j(ch) for j = J .. 15, columns < KS
-template <int KS, int C, int J = 0>
+// acc[j & 3] += kin[16 C + j] * bcast_j(ch) for j = 0 .. 15, columns < KS
+template <int KS, int C>
 struct RowBcastChunk {
     template <int KN>
     static __device__ __forceinline__ void run(double (&acc)[4], double ch, const double (&kin)[KN]) {
-        if constexpr (16 * C + J < KS) {
-            fmac_row_bcast<J>(acc[J & 3], ch, kin[16 * C + J]);
-            if constexpr (J + 1 < 16) RowBcastChunk<KS, C, J + 1>::run(acc, ch, kin);
-        }
+        constexpr int CNT = (KS - 16 * C) < 16 ? (KS - 16 * C) : 16;
+        if constexpr (CNT > 0) fmac_row_bcast_block<CNT>(acc, ch, kin + 16 * C);
     }
 };
 
