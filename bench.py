@@ -15,10 +15,13 @@ batch of synthetic QPs whose inputs are already resident in HBM.  Consecutive st
         contact schedules, through srbdqp_solve_ragged_device_f64 (bucketed launch)
 
 The one JSON line of the default run (`python bench.py`) carries, beside the configs[1] headline:
-  value             2 HIP streams + the longest-first dispatch hint taken from the SAME batch's previous solve (what a
-                    receding-horizon fleet has at hand: its own previous control step)
-  value_plain       1 stream, no hint: strictly serial steps in natural QP order
-  value_stale_hint  2 streams, hint taken from a DIFFERENT batch (uncorrelated iteration counts: a wrong hint)
+  value             2 HIP streams, natural QP order, tails deferred (SRBDQP_FLAG_DEFER_TAIL: a QP that reaches a rho-restart mark
+                    unconverged -- 4 % of a batch -- rides in the next solve on its stream instead of holding its own launch up;
+                    srbdqp_flush() INSIDE the timed region completes the last ones, so all K batches are solved when the clock stops)
+  value_plain       1 stream, no hint, tails deferred: strictly serial steps in natural QP order
+  value_stale_hint  2 streams, tails deferred, a longest-first hint taken from a DIFFERENT batch (a wrong hint)
+  in_place          round 3's modes for comparison: every solve complete at its own launch (rho restart in place): value = 2 streams +
+                    the hint from the SAME batch's previous solve, value_plain, value_stale_hint
   roofline          frac = flops the kernel really ISSUES (rocprofv3 PMC, profiles/*_pmc_summary.json of the same kernel)
                     over the live kernel time / the dense peak of the dtype; frac_algorithmic = SURVEY 8(d)'s W(N, K) of the
                     dense 12N-variable path over the same time (a throughput yardstick: the kernels execute far fewer flops)
@@ -96,6 +99,9 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=2,
                     help="consecutive steps alternate over this many HIP streams, so the straggler tail of one batch "
                          "(QPs that need many ADMM iterations) overlaps the bulk of the next; 1 = strictly serial steps")
+    ap.add_argument("--in-place", action="store_true",
+                    help="configs[1]: round 3's headline mode -- every solve complete at its own launch (rho restart in place) + the "
+                         "longest-first hint; default: tails deferred to the next solve on the stream (SRBDQP_FLAG_DEFER_TAIL), no hint")
     ap.add_argument("--no-sched-hint", action="store_true",
                     help="do not feed a batch's previous iteration counts back as the longest-first dispatch hint")
     ap.add_argument("--no-allgather", action="store_true", help="n_gpus > 1: leave the u_opt0 all-gather out of the headline value")
@@ -150,7 +156,11 @@ def _resolved_restart(N, B, it, cnt, max_iter, kname):
     if it <= 0 or it >= max_iter:
         return {"every": 0, "count": 0, "how": "off"}
     cnt = (cnt if cnt > 0 else (2 if auto else 1)) if wave else 1
-    return {"every": it, "count": cnt, "how": "in place, inside the one-wave kernel" if wave else "a second launch over the same grid"}
+    how = "a second launch over the same grid"
+    if wave:
+        how = ("deferred: a QP at a mark hands itself to the next launch on its stream (srbdqp_flush completes the last ones)" if "defer" in kname
+               else "in place, inside the one-wave kernel")
+    return {"every": it, "count": cnt, "how": how}
 
 
 def _auto_rho_fz(N):
@@ -163,17 +173,19 @@ def _auto_rho_fz(N):
 class Leg:
     """Homogeneous batches (configs[1], [2], [3]).  step(i, streams, hint): hint in {"own", "none", "stale"}."""
 
-    def __init__(self, cid, B, args, rank, local_rank, dev, torch, nb, stub=False, max_streams=2):
+    def __init__(self, cid, B, args, rank, local_rank, dev, torch, nb, stub=False, max_streams=2, defer=False):
         from g1_locomotion_amd import synth
         cfg = CONFIGS[cid]
         self.cid, self.cfg, self.B, self.N, self.f32, self.nb, self.stub = cid, cfg, B, cfg["horizon"], cfg["f32"], nb, stub
-        self.torch, self.dev = torch, dev
+        self.torch, self.dev, self.defer = torch, dev, defer
         N = self.N
         self.host_batches = [synth.synthetic_batch(B, N, seed=1000 * cid + 97 * j + rank, schedule=cfg["schedule"]) for j in range(nb)]
         self.tdt = tdt = torch.float32 if self.f32 else torch.float64
         self.d_in = [[torch.from_numpy(v).to(dev).to(tdt) if v.dtype == np.float64 else torch.from_numpy(v).to(dev) for v in hb]
                      for hb in self.host_batches]
-        self.NO = NO = max(nb, max_streams)      # output sets: steps in flight at the same time must not share outputs
+        # output sets: steps in flight at the same time must not share outputs; with deferred tails a step's outputs are written until
+        # rho_restart_count (2) further steps on its stream have run: twice the sets
+        self.NO = NO = max(nb, max_streams) * (2 if defer else 1)
         self.d_u = [torch.zeros((B, N, 12), dtype=tdt, device=dev) for _ in range(NO)]
         self.d_x = [torch.zeros((B, N + 1, 13), dtype=tdt, device=dev) for _ in range(NO)]
         self.d_st = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NO)]
@@ -190,6 +202,7 @@ class Leg:
             if args.rho_restart_count != 0: kw["rho_restart_count"] = args.rho_restart_count
             if args.rho > 0: kw["rho"] = args.rho
             if args.rho_fz_scale > 0: kw["rho_fz_scale"] = args.rho_fz_scale
+            if defer: kw["flags"] = _lib.FLAG_DEFER_TAIL
             self.eng = BatchMPC(horizon=N, device=local_rank, kernel=kid, max_contacts_per_step=cfg["maxs"], **kw)
             # non-default streams: the C-ABI treats a NULL stream as "the handle's own", and the HIP events that time a kernel
             # must sit on the stream the kernel is launched on
@@ -212,6 +225,11 @@ class Leg:
         self.eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), self.d_u[o].data_ptr(),
                               x_out=self.d_x[o].data_ptr(), status=self.d_st[o].data_ptr(), iters=self.d_it[o].data_ptr(),
                               stream=st.cuda_stream, f32=self.f32)
+
+    def flush(self):
+        """deferred tails: enqueue what no later step has picked up (a no-op otherwise)"""
+        if self.defer and self.eng is not None:
+            self.eng.flush()
 
     def stats(self, solved_code):
         iters = self.torch.stack([t.cpu() for t in self.d_it[:self.nb]]).numpy()
@@ -258,6 +276,11 @@ class RaggedLeg:
         self.kname = "ragged_wrench_f64_n8_n12_n16_n24"
         self.d_u = [s["u"] for s in self.sets]
 
+    defer = False
+
+    def flush(self):
+        pass
+
     def step(self, i, S=1, hint="none"):
         s = self.sets[i % self.nb]
         d = s["d"]
@@ -283,7 +306,21 @@ class RaggedLeg:
 
 
 def isolated_kernel_ms(leg, torch, n_iso, k0):
-    """the step's kernels in isolation (HIP events on the launch stream, one solve at a time)"""
+    """the step's kernels in isolation (HIP events on the launch stream, one solve at a time).  Deferred tails: a launch also runs the
+    continuations of the launches before it, so the kernel's duration is the average over a run of consecutive launches on ONE stream
+    (events around the whole run, the flush included), not of a launch alone on an empty list."""
+    if leg.defer:
+        n = max(n_iso, 20)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k = k0 + leg.NO * len(leg.streams)
+        torch.cuda.synchronize(leg.dev)
+        e0.record(leg.streams[0])
+        for i in range(n):
+            leg.step(k + i * len(leg.streams), S=len(leg.streams), hint="none")      # (a multiple of S: always stream 0)
+        leg.flush()
+        e1.record(leg.streams[0])
+        torch.cuda.synchronize(leg.dev)
+        return e0.elapsed_time(e1) / n, n
     iso = []
     for i in range(n_iso):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -310,10 +347,14 @@ def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step
          "traffic": None,
          "traffic_unit": "HBM bytes per solve = per launch of this step's kernels (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
          "algorithmic_bytes_per_launch": abytes, "kernel": kname, "kernel_ms": kernel_ms,
-         "kernel_ms_note": "mean of %d isolated solves, one at a time, after the warm-up steps and before the timed region (so the GPU is at its "
-                           "sustained clocks when the timed steps start); HIP events on the launch stream; with the rho restart on, a solve = the "
-                           "first pass + the pass in which the capped QPs continue; an _f32 solve of >= 512 QPs = the fp32-tile and the fp64-tile "
-                           "launch; a ragged solve = all its bucket launches.  The timed region overlaps consecutive steps on %d stream(s)" % (n_iso, S),
+         "kernel_ms_note": ("average launch duration over a run of %d consecutive launches on ONE stream (HIP events on that stream around the whole run, "
+                            "flush included): with deferred tails every launch also runs the continuations of the launches before it, so a launch alone "
+                            "on an empty list is not the kernel's steady state.  The timed region overlaps consecutive steps on %d stream(s)" % (n_iso, S))
+                           if "defer" in kname else
+                           ("mean of %d isolated solves, one at a time, after the warm-up steps and before the timed region (so the GPU is at its "
+                            "sustained clocks when the timed steps start); HIP events on the launch stream; with the rho restart on, a solve = the "
+                            "first pass + the pass in which the capped QPs continue; an _f32 solve of >= 512 QPs = the fp32-tile and the fp64-tile "
+                            "launch; a ragged solve = all its bucket launches.  The timed region overlaps consecutive steps on %d stream(s)" % (n_iso, S)),
          "algorithmic_flops_per_launch": flops_launch,
          "hbm_algorithmic_GBps": hbm_gbs, "hbm_frac_of_8TBps": hbm_gbs / 8000.0}
     try:
@@ -343,9 +384,29 @@ def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step
                 r["bound"] = ex["bound"]
                 r["utilisation"] = ex["utilisation"]
             r["pmc_summary"] = os.path.relpath(best["_file"], ROOT) + (" (counted at %d QPs per launch, scaled per QP)" % best["batch_per_launch"] if scaled else "")
+            # which library the counters were taken on (tools/pmc_summary.py records it) against the one loaded now
+            r["pmc_summary_library_sha256"] = best.get("library_sha256")
+            r["pmc_summary_git_rev"] = best.get("git_rev")
+            r["pmc_summary_matches_loaded_library"] = (best.get("library_sha256") == library_sha256()) if best.get("library_sha256") else None
     except Exception as e:          # the summary is evidence, not a dependency
         r["traffic_error"] = repr(e)
     return r
+
+
+_LIB_SHA = None
+
+
+def library_sha256():
+    """sha256 of the libsrbdqp.so this process loads (ties the line and the PMC summaries to a build)"""
+    global _LIB_SHA
+    if _LIB_SHA is None:
+        import hashlib
+        from g1_locomotion_amd import _lib
+        try:
+            _LIB_SHA = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+        except OSError:
+            _LIB_SHA = "unreadable"
+    return _LIB_SHA
 
 
 def main(argv=None):
@@ -387,14 +448,18 @@ def main(argv=None):
     if not stub:
         from g1_locomotion_amd import _lib
         SOLVED = _lib.SOLVED
+    # deferred tails (round 4): configs[1] on one GPU, on the one-wave kernel with its automatic rho restart.  Not with several ranks: the all-gather of
+    # u_opt0 behind every step needs that step's forces complete, and at 65,536 QPs per launch the tail is a tenth of the launch anyway.
+    defer = (cid == 1 and world == 1 and not stub and not args.in_place and args.kernel in ("auto", "wave") and B >= 4096
+             and args.rho_restart >= 0 and not args.same_batch)
     if cid == 4:
         leg = RaggedLeg(B, args, rank, local_rank, dev, torch, nb)
         S = 1
     else:
-        leg = Leg(cid, B, args, rank, local_rank, dev, torch, nb, stub=stub, max_streams=S)
+        leg = Leg(cid, B, args, rank, local_rank, dev, torch, nb, stub=stub, max_streams=S, defer=defer)
     N, f32 = leg.N, leg.f32
     NO = leg.NO
-    hint = "none" if (args.no_sched_hint or cid == 4) else "own"
+    hint = "none" if (args.no_sched_hint or cid == 4 or defer) else "own"
     d_u0_all = [torch.empty((world * B, 12), dtype=torch.float32 if f32 else torch.float64, device=dev) for _ in range(NO)] if (world > 1 and cid != 4) else None
 
     def u0_of(o):
@@ -423,6 +488,7 @@ def main(argv=None):
             lg.step(k, S=S_, hint=hint_)
             if with_exchange:
                 exchange(k)
+        lg.flush()                  # deferred tails: the continuations nothing has picked up yet run inside the timed region
         sync()
         if dist is not None:
             dist.barrier()
@@ -438,6 +504,7 @@ def main(argv=None):
     for i in range(max(args.warmup, NO)):
         leg.step(i, S=S, hint="none" if i < NO else hint)
         exchange(i)
+    leg.flush()
     sync()
     base = max(args.warmup, NO)
     base += (-base) % (S * NO)      # keep the (step -> stream, batch, output set) phase
@@ -459,30 +526,51 @@ def main(argv=None):
         assert torch.equal(mine, leg.d_u[o][:, 0, :]), "all-gather result does not hold this rank's forces"
     # ---- the same K steps without the two things that shape the headline (configs[1] at one GPU)
     extra = {}
-    if world == 1 and not stub and cid in (1, 3) and not args.no_also and hint == "own":
-        el_plain = timed(leg, base, steps, False, 1, "none")
-        for i in range(NO):                    # refresh every output set's counts, then hints taken from ANOTHER batch
-            leg.step(base + i, S=S, hint="none")
+    def variants(lg):
+        el_plain = timed(lg, base, steps, False, 1, "none")
+        for i in range(lg.NO):                 # refresh every output set's counts, then hints taken from ANOTHER batch
+            lg.step(base + i, S=S, hint="none")
+        lg.flush()
         sync()
-        el_stale = timed(leg, base, steps, False, S, "stale")
-        extra["value_plain"] = B * steps / el_plain
-        extra["value_stale_hint"] = B * steps / el_stale
-        extra["value_variants_note"] = ("value: %d streams + longest-first hint = the same batch's previous iteration counts; value_plain: 1 stream, no hint "
-                                        "(strictly serial steps, natural QP order); value_stale_hint: %d streams, hint = the counts of a DIFFERENT "
-                                        "batch (uncorrelated: a wrong hint only reorders work)" % (S, S))
+        el_stale = timed(lg, base, steps, False, S, "stale")
+        return B * steps / el_plain, B * steps / el_stale
+
+    if world == 1 and not stub and cid in (1, 3) and not args.no_also and (hint == "own" or defer):
+        extra["value_plain"], extra["value_stale_hint"] = variants(leg)
+        if defer:
+            extra["value_variants_note"] = ("value: %d streams, natural QP order, tails deferred to the next solve on the stream (SRBDQP_FLAG_DEFER_TAIL), flushed inside "
+                                            "the timed region; value_plain: the same on 1 stream (strictly serial steps); value_stale_hint: %d streams + a "
+                                            "longest-first hint from the counts of a DIFFERENT batch (a wrong hint only reorders work); in_place: the three "
+                                            "with every solve complete at its own launch (rho restart in place, round 3's kernel), `value` there = %d streams + "
+                                            "the hint from the SAME batch's previous solve" % (S, S, S))
+            # round 3's modes on the same box, same batches: every solve complete at its own launch
+            leg_ip = Leg(cid, B, args, rank, local_rank, dev, torch, nb, max_streams=S, defer=False)
+            for i in range(2 * leg_ip.NO):
+                leg_ip.step(i, S=S, hint="none" if i < leg_ip.NO else "own")
+            sync()
+            el_ip = timed(leg_ip, base, steps, False, S, "own")
+            ip_it, ip_solved, _ = leg_ip.stats(SOLVED)
+            ip_plain, ip_stale = variants(leg_ip)
+            extra["in_place"] = {"value": B * steps / el_ip, "value_plain": ip_plain, "value_stale_hint": ip_stale, "kernel": leg_ip.eng.kernel_name(),
+                                 "solved_frac": ip_solved, "admm_mean_iters": ip_it}
+            leg_ip.close()
+        else:
+            extra["value_variants_note"] = ("value: %d streams + longest-first hint = the same batch's previous iteration counts; value_plain: 1 stream, no hint "
+                                            "(strictly serial steps, natural QP order); value_stale_hint: %d streams, hint = the counts of a DIFFERENT "
+                                            "batch (uncorrelated: a wrong hint only reorders work)" % (S, S))
         if args.rho_restart == 0 and kname.startswith("wave_") and B >= 4096:
             # what the rho restart in place costs and buys: the same steps with it switched off (plain fixed-rho ADMM, the algorithm of rounds 1-2)
             import copy
             args_off = copy.copy(args); args_off.rho_restart = -1
             leg_off = Leg(cid, B, args_off, rank, local_rank, dev, torch, nb, max_streams=S)
             for i in range(2 * leg_off.NO):
-                leg_off.step(i, S=S, hint="none" if i < leg_off.NO else hint)
+                leg_off.step(i, S=S, hint="none" if i < leg_off.NO else "own")
             sync()
-            el_off = timed(leg_off, base, steps, False, S, hint)
+            el_off = timed(leg_off, base, steps, False, S, "own")
             it_off, solved_off, _ = leg_off.stats(SOLVED)
             leg_off.close()
             extra["without_rho_restart"] = {"value": B * steps / el_off, "solved_frac": solved_off, "admm_mean_iters": it_off,
-                                            "note": "the same steps with rho_restart_iter = -1; value / solved_frac above are with the default (srbdqp.h rho_restart_iter)"}
+                                            "note": "the same steps with rho_restart_iter = -1 (plain fixed-rho ADMM; %d streams + the longest-first hint); value / solved_frac above are with the default (srbdqp.h rho_restart_iter)" % S}
 
     if rank == 0:
         total_qp = world * B * steps
@@ -496,11 +584,13 @@ def main(argv=None):
             "config": {"workload": cfg["workload"].format(B=B) + ("; u_opt0 all-gather over RCCL every step" if use_ag else "")
                                    + (f"; steps rotate over {nb} distinct device batches" if nb > 1 else "; every step solves the same batch"),
                        "horizon": N if cid != 4 else list(RAGGED_HORIZONS), "batch_per_gpu": B, "kernel": kname, "streams": S,
-                       "longest_first_hint": hint == "own", "world_size": world if dist is None else dist.get_world_size(),
+                       "longest_first_hint": hint == "own", "deferred_tails": bool(defer), "world_size": world if dist is None else dist.get_world_size(),
                        "distinct_batches": nb, "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
                        "allgather_in_value": bool(use_ag)},
         }
         out.update(extra)
+        if not stub:
+            out["library_sha256"] = library_sha256()
         if leg.eng is not None and cid != 4:
             c = leg.eng.cfg
             out["config"].update({"eps_abs": max(c.eps_abs, 2e-6) if f32 else c.eps_abs, "eps_rel": max(c.eps_rel, 2e-6) if f32 else c.eps_rel,
@@ -572,7 +662,7 @@ def also_legs(args, rank, local_rank, dev, torch, SOLVED):
     return res
 
 
-def latency_batch1(synth, calls=2000):
+def latency_batch1(synth, calls=10000):
     """p50/p99 of single-QP calls: through the Python MPC.update() path (ctypes + staging + kernel) and through the C-ABI
     alone, for the synthetic single-support gait of configs[1] AND for the reference's own call pattern -- full double
     support on every step (g1_mujoco_sim/src/run_simulation.py:100-101 feeds [1, 1, 1, 1] per step, :106 calls update())."""
@@ -612,19 +702,67 @@ def latency_batch1(synth, calls=2000):
                 ts.append(time.perf_counter() - t); its.append(int(st["iters"][0]))
             return dict(pct(ts), mean_iters=float(np.mean(its[50:])), kernel=eng.kernel_name())
 
+    def mpc_update_arrays(sched, n):
+        """the same call with (N, 12) / (N, 4) arrays instead of the reference's per-step lists (what the two np.concatenate cost)"""
+        x0, xr, ft, ct = sets[sched]
+        mpc = MPC(dt=0.04, horizon=HORIZON)
+        mpc.init_matrices()
+        ts = []
+        for i in range(n + 50):
+            b = i % 64
+            mpc.x_ref_hor[:] = xr[b]
+            pc = xr[b][:, 3:6]
+            t = time.perf_counter()
+            mpc.update(ct[b], ft[b], pc, x_current=x0[b], one_rollout=True)
+            ts.append(time.perf_counter() - t)
+        mpc.close()
+        return pct(ts)
+
+    def closed_loop(warm, n):
+        """a CORRELATED sequence: one robot stepping in place (msgs.AlternatingGait), every control step's state = the state the
+        previous plan predicted (the linear model as the plant) with a push every 40 steps; cold = every solve from zero, warm = from
+        the previous plan and duals shifted by one step -- the receding-horizon warm start, on consecutive QPs of the same robot"""
+        from g1_locomotion_amd import msgs
+        mpc = MPC(dt=0.04, horizon=HORIZON, warm_start=warm, strict=False)
+        mpc.init_matrices()
+        gait = msgs.AlternatingGait(dt=0.04)
+        feet = np.array([0.0, 0.0645, 0.0, 0.17, 0.0645, 0.0, 0.0, -0.0645, 0.0, 0.17, -0.0645, 0.0])
+        com = np.array([0.085, 0.0, 0.598])
+        x = np.zeros(13); x[3:6] = com + np.array([0.01, -0.01, -0.01]); x[0] = 0.03; x[12] = -9.80665
+        rng = np.random.default_rng(5)
+        ts, its = [], []
+        c_h = [feet.copy() for _ in range(HORIZON)]
+        for k in range(n + 50):
+            mpc.x_ref_hor[:] = 0.0
+            mpc.x_ref_hor[:, 2] = x[2]; mpc.x_ref_hor[:, 3:6] = com; mpc.x_ref_hor[:, 12] = x[12]
+            ct_h = list(gait.contact_horizon(0.04 * k, HORIZON))
+            pc = np.repeat(x[3:6][None, :], HORIZON, axis=0)
+            t = time.perf_counter()
+            u0, xo = mpc.update(ct_h, c_h, pc, x_current=x.reshape(13, 1), one_rollout=True)
+            ts.append(time.perf_counter() - t); its.append(mpc.iters)
+            x = xo[1].copy()
+            if k % 40 == 5:
+                x[9:12] += rng.uniform(-0.08, 0.08, 3) * np.array([1.0, 1.0, 0.3])
+            if not np.all(np.isfinite(x)) or abs(x[5] - com[2]) > 0.3:      # (never seen: restart the robot rather than time nonsense)
+                x[:] = 0.0; x[3:6] = com; x[12] = -9.80665
+        mpc.close()
+        return dict(pct(ts), mean_iters=float(np.mean(its[50:])))
+
     out["cold"] = mpc_update("single", False, calls)
-    out["warm"] = mpc_update("single", True, calls)
     out["c_abi"] = c_abi("single", calls)
     out["c_abi_eps1e-3"] = c_abi("single", calls, eps_abs=1e-3, eps_rel=1e-3)
     out["c_abi_double_support"] = c_abi("double", calls)
     out["mpc_update_double_support"] = mpc_update("double", False, calls)
+    out["mpc_update_double_support_arrays"] = mpc_update_arrays("double", calls)
+    out["closed_loop_cold"] = closed_loop(False, calls // 2)
+    out["closed_loop_warm"] = closed_loop(True, calls // 2)
     # the two-phase call: the set-up (contact schedule, contact points, reference known beforehand) has run and finished;
     # timed = the second phase only, from "the measured state is in the staging array" to "the forces are there"
     x0, xr, ft, ct = sets["single"]
     with BatchMPC(horizon=HORIZON) as eng:
         st = eng.stage()
         ts = []
-        for i in range(calls // 2 + 50):
+        for i in range(calls // 4 + 50):
             b = i % 64
             st["x0"][0] = x0[(b + 1) % 64]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]   # a wrong prediction
             eng.prepare_staged(1)
@@ -634,10 +772,15 @@ def latency_batch1(synth, calls=2000):
             eng.solve_prepared(1, want_x=True)
             ts.append(time.perf_counter() - t)
         out["c_abi_prepared_phase2"] = pct(ts)
-    out["note"] = ("cold / warm: MPC.update() on the single-support gait of configs[1], from zero / from the previous call's shifted plan and duals; "
-                   "c_abi: srbdqp_solve_staged_f64(B=1) alone on that gait (everything between the inputs and the forces); eps1e-3: OSQP's default "
+    out["calls_per_variant"] = calls
+    out["note"] = ("p50 / p99 over %d calls each (closed loops: %d, phase 2: %d).  " % (calls, calls // 2, calls // 4) +
+                   "cold: MPC.update() on the single-support gait of configs[1] (64 unrelated QPs "
+                   "in rotation, every solve from zero); c_abi: srbdqp_solve_staged_f64(B=1) alone on that gait (everything between the inputs and the forces); eps1e-3: OSQP's default "
                    "tolerance instead of 1e-6; c_abi_double_support / mpc_update_double_support: the same two calls on the REFERENCE'S OWN call "
-                   "pattern, all four contact points active on every step (run_simulation.py:100-101,106); c_abi_prepared_phase2: "
+                   "pattern, all four contact points active on every step, per-step lists as the reference passes them (run_simulation.py:94-101,106); "
+                   "..._arrays: (N, 12) / (N, 4) arrays instead of the lists; closed_loop_cold / closed_loop_warm: one robot stepping in place, "
+                   "consecutive control steps (each state = the previous plan's prediction, a push every 40 steps) -- cold from zero, warm from the "
+                   "previous plan and duals shifted by one step: the receding-horizon warm start on a correlated sequence; c_abi_prepared_phase2: "
                    "srbdqp_solve_prepared_f64 alone after a finished srbdqp_prepare_staged_f64 -- a different mode of operation (the "
                    "factorisation ran before the state arrived), listed beside c_abi, not instead of it")
     return out

@@ -24,6 +24,8 @@ FLAG_SETUP4 = 4
 FLAG_F64_TILES = 8     # _f32 calls: fp64 tiles for every QP
 FLAG_F32_TILES = 16    # _f32 calls: fp32 tiles for the eligible QPs of small batches too
 FLAG_NO_LAT = 32       # staged calls on the general kernel: the batch instantiation instead of the low-latency one
+FLAG_DEFER_TAIL = 64   # one-wave kernel: continuations of unconverged QPs ride in the next solve on the stream (srbdqp_flush completes them)
+PENDING = 0
 KERNEL_AUTO, KERNEL_COMPACT, KERNEL_SPLIT, KERNEL_WAVE, KERNEL_WRENCH = 0, 3, 4, 5, 6   # 1, 2: the retired round-1 baselines
 
 EXPORTS = (
@@ -32,7 +34,7 @@ EXPORTS = (
     "srbdqp_assemble_f64", "srbdqp_assemble_wrench_f64",
     "srbdqp_ragged_create", "srbdqp_ragged_destroy", "srbdqp_ragged_last_error", "srbdqp_solve_ragged_device_f64", "srbdqp_solve_ragged_f64",
     "srbdqp_solve_ragged_device_f32", "srbdqp_solve_ragged_f32", "srbdqp_solve_ragged_warm_device_f64", "srbdqp_solve_ragged_warm_device_f32",
-    "srbdqp_set_schedule_hint", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_update_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
+    "srbdqp_set_schedule_hint", "srbdqp_flush", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_update_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
     "srbdqp_mpc_inputs_f64", "srbdqp_mpc_inputs_device_f64",
@@ -148,6 +150,8 @@ def load():
     lib.srbdqp_solve_ragged_f64.restype = C.c_int
     lib.srbdqp_set_schedule_hint.argtypes = [H, C.c_void_p, C.c_int32]
     lib.srbdqp_set_schedule_hint.restype = C.c_int
+    lib.srbdqp_flush.argtypes = [H, C.c_void_p]
+    lib.srbdqp_flush.restype = C.c_int
     lib.srbdqp_stage_ptrs.argtypes = [H, C.POINTER(Stage)]
     lib.srbdqp_stage_ptrs.restype = C.c_int
     lib.srbdqp_solve_staged_f64.argtypes = [H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]

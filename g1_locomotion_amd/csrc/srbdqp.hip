@@ -50,6 +50,12 @@ struct srbdqp_handle {
         char* rs = nullptr; size_t rs_items = 0, rs_rows = 0;
         float* resid = nullptr; double* ybuf = nullptr;
         int32_t* stbuf = nullptr;
+        // deferred tails (SRBDQP_FLAG_DEFER_TAIL): three rotating lists of continuation records, their counts, and a GPU-mapped host word through
+        // which every launch reports how many records it found (launch_wave_defer sizes the next launches' tail workgroups from it)
+        char* tail = nullptr; int32_t* tail_cnt = nullptr; size_t tail_cap = 0;
+        int32_t* tail_seen_h = nullptr; int32_t* tail_seen_d = nullptr;
+        unsigned long long tail_k = 0;     // launches so far: list k % 3 is appended to, (k + 2) % 3 read, (k + 1) % 3 zeroed
+        bool tail_live = false;            // records may be pending (a solve since the last flush)
     };
     static constexpr int kMaxSlots = 8;
     StreamSlot slots[kMaxSlots];
@@ -307,6 +313,50 @@ int launch_wave(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
     HIP_TRY(h, hipGetLastError());
     return SRBDQP_OK;
 }
+
+// The one-wave kernel with deferred tails (srbdqp_setup1.hpp, srbdqp_wave_defer_kernel): grid = tail workgroups (continuations of earlier launches on this
+// stream, first) + one workgroup per QP of this launch.  a.B = 0: a flush launch (continuations only, one workgroup per record the lists can hold).
+template <int N, int MAXS>
+int launch_wave_defer(srbdqp_handle* h, KArgs a, hipStream_t st, srbdqp_handle::StreamSlot* slot) {
+    constexpr size_t lds1 = srbdqp::Setup1Smem<N, MAXS>::bytes + 3 * 64 * sizeof(double);
+    static_assert(8 * ((lds1 + 1279) / 1280) * 1280 <= 163840, "eight QPs per CU");
+    static const std::string nm = "wave_defer_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
+    h->kname = nm.c_str();
+    const unsigned long long k = slot->tail_k++;
+    a.tail_lists = slot->tail; a.tail_cnt = slot->tail_cnt; a.tail_seen = slot->tail_seen_d; a.tail_cap = (int32_t)slot->tail_cap;
+    a.tail_iout = (int32_t)(k % 3); a.tail_iin = (int32_t)((k + 2) % 3); a.tail_izero = (int32_t)((k + 1) % 3);
+    long long T = (long long)slot->tail_cap;
+    if (a.B > 0) {   // twice what the last launch that reported found (stale by a launch or two: a record beyond tail_wgs just moves on to the next launch)
+        const long long seen = *reinterpret_cast<volatile int32_t*>(slot->tail_seen_h);
+        T = 2 * seen + 64;
+        const long long lo = a.B / 16 > 64 ? a.B / 16 : 64;
+        if (T < lo) T = lo;
+        if (T > (long long)slot->tail_cap) T = (long long)slot->tail_cap;
+    }
+    a.tail_wgs = (int32_t)T;
+    if (a.B > 0) hipLaunchKernelGGL((srbdqp::srbdqp_wave_defer_kernel<N, MAXS, false>), dim3((unsigned)(T + a.B)), dim3(64), lds1, st, a);
+    else hipLaunchKernelGGL((srbdqp::srbdqp_wave_defer_kernel<N, MAXS, true>), dim3((unsigned)T), dim3(64), lds1, st, a);
+    HIP_TRY(h, hipGetLastError());
+    slot->tail_live = true;
+    return SRBDQP_OK;
+}
+
+int launch_wave_defer_any(srbdqp_handle* h, const KArgs& a, hipStream_t st, srbdqp_handle::StreamSlot* slot, int maxs) {
+    const bool s2 = maxs <= 2;
+    switch (h->cfg.horizon) {
+        case 4: return s2 ? launch_wave_defer<4, 2>(h, a, st, slot) : launch_wave_defer<4, 4>(h, a, st, slot);
+        case 8: if (s2) return launch_wave_defer<8, 2>(h, a, st, slot); break;
+        case 10: if (s2) return launch_wave_defer<10, 2>(h, a, st, slot); break;
+        default: break;
+    }
+    h->err = "deferred tails exist for the one-wave kernel only (N <= 10, at most 2 stance contacts per step)";
+    return SRBDQP_E_INVALID;
+}
+
+// lists for launches of up to B QPs that may re-balance up to rmax times: (rmax + 1) records per QP of a launch can never overflow (a list holds what one
+// launch defers: at most its own QPs plus the unfinished records of the list before it)
+int ensure_tail_lists(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, int rmax);
+int flush_slot(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st);
 
 // one staged QP whose inputs still sit in the library's own staging arrays: they ride in the kernel-argument segment (srbdqp_common.hpp StagedIn)
 template <int N>
@@ -577,6 +627,49 @@ int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hi
     return SRBDQP_OK;
 }
 
+int ensure_tail_lists(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, int rmax) {
+    const size_t want = (size_t)(rmax + 1) * B + 4096 + 64;        // (+ the margin the kernel keeps free, srbdqp_setup1.hpp rs.more)
+    if (slot->tail && slot->tail_cap >= want) return SRBDQP_OK;
+    if (slot->tail) {                                               // growing: finish what the old lists hold, then let go of them
+        int rc = flush_slot(h, slot, st);
+        if (rc != SRBDQP_OK) return rc;
+        HIP_TRY(h, hipStreamSynchronize(st));
+        HIP_TRY(h, hipFree(slot->tail)); slot->tail = nullptr; slot->tail_cap = 0;
+    }
+    if (!slot->tail_cnt) {
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&slot->tail_cnt), 64));
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&slot->tail_seen_h), 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&slot->tail_seen_d), slot->tail_seen_h, 0));
+        *slot->tail_seen_h = 0;
+    }
+    const size_t cap = want + want / 4;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&slot->tail), 3 * cap * srbdqp::kTailRecDoubles * sizeof(double));
+    if (e != hipSuccess) { h->err = std::string("hipMalloc tail lists: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
+    slot->tail_cap = cap;
+    slot->tail_k = 0;
+    HIP_TRY(h, hipMemsetAsync(slot->tail_cnt, 0, 64, st));
+    return SRBDQP_OK;
+}
+
+// run what the lists of this launch stream still hold: every flush launch runs ONE pass of every record (one workgroup per record the lists can hold), so
+// rho_restart_count of them finish everything; enqueued on st, no host synchronisation
+int flush_slot(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st) {
+    if (!slot->tail || !slot->tail_live) return SRBDQP_OK;
+    int rcount = 1;
+    const int maxs = h->cfg.max_contacts_per_step > 0 ? h->cfg.max_contacts_per_step : 2;
+    const int restart = restart_iter_of(h, maxs, kRestartMinBatch, true, &rcount);
+    KArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_args(h->cfg, a);
+    a.B = 0; a.restart_every = restart; a.restart_max = rcount;
+    for (int j = 0; j < rcount; ++j) {
+        const int rc = launch_wave_defer_any(h, a, st, slot, maxs <= 2 ? 2 : 4);
+        if (rc != SRBDQP_OK) return rc;
+    }
+    slot->tail_live = false;
+    return SRBDQP_OK;
+}
+
 // second pass of a two-pass solve: the same grid again; the workgroup of a QP that ended at the cap re-balances its rho from
 // the maxima of its last check and continues from its own (x, y), every other workgroup leaves at once.  No selection
 // kernel and no list between the passes: a one-workgroup kernel queued behind a chip-filling launch of another stream
@@ -706,7 +799,10 @@ int srbdqp_destroy(srbdqp_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
-    for (auto& sl : h->slots) { if (sl.perm) (void)hipFree(sl.perm); if (sl.ws) (void)hipFree(sl.ws); if (sl.rs) (void)hipFree(sl.rs); }
+    for (auto& sl : h->slots) {
+        if (sl.perm) (void)hipFree(sl.perm); if (sl.ws) (void)hipFree(sl.ws); if (sl.rs) (void)hipFree(sl.rs);
+        if (sl.tail) (void)hipFree(sl.tail); if (sl.tail_cnt) (void)hipFree(sl.tail_cnt); if (sl.tail_seen_h) (void)hipHostFree(sl.tail_seen_h);
+    }
     if (h->done_count) (void)hipFree(h->done_count);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -901,8 +997,22 @@ int srbdqp_set_stamp_buffer(srbdqp_handle* h, void* device_ptr) {
     return SRBDQP_OK;
 }
 
+int srbdqp_flush(srbdqp_handle* h, void* stream) {
+    if (!h) return SRBDQP_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (auto& sl : h->slots) {
+        if (!sl.used || !sl.tail_live) continue;
+        if (stream && sl.st != reinterpret_cast<hipStream_t>(stream)) continue;
+        const int rc = flush_slot(h, &sl, sl.st);
+        if (rc != SRBDQP_OK) return rc;
+    }
+    return SRBDQP_OK;
+}
+
 int srbdqp_synchronize(srbdqp_handle* h) {
     if (!h) return SRBDQP_E_INVALID;
+    for (auto& sl : h->slots)                      // deferred tails of the handle's own stream are part of "everything enqueued"
+        if (sl.used && sl.tail_live && sl.st == h->stream) { const int rc = flush_slot(h, &sl, sl.st); if (rc != SRBDQP_OK) return rc; }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SRBDQP_OK;
 }
@@ -966,6 +1076,14 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
     int rcount = 1;
     const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h, maxs, B, wave, &rcount);
     if (restart && wave) { a.restart_every = restart; a.restart_max = rcount; }   // the one-wave kernel restarts in place
+    if (restart && wave && (h->cfg.flags & SRBDQP_FLAG_DEFER_TAIL) && !a.stamps && !a.done_flag && !h->io_f32) {
+        // ... or not at all: continuations deferred to the next launch on this stream (srbdqp_flush() completes them)
+        auto* slot = stream_slot(h, lst);
+        if (!slot) return SRBDQP_E_INVALID;
+        int rc = ensure_tail_lists(h, slot, lst, (size_t)B, rcount);
+        if (rc != SRBDQP_OK) return rc;
+        return launch_wave_defer_any(h, a, lst, slot, maxs);
+    }
     if (!restart || wave) return launch(h, a, lst, maxs);
 
     // ---- two passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those

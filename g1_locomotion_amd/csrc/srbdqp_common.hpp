@@ -58,6 +58,14 @@ struct KArgs {
     int32_t y_capped_only;   // first pass, y_out = the engine's own buffer (the caller asked for no duals): only a QP that ends at the cap stores them
                              //   (20 N values per QP for every QP was a quarter of the HBM traffic of a configs[2] solve)
     int32_t qp_span;         // host only: number of QP slots the per-QP workspaces must hold (second pass: original B)
+    // deferred tails (SRBDQP_FLAG_DEFER_TAIL, srbdqp_wave_defer_kernel): a QP that reaches a restart mark unconverged is not continued by its own
+    // workgroup but appended -- (x, y), its re-balanced rho, its own input / output pointers -- to a list in HBM, and one of the first tail_wgs workgroups
+    // of the NEXT launch on the same stream runs its next pass.  Three lists per launch stream in rotation: this launch reads tail_cnt[tail_iin] records
+    // from list tail_iin, appends to list tail_iout and zeroes the count of list tail_izero (the one the next launch appends to).
+    char* tail_lists;        // [3][tail_cap] records of kTailRecDoubles doubles, or null (no deferral)
+    int32_t* tail_cnt;       // [3] record counts
+    int32_t* tail_seen;      // GPU-mapped host word: the number of records this launch found (the host sizes tail_wgs of later launches from it)
+    int32_t tail_cap, tail_wgs, tail_iin, tail_iout, tail_izero;
     int32_t* done_flag;      // low-latency completion: GPU-mapped host word that receives done_value once every QP of the
     int32_t* done_count;     //   launch has stored its outputs (done_count: device counter of finished workgroups), or null
     int32_t done_value;
@@ -91,6 +99,25 @@ __device__ __forceinline__ const char* staged_in_base(const KArgs& a) {
     if constexpr (sizeof(KArgs) + sizeof(StagedIn<N>) > 4096) return nullptr;        // (the long horizons have no *_in kernel: the segment holds 4 KB)
     else return a.inline_in ? (const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(KArgs) : nullptr;
 }
+
+// The per-QP pointers of a solve.  The kernels of a launch read them from their KArgs; a deferred continuation (TailRec) carries those of the launch its QP
+// came from, which may have been another batch in other buffers.
+struct QpIo {
+    const double *x0, *xref, *foot, *pcom;
+    const uint8_t* contact;
+    double *u_out, *x_out, *y_out;
+    int32_t *status, *iters;
+};
+__device__ __forceinline__ QpIo io_of(const KArgs& a) { return QpIo{a.x0, a.xref, a.foot, a.pcom, a.contact, a.u_out, a.x_out, a.y_out, a.status, a.iters}; }
+// One deferred continuation in HBM: header (16 doubles) + the parked x (newtons), y of slot A, y of slot B of the one-wave ADMM's 64 lanes
+struct TailRecHead {
+    int32_t b, pass, done, pad;      // QP index in ITS launch's arrays, passes completed, iterations completed
+    double rho;                      // re-balanced rho of the pass to run
+    QpIo io;
+};
+static_assert(sizeof(TailRecHead) <= 16 * sizeof(double), "the header of a tail record is 16 doubles");
+constexpr int kTailRecDoubles = 16 + 3 * 64;
+constexpr int kStatusPending = 0;    // status[] of a QP whose continuation is deferred (SRBDQP_PENDING)
 
 // QP index of this workgroup
 #define SRBDQP_QP_INDEX(a) ((a).perm ? (a).perm[blockIdx.x] : (int)blockIdx.x)
@@ -303,12 +330,12 @@ __device__ __forceinline__ void block_max(double (&v)[NV], double* red) {
 // xs (LDS, n doubles) holds the scaled solution u_hat.
 // ---------------------------------------------------------------------------------------------------------
 template <int N, class L, int BT = kThreads>
-__device__ void rollout_and_store(const KArgs& a, int b, double* sm, const double* uh, double* scratch /* >= 12N */) {
+__device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_out, int b, double* sm, const double* uh, double* scratch /* >= 12N */) {
     using S = L;
     constexpr int n = Dims<N>::n;
     const int t = threadIdx.x;
-    for (int c = t; c < n; c += BT) a.u_out[(size_t)b * n + c] = a.s * uh[c];
-    if (!a.x_out) return;
+    for (int c = t; c < n; c += BT) u_out[(size_t)b * n + c] = a.s * uh[c];
+    if (!x_out) return;
     const double* x0 = sm + S::o_x0;
     // phase A1: per-step angular / linear acceleration sums  s_j = J_j u_j (3), sum_contacts u_j / m (3)  -- one step
     // per thread (60 threads x 12 products; a thread per (k, comp) summing all steps j < k itself took 10 x as long, 4 us
@@ -339,7 +366,7 @@ __device__ void rollout_and_store(const KArgs& a, int b, double* sm, const doubl
         scratch[idx] = v;
     }
     __syncthreads();
-    double* xo = a.x_out + (size_t)b * (N + 1) * 13;
+    double* xo = x_out + (size_t)b * (N + 1) * 13;
     for (int idx = t; idx < 13 * (N + 1); idx += BT) {
         const int k = idx / 13, comp = idx % 13;
         double v;
@@ -361,6 +388,10 @@ __device__ void rollout_and_store(const KArgs& a, int b, double* sm, const doubl
         }
         xo[idx] = v;
     }
+}
+template <int N, class L, int BT = kThreads>
+__device__ __forceinline__ void rollout_and_store(const KArgs& a, int b, double* sm, const double* uh, double* scratch /* >= 12N */) {
+    rollout_and_store_to<N, L, BT>(a, a.u_out, a.x_out, b, sm, uh, scratch);
 }
 
 }  // namespace srbdqp

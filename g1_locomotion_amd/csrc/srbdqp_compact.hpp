@@ -349,8 +349,9 @@ __device__ __forceinline__ void dump_presolved(const KArgs& a, int b, int n_eff,
 template <int N, int MAXS> struct SplitWs;
 struct WaveRestart;
 template <int N, int MAXS, bool RST>
-__device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS],
-                                                     double* xs_full, int& status_out, int& iters_out, WaveRestart* rs);   // srbdqp_split.hpp
+__device__ __forceinline__ void admm_wave_iterations(const KArgs& a, const QpIo& io, const double* warm_u, const double* warm_y, int b, double rho_b, double* sm,
+                                                     const double (&kin)[SplitWs<N, MAXS>::KS], double* xs_full, int& status_out, int& iters_out,
+                                                     WaveRestart* rs);   // srbdqp_split.hpp
 
 // TAIL1 (the staged batch-1 instantiation, compiled for one workgroup's worth of registers): the four waves set the problem up, then wave 0 alone runs the
 // one-wave iteration (a K^-1 row per lane, no LDS operation and no barrier in the loop: 0.36 us per iteration against 0.52 for the 4-wave loop at batch 1,
@@ -887,7 +888,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
         int* fin = reinterpret_cast<int*>(sm + S::o_red);
         if (!failed) {
             if (w == 0) {
-                admm_wave_iterations<N, MAXS, false>(a, b, rho_b, sm, kin1, sm + S::o_xs, status, iters, nullptr);
+                admm_wave_iterations<N, MAXS, false>(a, io_of(a), a.warm_u, a.warm_y, b, rho_b, sm, kin1, sm + S::o_xs, status, iters, nullptr);
                 if (lane == 0) { fin[0] = status; fin[1] = iters; }
             }
             __syncthreads();

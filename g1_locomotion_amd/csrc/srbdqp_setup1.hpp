@@ -76,10 +76,12 @@ struct Setup1Smem {
 //                lane-index arithmetic, fp64 constants and literal materialisations in front of the loop and keep them in registers through the whole body
 //                (256 VGPRs + 228 bytes of scratch against 224 + 0, -7 % on every QP); this way only the restarted QPs run the loop's code.
 //                The (x, y) of a pass wait in 1.5 KB of LDS behind the kernel's own.  oracle: SrbdParams.rho_restart_iter / rho_restart_count.
-// One pass of the body.  RP: 0 = the whole solve of a kernel without restart; 1 = first pass of the restart kernel; 2 = a continued pass.  Returns true if another
-// pass follows (rho_b, rs_pass, rs_done updated).
+// One pass of the body.  RP: 0 = the whole solve of a kernel without restart; 1 = first pass of a restart kernel; 2 = a continued pass in the SAME workgroup (the
+// strip is in place); 3 = a continued pass in ANOTHER workgroup (deferred tails, srbdqp_wave_defer_kernel: the strip is rebuilt from the inputs, (x, y) of the
+// pass before were put into park[] by the caller).  io: the QP's own pointers (RP = 3: those of the launch it came from).  Returns true if another pass follows
+// (rho_b, rs_pass, rs_done updated; (x, y) in park[]).
 template <int N, int MAXS, bool FUSED, bool DUMP, bool PHI, int RP>
-__device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double* sm, double& rho_b, int& rs_pass, int& rs_done) {
+__device__ __forceinline__ bool setup1_pass(const KArgs& a, const QpIo& io, const int b, double* sm, double& rho_b, int& rs_pass, int& rs_done) {
     using S = CompactSmem<N, MAXS>;
     using W = SplitWs<N, MAXS>;
     using L1 = Setup1Smem<N, MAXS>;
@@ -106,21 +108,21 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
         }
         __syncthreads();
     } else {
-        const double* gx0 = a.x0 + (size_t)b * 13;
-        const double* gxr = a.xref + (size_t)b * N * 13;
-        const double* gft = a.foot + (size_t)b * N * 12;
-        const uint8_t* gct = a.contact + (size_t)b * N * 4;
+        const double* gx0 = io.x0 + (size_t)b * 13;
+        const double* gxr = io.xref + (size_t)b * N * 13;
+        const double* gft = io.foot + (size_t)b * N * 12;
+        const uint8_t* gct = io.contact + (size_t)b * N * 4;
         if (lane < 13) sm[S::o_x0 + lane] = gx0[lane];
         if (lane >= 32 && lane < 44) sm[S::o_sq + lane - 32] = a.sqrtq[lane - 32];
         for (int i = lane; i < N * 13; i += 64) sm[L1::o_xref + i] = gxr[i];
         for (int i = lane; i < N * 12; i += 64) sm[L1::o_foot + i] = gft[i];
         if (lane < N * 4) sct[lane] = gct[lane] ? 1 : 0;
-        if (a.pcom) {
-            const double* gpc = a.pcom + (size_t)b * N * 3;
+        if (io.pcom) {
+            const double* gpc = io.pcom + (size_t)b * N * 3;
             if (lane < N * 3) sm[L1::o_pcom + lane] = gpc[lane];
         }
         __syncthreads();
-        if (!a.pcom && lane < N * 3) sm[L1::o_pcom + lane] = sm[L1::o_xref + (lane / 3) * 13 + 3 + (lane % 3)];
+        if (!io.pcom && lane < N * 3) sm[L1::o_pcom + lane] = sm[L1::o_xref + (lane / 3) * 13 + 3 + (lane % 3)];
         if (lane < N) {   // Rz(yaw_k)'
             double sn, cs;
             sincos(sm[L1::o_xref + lane * 13 + 2], &sn, &cs);
@@ -176,14 +178,14 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
     if (RP != 2 && (imisc[1] != 0 || na == 0)) {   // bound violated (status -2) or nothing to solve (all forces 0): finished here
         if constexpr (DUMP) { if (lane == 0) a.ub_out[(size_t)b * m] = (imisc[1] != 0) ? -1.0 : 0.0; return false; }   // assembly dump: nothing to show
         for (int c = lane; c < n; c += 64) xs0[c] = 0.0;
-        if (a.y_out) for (int i = lane; i < m; i += 64) a.y_out[(size_t)b * m + i] = 0.0;
+        if (io.y_out) for (int i = lane; i < m; i += 64) io.y_out[(size_t)b * m + i] = 0.0;
         if (lane == 0) {
-            if (a.status) a.status[b] = (imisc[1] != 0) ? kStatusContactBound : 1;
-            if (a.iters) a.iters[b] = a.iters_base;
+            if (io.status) io.status[b] = (imisc[1] != 0) ? kStatusContactBound : 1;
+            if (io.iters) io.iters[b] = a.iters_base;
             if constexpr (!FUSED) ws[S::o_misc + 1] = 1.0;
         }
         __syncthreads();
-        rollout_and_store<N, S, 64>(a, b, sm, xs0, xs0 + n);
+        rollout_and_store_to<N, S, 64>(a, io.u_out, io.x_out, b, sm, xs0, xs0 + n);
         return false;
     }
 
@@ -272,10 +274,10 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
     __syncthreads();
     WSTAMP(a, b, 2);
     if constexpr (RP != 2) for (int c = lane; c < n_eff; c += 64) sm[S::o_q + c] = gt_eval(c);      // (a continued pass: q stays)
-    if (RP == 2 || a.warm_u) {   // P x^0 through the tables; a continued pass: of the x the pass before left (in newtons, one per lane), as a second launch would
+    if (RP >= 2 || a.warm_u) {   // P x^0 through the tables; a continued pass: of the x the pass before left (in newtons, one per lane), as a second launch would
         double* TF = sm + L1::o_tf;
         for (int c = lane; c < n_eff; c += 64)
-            sm[L1::o_x0c + c] = (RP == 2 ? park[c] : a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)]) / a.s;
+            sm[L1::o_x0c + c] = (RP >= 2 ? park[c] : a.warm_u[(size_t)b * n + 3 * act[c / 3] + (c % 3)]) / a.s;
         __syncthreads();
         for (int tt = lane; tt < 6 * N; tt += 64) {
             const int j = tt / 6, comp = tt - 6 * j;
@@ -579,10 +581,14 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
             const int left = a.max_iter - rs_done;                                   // the cap is on the total
             rs.pass = rs_pass;
             rs.more = rs_pass < a.restart_max && a.restart_every < left;
+            // deferred tails: the continuation goes to a list of tail_cap records; with less room than every wave in flight could claim at once, this QP
+            // simply runs on at its rho (the host sizes the lists so that this cannot happen: (rho_restart_count + 1) records per QP of a launch)
+            if (a.tail_lists) rs.more = rs.more && (a.tail_cnt[a.tail_iout] + 4096 < a.tail_cap);
             rs.kcap = rs.more ? a.restart_every : left;
             rs.park = park;
             int status = -1, iters = 0;
-            admm_wave_iterations<N, MAXS, true>(a, b, rho_b, sm, kin, sm + SplitSmem<N, MAXS>::o_xs, status, iters, &rs);
+            admm_wave_iterations<N, MAXS, true>(a, io, RP == 1 ? a.warm_u : nullptr, RP == 1 ? a.warm_y : nullptr, b, rho_b, sm, kin, sm + SplitSmem<N, MAXS>::o_xs,
+                                                status, iters, &rs);
             rs_done += iters;
             if (status == 2 && rs.more) {   // (wave-uniform) at the mark, not converged: another pass
                 rho_b = restart_rho_of(rho_b, rs.v);
@@ -590,7 +596,7 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const int b, double*
                 __syncthreads();
                 return true;
             }
-            admm_wave_finish<N, MAXS>(a, b, sm, status, rs_done);
+            admm_wave_finish<N, MAXS>(a, io, b, sm, status, rs_done);
         }
         WSTAMP(a, b, 10);
         WSTAMP(a, b, 11);
@@ -612,11 +618,99 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     if (SRBDQP_RESTART_SKIP(a, b)) return;
     double rho_b = SRBDQP_RHO_OF(a, b);
     int rs_pass = 0, rs_done = 0;
+    const QpIo io = io_of(a);
     if constexpr (!RST) {
-        setup1_pass<N, MAXS, FUSED, DUMP, PHI, 0>(a, b, sm, rho_b, rs_pass, rs_done);
+        setup1_pass<N, MAXS, FUSED, DUMP, PHI, 0>(a, io, b, sm, rho_b, rs_pass, rs_done);
     } else {
-        bool again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 1>(a, b, sm, rho_b, rs_pass, rs_done);
-        while (again) again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 2>(a, b, sm, rho_b, rs_pass, rs_done);
+        bool again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 1>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        while (again) again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+    }
+}
+
+// ---- deferred tails (SRBDQP_FLAG_DEFER_TAIL) --------------------------------------------------------------------------------------------------------------
+// A launch of the restart kernel above lasts as long as its slowest QP: up to three set-ups and 250 iterations on one wave (0.24 ms alone on the device, when
+// the bulk of 4096 QPs is done after 0.12 ms) -- which is why the step rate of round 3 leaned on a longest-first dispatch hint and on a second stream.  Here no
+// workgroup runs more than ONE pass: a QP that reaches a restart mark unconverged parks (x, y), re-balances its rho and appends itself -- with the pointers
+// of its own launch -- to a list in HBM; the first tail_wgs workgroups of the NEXT launch on the same stream (another batch, other buffers) each take one record,
+// rebuild the strip from the QP's inputs and run its next pass.  Same passes, same arithmetic, same statuses and iteration counts as the restart in place; the
+// outputs of a deferred QP arrive one or two launches later (status[] says SRBDQP_PENDING until then; srbdqp_flush() runs what is left).  No loop around the
+// body anywhere: both arms are straight-line code.
+__device__ __forceinline__ unsigned long long unis_u64(unsigned long long v) {
+    int lo, hi;
+    asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"((int)(unsigned)v), "v"((int)(unsigned)(v >> 32)));
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+template <typename T> __device__ __forceinline__ T* unis_ptr(T* p) { return reinterpret_cast<T*>(unis_u64(reinterpret_cast<unsigned long long>(p))); }
+
+__device__ __forceinline__ double* tail_claim(const KArgs& a) {   // a free record of the list this launch appends to (null: full -- cannot happen, see rs.more)
+    int slot = 0;
+    if (threadIdx.x == 0) slot = atomicAdd(a.tail_cnt + a.tail_iout, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= a.tail_cap) return nullptr;
+    return reinterpret_cast<double*>(a.tail_lists) + ((size_t)a.tail_iout * (size_t)a.tail_cap + (size_t)slot) * kTailRecDoubles;
+}
+
+__device__ __forceinline__ void tail_export(const KArgs& a, const QpIo& io, int b, double rho_b, int rs_pass, int rs_done, const double* park) {
+    const int lane = threadIdx.x;
+    double* rec = tail_claim(a);
+    if (!rec) return;
+    if (lane == 0) {
+        TailRecHead* hd = reinterpret_cast<TailRecHead*>(rec);
+        hd->b = b; hd->pass = rs_pass; hd->done = rs_done; hd->pad = 0; hd->rho = rho_b; hd->io = io;
+        if (io.status) io.status[b] = kStatusPending;
+    }
+    rec[16 + lane] = park[lane]; rec[80 + lane] = park[64 + lane]; rec[144 + lane] = park[128 + lane];
+}
+
+// FLUSH: the continuations alone (srbdqp_flush: a launch with no QPs of its own; a kernel of its own name, so that profiles keep the two apart)
+template <int N, int MAXS, bool FLUSH = false>
+__global__ __launch_bounds__(64, 2) void srbdqp_wave_defer_kernel(KArgs a) {
+    static_assert(Setup1Smem<N, MAXS>::supported && 4 * N <= 64, "the one-wave kernel's limits");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    using L1 = Setup1Smem<N, MAXS>;
+    const int lane = threadIdx.x;
+    const int T = a.tail_wgs;
+    double* const park = sm + L1::o_end;
+    if ((int)blockIdx.x < T) {
+        // ---- a continuation of an earlier launch (first in the grid: these are the long ones)
+        const int i = blockIdx.x;
+        int cnt = a.tail_cnt[a.tail_iin];
+        cnt = cnt < a.tail_cap ? cnt : a.tail_cap;
+        if (i == 0 && lane == 0) {
+            a.tail_cnt[a.tail_izero] = 0;                                                  // the list the NEXT launch appends to
+            __hip_atomic_store(a.tail_seen, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host sizes later launches' tail_wgs from this
+        }
+        const double* lin = reinterpret_cast<const double*>(a.tail_lists) + (size_t)a.tail_iin * (size_t)a.tail_cap * kTailRecDoubles;
+        for (int r = i + T; r < cnt; r += T) {   // more records than tail workgroups (the host's estimate was low): they move on to the next launch unchanged
+            double* dst = tail_claim(a);
+            const double* src = lin + (size_t)r * kTailRecDoubles;
+            if (dst) {
+                dst[lane] = src[lane]; dst[64 + lane] = src[64 + lane]; dst[128 + lane] = src[128 + lane];
+                if (lane < kTailRecDoubles - 192) dst[192 + lane] = src[192 + lane];
+            }
+        }
+        if (i >= cnt) return;
+        const double* rec = lin + (size_t)i * kTailRecDoubles;
+        const TailRecHead* hd = reinterpret_cast<const TailRecHead*>(rec);
+        QpIo io;
+        io.x0 = unis_ptr(hd->io.x0); io.xref = unis_ptr(hd->io.xref); io.foot = unis_ptr(hd->io.foot); io.pcom = unis_ptr(hd->io.pcom);
+        io.contact = unis_ptr(hd->io.contact); io.u_out = unis_ptr(hd->io.u_out); io.x_out = unis_ptr(hd->io.x_out); io.y_out = unis_ptr(hd->io.y_out);
+        io.status = unis_ptr(hd->io.status); io.iters = unis_ptr(hd->io.iters);
+        const int b = __builtin_amdgcn_readfirstlane(hd->b);
+        int rs_pass = __builtin_amdgcn_readfirstlane(hd->pass), rs_done = __builtin_amdgcn_readfirstlane(hd->done);
+        double rho_b = unis(hd->rho);
+        park[lane] = rec[16 + lane]; park[64 + lane] = rec[80 + lane]; park[128 + lane] = rec[144 + lane];
+        __syncthreads();
+        if (setup1_pass<N, MAXS, true, false, false, 3>(a, io, b, sm, rho_b, rs_pass, rs_done)) tail_export(a, io, b, rho_b, rs_pass, rs_done, park);
+    } else if constexpr (!FLUSH) {
+        // ---- a QP of this launch: its first pass
+        const int wg = (int)blockIdx.x - T;
+        if (wg >= a.B) return;
+        const int b = a.perm ? a.perm[wg] : wg;
+        double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+        int rs_pass = 0, rs_done = 0;
+        const QpIo io = io_of(a);
+        if (setup1_pass<N, MAXS, true, false, false, 1>(a, io, b, sm, rho_b, rs_pass, rs_done)) tail_export(a, io, b, rho_b, rs_pass, rs_done, park);
     }
 }
 

@@ -39,9 +39,11 @@ struct WaveRestart {
     float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 };
 
+// io: the QP's own pointers (the launch's, or -- a deferred continuation -- those of the launch it came from); warm_u / warm_y: the caller's warm start or null
+// (a continuation starts from rs->park, never from these).
 template <int N, int MAXS, bool RST>
-__device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS],
-                                                     double* xs_full, int& status_out, int& iters_out, WaveRestart* rs) {
+__device__ __forceinline__ void admm_wave_iterations(const KArgs& a, const QpIo& io, const double* warm_u, const double* warm_y, int b, double rho_b, double* sm,
+                                                     const double (&kin)[SplitWs<N, MAXS>::KS], double* xs_full, int& status_out, int& iters_out, WaveRestart* rs) {
     using S = CompactSmem<N, MAXS>;
     using W = SplitWs<N, MAXS>;
     constexpr int n = Dims<N>::n, m = Dims<N>::m, KS = W::KS;
@@ -80,10 +82,10 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, doub
     int status = -1, iters = 0;
     if (!failed) {
         const double qv = active ? sm[S::o_q + lane] : 0.0;
-        double x = (active && a.warm_u) ? a.warm_u[(size_t)b * n + 3 * gc + ax] / a.s : 0.0;
+        double x = (active && warm_u) ? warm_u[(size_t)b * n + 3 * gc + ax] / a.s : 0.0;
         double cpx = active ? sm[S::o_px0 + lane] : 0.0, spxA = 0.0, spxB = 0.0;
-        double yA = (rowA && a.warm_y) ? a.warm_y[(size_t)b * m + irowA] : 0.0;
-        double yB = (rowB && a.warm_y) ? a.warm_y[(size_t)b * m + irowB] : 0.0;
+        double yA = (rowA && warm_y) ? warm_y[(size_t)b * m + irowA] : 0.0;
+        double yB = (rowB && warm_y) ? warm_y[(size_t)b * m + irowB] : 0.0;
         int kmax = a.max_iter;
         if constexpr (RST) {
             kmax = rs->kcap;
@@ -177,9 +179,9 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, doub
             parked = status == 2 && rs->more;
             if (parked) { rs->park[lane] = a.s * x; rs->park[64 + lane] = yA; rs->park[128 + lane] = yB; }
         }
-        if (a.y_out && (!a.y_capped_only || status == 2) && !parked) {
-            if (rowA) a.y_out[(size_t)b * m + irowA] = yA;
-            if (rowB) a.y_out[(size_t)b * m + irowB] = yB;
+        if (io.y_out && (!a.y_capped_only || status == 2) && !parked) {
+            if (rowA) io.y_out[(size_t)b * m + irowA] = yA;
+            if (rowB) io.y_out[(size_t)b * m + irowB] = yB;
         }
     }
     status_out = status; iters_out = iters;
@@ -187,7 +189,7 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, int b, doub
 
 // What follows the iterations of the one-wave kernels: the duals of the eliminated rows, status, iteration count, roll-out
 template <int N, int MAXS>
-__device__ __forceinline__ void admm_wave_finish(const KArgs& a, int b, double* sm, int status, int iters) {
+__device__ __forceinline__ void admm_wave_finish(const KArgs& a, const QpIo& io, int b, double* sm, int status, int iters) {
     using S = CompactSmem<N, MAXS>;
     using L = SplitSmem<N, MAXS>;
     constexpr int m = Dims<N>::m;
@@ -195,24 +197,25 @@ __device__ __forceinline__ void admm_wave_finish(const KArgs& a, int b, double* 
     double* xs_full = sm + L::o_xs;
     const bool failed = sm[S::o_misc] != 0.0;
     __syncthreads();
-    if (a.y_out && (!a.y_capped_only || status == 2)) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
+    if (io.y_out && (!a.y_capped_only || status == 2)) {   // rows of eliminated (swing) contacts, or of a failed solve: 0
         const uint8_t* sct = reinterpret_cast<const uint8_t*>(sm + S::o_ct);
         for (int i = lane; i < m; i += 64)
-            if (failed || sct[i / 5] == 0) a.y_out[(size_t)b * m + i] = 0.0;
+            if (failed || sct[i / 5] == 0) io.y_out[(size_t)b * m + i] = 0.0;
     }
     if (lane == 0) {
-        if (a.status) a.status[b] = status;
-        if (a.iters) a.iters[b] = iters + a.iters_base;
+        if (io.status) io.status[b] = status;
+        if (io.iters) io.iters[b] = iters + a.iters_base;
     }
-    rollout_and_store<N, S, 64>(a, b, sm, xs_full, sm + L::o_scr);
+    rollout_and_store_to<N, S, 64>(a, io.u_out, io.x_out, b, sm, xs_full, sm + L::o_scr);
 }
 
 // ADMM iterations + roll-out of one QP on one wave (the one-wave kernels).  sm: the persistent strip at [0, S::o_R) and SplitSmem's vectors behind it.
 template <int N, int MAXS>
 __device__ __forceinline__ void admm_wave_body(const KArgs& a, int b, double rho_b, double* sm, const double (&kin)[SplitWs<N, MAXS>::KS]) {
     int status = -1, iters = 0;
-    admm_wave_iterations<N, MAXS, false>(a, b, rho_b, sm, kin, sm + SplitSmem<N, MAXS>::o_xs, status, iters, nullptr);
-    admm_wave_finish<N, MAXS>(a, b, sm, status, iters);
+    const QpIo io = io_of(a);
+    admm_wave_iterations<N, MAXS, false>(a, io, a.warm_u, a.warm_y, b, rho_b, sm, kin, sm + SplitSmem<N, MAXS>::o_xs, status, iters, nullptr);
+    admm_wave_finish<N, MAXS>(a, io, b, sm, status, iters);
 }
 
 template <int N, int MAXS>

@@ -182,6 +182,11 @@ class BatchMPC:
         _lib.check(self._lib.srbdqp_set_schedule_hint(self._h, C.c_void_p(int(iters_prev_ptr)) if iters_prev_ptr else None,
                                                       int(length) if iters_prev_ptr else 0), self._h)
 
+    def flush(self, stream=0):
+        """FLAG_DEFER_TAIL: enqueue the continuations no later solve has picked up (srbdqp_flush); stream = a hipStream_t address, 0 = every
+        stream this engine has launched on.  Does not synchronise."""
+        _lib.check(self._lib.srbdqp_flush(self._h, C.c_void_p(int(stream)) if stream else None), self._h)
+
     # -- low-latency staged API (small batches; the single-robot control loop) --------------------------
     def stage(self):
         """NumPy views of the library's pinned, GPU-mapped staging arrays (dict; first axis = capacity)."""

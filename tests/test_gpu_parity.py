@@ -934,3 +934,60 @@ def test_assembly_of_a_flight_phase_qp(torch_first, built_lib, kernel):
         np.testing.assert_array_equal(got["l"][b], qp["l"])
         np.testing.assert_array_equal(got["u"][b], qp["u"])
     assert np.all(got["P"][1] == 0.0) and np.all(got["q"][1] == 0.0)
+
+
+@pytest.mark.parametrize("N,every,count,schedule,B", [(10, 0, 0, "single", 4096), (10, 25, 3, "single", 1024), (8, 30, 2, "single", 1024), (4, 25, 3, "double", 512)])
+def test_deferred_tails_equal_the_restart_in_place(torch_first, built_lib, N, every, count, schedule, B):
+    """SRBDQP_FLAG_DEFER_TAIL: a QP that reaches a restart mark unconverged rides in the next solve on the stream instead of holding its own launch up.  Same
+    passes, same arithmetic: after srbdqp_flush() every status, iteration count, force and state equals the restart in place, batch by batch -- over a
+    pipeline of different batches in different buffers, a batch of another size in between, a dispatch hint, and two launch streams through one handle."""
+    torch = torch_first
+    from g1_locomotion_amd import BatchMPC, _lib
+    dev = torch.device("cuda", 0)
+    kw = dict(max_contacts_per_step=2 if schedule == "single" else 4, kernel=_lib.KERNEL_WAVE)
+    if every:
+        kw.update(rho_restart_iter=every, rho_restart_count=count)
+    sizes = [B, B, B // 2, B, B]
+    batches = [orc.synthetic_batch(sizes[j], N, seed=1000 + 7 * j, schedule=schedule) for j in range(len(sizes))]
+    d_in = [[torch.from_numpy(v).to(dev) for v in hb] for hb in batches]
+
+    def outputs():
+        return [dict(u=torch.zeros((sz, N, 12), dtype=torch.float64, device=dev), x=torch.zeros((sz, N + 1, 13), dtype=torch.float64, device=dev),
+                     st=torch.full((sz,), -77, dtype=torch.int32, device=dev), it=torch.zeros(sz, dtype=torch.int32, device=dev)) for sz in sizes]
+
+    def run(eng, outs, streams, hint):
+        for j, (d, o) in enumerate(zip(d_in, outs)):
+            s = streams[j % len(streams)]
+            if hint and j > 0 and sizes[j] == sizes[0]:
+                eng.set_schedule_hint(ref_outs[0]["it"].data_ptr(), sizes[0])
+            else:
+                eng.set_schedule_hint(0, 0)
+            eng.solve_device(sizes[j], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), o["u"].data_ptr(), x_out=o["x"].data_ptr(),
+                             status=o["st"].data_ptr(), iters=o["it"].data_ptr(), stream=s.cuda_stream)
+
+    s0, s1 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ref_outs = outputs()
+    with BatchMPC(horizon=N, **kw) as eng:                          # the restart in place
+        if B < 4096 and not every:
+            pytest.skip("automatic restart needs 4096 QPs")
+        run(eng, ref_outs, [s0], False)
+        torch.cuda.synchronize(dev)
+        assert eng.kernel_name().startswith("wave_f64"), eng.kernel_name()
+    restarted = sum(int((o["it"] > (every or 55)).sum()) for o in ref_outs)
+    assert restarted >= 8, restarted                               # the marks are really passed
+    for streams, hint in (([s0], False), ([s0], True), ([s0, s1], False)):
+        outs = outputs()
+        with BatchMPC(horizon=N, flags=_lib.FLAG_DEFER_TAIL, **kw) as eng:
+            run(eng, outs, streams, hint)
+            assert eng.kernel_name().startswith("wave_defer_f64"), eng.kernel_name()
+            torch.cuda.synchronize(dev)
+            pending = sum(int((o["st"] == _lib.PENDING).sum()) for o in outs)
+            assert pending >= 1                                    # the last launches' continuations are still waiting
+            assert all(int((o["st"] == -77).sum()) == 0 for o in outs)
+            eng.flush()
+            torch.cuda.synchronize(dev)
+            eng.flush()                                            # nothing left: a no-op
+            torch.cuda.synchronize(dev)
+        for j, (o, r) in enumerate(zip(outs, ref_outs)):
+            assert torch.equal(o["st"], r["st"]) and torch.equal(o["it"], r["it"]), (j, streams, hint)
+            assert float((o["u"] - r["u"]).abs().max()) <= 1e-9 and float((o["x"] - r["x"]).abs().max()) <= 1e-11, (j, float((o["u"] - r["u"]).abs().max()))

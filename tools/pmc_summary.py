@@ -86,7 +86,19 @@ def main():
     else:
         bound = "latency (valu %.0f %%, mfma %.0f %%, lds %.0f %% busy; waves issue %.0f %%, issue-stalled %.0f %%, parked on s_waitcnt / barriers %.0f %% of their time)" % (
             100 * vu, 100 * mu, 100 * lu, 100 * ws["issuing"], 100 * ws["issue_stalled"], 100 * ws["parked_waitcnt_or_barrier"])
-    d = {"round": rnd, "bench_kernel_name": kname, "batch_per_launch": B, "horizon": N,
+    # which build the counters were taken on: bench.py compares library_sha256 with the library it has loaded and says so in its line
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libp = os.environ.get("SRBDQP_LIB") or os.path.join(root, "g1_locomotion_amd", "libsrbdqp.so")
+    try:
+        lib_sha = hashlib.sha256(open(libp, "rb").read()).hexdigest()
+    except OSError:
+        lib_sha = None
+    try:
+        git_rev = open(os.path.join(root, "g1_locomotion_amd", "libsrbdqp.rev")).read().strip()      # written by the build (tools/build.sh, __graft_entry__.build)
+    except OSError:
+        git_rev = None
+    d = {"round": rnd, "bench_kernel_name": kname, "batch_per_launch": B, "horizon": N, "library_sha256": lib_sha, "git_rev": git_rev,
          "dominant_kernel": d0["rocprof_kernel_trace"]["name"],
          "workload": "bench.py --streams 1 ...: one solve at a time; see `command`",
          "command": "tools/pmc_collect.sh (one rocprofv3 --pmc <group> --kernel-trace pass per counter group) + rocprofv3 --kernel-trace --stats on the same bench command",
