@@ -152,11 +152,11 @@ def _resolved_restart(N, B, it, cnt, max_iter, kname):
     wave = kname.startswith("wave_")
     auto = it == 0
     if auto:
-        it = (100 if N <= 16 else 125) if N > 10 else (55 if (wave and B >= 4096) else 0)
+        it = (100 if N <= 16 else 125) if N > 10 else 55
     if it <= 0 or it >= max_iter:
         return {"every": 0, "count": 0, "how": "off"}
-    cnt = (cnt if cnt > 0 else (2 if auto else 1)) if wave else 1
-    how = "a second launch over the same grid"
+    cnt = cnt if cnt > 0 else (2 if (auto and N <= 10) else 1)
+    how = "one more launch over the same grid per pass (only the workgroups of the capped QPs do anything)"
     if wave:
         how = ("deferred: a QP at a mark hands itself to the next launch on its stream (srbdqp_flush completes the last ones)" if "defer" in kname
                else "in place, inside the one-wave kernel")
@@ -719,34 +719,28 @@ def latency_batch1(synth, calls=10000):
         return pct(ts)
 
     def closed_loop(warm, n):
-        """a CORRELATED sequence: one robot stepping in place (msgs.AlternatingGait), every control step's state = the state the
-        previous plan predicted (the linear model as the plant) with a push every 40 steps; cold = every solve from zero, warm = from
-        the previous plan and duals shifted by one step -- the receding-horizon warm start, on consecutive QPs of the same robot"""
-        from g1_locomotion_amd import msgs
+        """a CORRELATED sequence: segments of 25 consecutive control steps, each starting from a synthetic state of the mixed gait (a large
+        disturbance) and then receding -- every state the previous plan's prediction, the contact schedule shifted by one step; cold = every solve
+        from zero, warm = from the previous plan and duals shifted by one step (the receding-horizon warm start; reset at a segment's start)"""
+        L = 25
+        segs = (n + 50 + L - 1) // L
+        X0, XR, FT, CT = synth.synthetic_batch(segs, HORIZON, seed=77, schedule="mixed")
         mpc = MPC(dt=0.04, horizon=HORIZON, warm_start=warm, strict=False)
         mpc.init_matrices()
-        gait = msgs.AlternatingGait(dt=0.04)
-        feet = np.array([0.0, 0.0645, 0.0, 0.17, 0.0645, 0.0, 0.0, -0.0645, 0.0, 0.17, -0.0645, 0.0])
-        com = np.array([0.085, 0.0, 0.598])
-        x = np.zeros(13); x[3:6] = com + np.array([0.01, -0.01, -0.01]); x[0] = 0.03; x[12] = -9.80665
-        rng = np.random.default_rng(5)
-        ts, its = [], []
-        c_h = [feet.copy() for _ in range(HORIZON)]
-        for k in range(n + 50):
-            mpc.x_ref_hor[:] = 0.0
-            mpc.x_ref_hor[:, 2] = x[2]; mpc.x_ref_hor[:, 3:6] = com; mpc.x_ref_hor[:, 12] = x[12]
-            ct_h = list(gait.contact_horizon(0.04 * k, HORIZON))
-            pc = np.repeat(x[3:6][None, :], HORIZON, axis=0)
-            t = time.perf_counter()
-            u0, xo = mpc.update(ct_h, c_h, pc, x_current=x.reshape(13, 1), one_rollout=True)
-            ts.append(time.perf_counter() - t); its.append(mpc.iters)
-            x = xo[1].copy()
-            if k % 40 == 5:
-                x[9:12] += rng.uniform(-0.08, 0.08, 3) * np.array([1.0, 1.0, 0.3])
-            if not np.all(np.isfinite(x)) or abs(x[5] - com[2]) > 0.3:      # (never seen: restart the robot rather than time nonsense)
-                x[:] = 0.0; x[3:6] = com; x[12] = -9.80665
+        ts, its, capped = [], [], 0
+        for s in range(segs):
+            x = X0[s].copy()
+            mpc.x_ref_hor[:] = XR[s]
+            c_h = list(FT[s])
+            mpc.reset_warm_start()
+            for j in range(L):
+                ct_h = list(np.roll(CT[s], -j, axis=0))
+                t = time.perf_counter()
+                u0, xo = mpc.update(ct_h, c_h, None, x_current=x.reshape(13, 1), one_rollout=True)
+                ts.append(time.perf_counter() - t); its.append(mpc.iters); capped += mpc.status == 2
+                x = xo[1].copy()
         mpc.close()
-        return dict(pct(ts), mean_iters=float(np.mean(its[50:])))
+        return dict(pct(ts), mean_iters=float(np.mean(its[50:])), max_iter_rate=capped / len(ts))
 
     out["cold"] = mpc_update("single", False, calls)
     out["c_abi"] = c_abi("single", calls)
@@ -778,9 +772,10 @@ def latency_batch1(synth, calls=10000):
                    "in rotation, every solve from zero); c_abi: srbdqp_solve_staged_f64(B=1) alone on that gait (everything between the inputs and the forces); eps1e-3: OSQP's default "
                    "tolerance instead of 1e-6; c_abi_double_support / mpc_update_double_support: the same two calls on the REFERENCE'S OWN call "
                    "pattern, all four contact points active on every step, per-step lists as the reference passes them (run_simulation.py:94-101,106); "
-                   "..._arrays: (N, 12) / (N, 4) arrays instead of the lists; closed_loop_cold / closed_loop_warm: one robot stepping in place, "
-                   "consecutive control steps (each state = the previous plan's prediction, a push every 40 steps) -- cold from zero, warm from the "
-                   "previous plan and duals shifted by one step: the receding-horizon warm start on a correlated sequence; c_abi_prepared_phase2: "
+                   "..._arrays: (N, 12) / (N, 4) arrays instead of the lists; closed_loop_cold / closed_loop_warm: segments of 25 "
+                   "consecutive control steps, each from a synthetic mixed-gait state and then receding (every state the previous plan's prediction, the contact schedule "
+                   "shifted by one step) -- cold from zero, warm from the previous plan and duals shifted by one step: the receding-horizon warm start on a correlated "
+                   "sequence; max_iter_rate = share of the solves that end at the iteration cap; c_abi_prepared_phase2: "
                    "srbdqp_solve_prepared_f64 alone after a finished srbdqp_prepare_staged_f64 -- a different mode of operation (the "
                    "factorisation ran before the state arrived), listed beside c_abi, not instead of it")
     return out
@@ -813,7 +808,7 @@ def cpu_baseline(config, N, batch):
     import srbd_oracle as orc
     import c_oracle
     x0, xr, ft, ct = batch
-    r_iter, r_count = orc.default_restart(N, one_wave=CONFIGS[config]["maxs"] <= 2 and x0.shape[0] >= 4096)
+    r_iter, r_count = orc.default_restart(N)
     p = orc.params_for(N, rho_restart_iter=r_iter, rho_restart_count=r_count)    # as the engine runs the config by default
     cores = _cpu_share()
     # sized for ~10-30 s of CPU work: N = 10 -> 4096 QPs x 24 (0.15 ms per QP and thread), N = 20 -> 1024 QPs x 2 (dense

@@ -50,6 +50,7 @@ struct srbdqp_handle {
         char* rs = nullptr; size_t rs_items = 0, rs_rows = 0;
         float* resid = nullptr; double* ybuf = nullptr;
         int32_t* stbuf = nullptr;
+        double* rhobuf[2] = {nullptr, nullptr};   // rho a restart pass ran its QPs with, for the pass behind it (alternating)
         // deferred tails (SRBDQP_FLAG_DEFER_TAIL): three rotating lists of continuation records, their counts, and a GPU-mapped host word through
         // which every launch reports how many records it found (launch_wave_defer sizes the next launches' tail workgroups from it)
         char* tail = nullptr; int32_t* tail_cnt = nullptr; size_t tail_cap = 0;
@@ -73,7 +74,9 @@ struct srbdqp_handle {
     bool staged_call = false;      // inside srbdqp_solve_staged_f64 (with or without the completion word)
     int staged_neff = 0;           // ... with the largest number of presolved variables (3 x stance contacts) among its QPs
     bool lazy_restart = false;     // staged path: run only the first pass; the host starts the second one if a status asks for it
-    bool lazy_pending = false;     // ... and the last solve really was such a first pass: last_args are its arguments
+    bool lazy_pending = false;     // ... and the last solve really was such a first pass: last_args are its arguments,
+    int lazy_rcount = 1;           //     this many restart passes may follow it,
+    StreamSlot* lazy_slot = nullptr;   //  with the buffers of this launch-stream slot
     int32_t prepared_B = 0; int prepared_maxs = 4; bool prepared_pcom = false;   // two-phase call: a set-up is pending
     KArgs last_args;               // arguments of that first pass (for the lazily started second pass)
     // kernels whose dynamic-LDS limit has been raised on this handle's device (function attributes are per device, and a
@@ -584,28 +587,31 @@ struct Carver {
 
 // Iteration at which a solve of this handle re-balances rho (0 = never), and how many times it may (*count).  srbdqp_config.rho_restart_iter: > 0 that
 // iteration, < 0 off, 0 = automatic:
-//  * N > 10, every kernel: 100 (125 above N = 16), once, as a second launch -- the long horizons have a 1 - 3 % tail of slow QPs (N = 20 single support: 98.4 %
-//    solved without, 99.3 % with; round 3, N = 20 double support with the (0.7, 4) penalties: 17 % of the QPs run past 80 iterations, 8 % past 100, 3 % past 125 --
-//    an earlier restart sends too many through a second set-up: 80 instead of 125 cost configs[2] 10 % for 99.90 % instead of 99.89 % solved) and at their 3 - 20 ms
-//    steps the second launch costs 3 - 5 %;
-//  * N <= 10 on the one-wave kernel (wave = true): every 55 iterations, up to twice, IN PLACE (srbdqp_setup1.hpp RST) -- 99.3 % -> 99.93 % of the configs[1] QPs solved
-//    inside the same 250-iteration cap, at fewer iterations in total (34.8 -> 33.8) and 3 % of the throughput.  Measured on the device (configs[1], 4 x 4096 QPs;
-//    M QP/s, solved, duration of one isolated launch): off 30.6, 0.9929, 0.19 ms; 80 x 1 30.2, 0.9981, 0.21; 65 x 2 30.0, 0.9991, 0.24; 55 x 2 29.6, 0.9993, 0.24;
-//    70 x 3 29.2, 0.9996, 0.27; 60 x 3 29.9 (another box), 0.9998; 50 x 3 29.5, 0.9999 -- every restarted QP repeats two thirds of a set-up, which is most of a
-//    solve at these sizes, and the slowest QP of a launch now carries up to two of them (a launch alone on the device lasts as long as its slowest QP:
-//    without the longest-first hint the step rate drops by a fifth);
-//    automatic for batches of 4096 QPs and more only: a restarted QP is a chain of up to 250 iterations and three set-ups (0.24 ms alone on the device), and a
-//    call cannot end before its slowest QP -- 512 QPs per call: 7.2 -> 5.2 M QP/s with the restart on; an explicit rho_restart_iter applies at every batch size;
-//  * the other N <= 10 solves: off (the batch kernels run 0.16 ms steps, where a second launch costs 15 %: DESIGN.md).
+//  * N > 10: once after 100 (125 above N = 16) iterations -- the long horizons have a 1 - 3 % tail of slow QPs (N = 20 single support: 98.4 % solved without,
+//    99.3 % with; N = 20 double support with the (0.7, 4) penalties: 17 % of the QPs run past 80 iterations, 8 % past 100, 3 % past 125 -- an earlier restart sends
+//    too many through a second set-up: 80 instead of 125 cost configs[2] 10 % for 99.90 % instead of 99.89 % solved);
+//  * N <= 10: every 55 iterations, up to twice, each time from the rho of the pass before it -- 99.3 % -> 99.93 % of the configs[1] QPs solved inside the same
+//    250-iteration cap, at fewer iterations in total (34.8 -> 33.8).  Measured on the one-wave kernel (configs[1], 4 x 4096 QPs; M QP/s, solved, duration of one
+//    isolated launch): off 30.6, 0.9929, 0.19 ms; 80 x 1 30.2, 0.9981, 0.21; 65 x 2 30.0, 0.9991, 0.24; 55 x 2 29.6, 0.9993, 0.24; 70 x 3 29.2, 0.9996, 0.27;
+//    50 x 3 29.5, 0.9999.
+// Since round 4 the rule is the SAME for every kernel and batch size (round 3: at N <= 10 only where the one-wave kernel ran a call of >= 4096 QPs, so one QP
+// could end SOLVED in a large batch and MAX_ITER alone): what differs is how the passes run --
+//    one-wave kernel:      in place, inside the kernel (srbdqp_setup1.hpp RST), or handed to the next launch on the stream (SRBDQP_FLAG_DEFER_TAIL);
+//    every other kernel:   one more launch over the same grid per pass, in which only the workgroups of the QPs the pass before left at its cap do anything
+//                          (the rho of a pass reaches the next one through StreamSlot::rhobuf);
+//    staged (batch-1) call: the host starts a further pass only when a status[] asks for it (4 % of the calls take a second launch, 1 % a third).
+// The price where a call is small: it cannot end before its slowest QP, and a restarted one is a chain of up to three set-ups and 250 iterations (0.22 ms
+// against 0.16 ms for 250 iterations at one rho): 512 QPs per call on the one-wave kernel 7.2 -> 5.2 M QP/s.  rho_restart_iter = -1 buys that back.
 inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B, bool wave = false, int* count = nullptr) {
+    (void)maxs; (void)B; (void)wave;
     const srbdqp_config& c = h->cfg;
     const int rk = resolve_kernel(c);
     if (count) *count = 1;
     if (rk != SRBDQP_KERNEL_COMPACT && rk != SRBDQP_KERNEL_WRENCH) return 0;   // v0 / v1 have no restart
     int r = c.rho_restart_iter;
     const bool automatic = r == 0;
-    if (automatic) r = (c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : ((wave && B >= kRestartMinBatch) ? 55 : 0);
-    if (count && wave) *count = c.rho_restart_count > 0 ? c.rho_restart_count : (automatic ? 2 : 1);
+    if (automatic) r = (c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : 55;
+    if (count) *count = c.rho_restart_count > 0 ? c.rho_restart_count : ((automatic && c.horizon <= 10) ? 2 : 1);
     return (r > 0 && r < c.max_iter) ? r : 0;
 }
 
@@ -616,6 +622,7 @@ int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hi
     if (slot->rs) { HIP_TRY(h, hipFree(slot->rs)); slot->rs = nullptr; }
     auto carve = [&](Carver& c) {
         slot->resid = c.take<float>(B * 4); slot->ybuf = c.take<double>(B * m); slot->stbuf = c.take<int32_t>(B);
+        slot->rhobuf[0] = c.take<double>(B); slot->rhobuf[1] = c.take<double>(B);
     };
     Carver sz(nullptr);
     carve(sz);
@@ -670,19 +677,26 @@ int flush_slot(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st
     return SRBDQP_OK;
 }
 
-// second pass of a two-pass solve: the same grid again; the workgroup of a QP that ended at the cap re-balances its rho from
-// the maxima of its last check and continues from its own (x, y), every other workgroup leaves at once.  No selection
-// kernel and no list between the passes: a one-workgroup kernel queued behind a chip-filling launch of another stream
-// waits ~150 us for its turn at the dispatcher (rocprofv3 timeline, round 2), which cost more than the second pass itself.
-// a1 = the arguments of the first pass (status / y_out / resid_out set).
-int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int maxs, bool signal) {
+// Restart pass p (1 = the first re-balancing) of a solve whose first pass ran with the arguments a1 (status / y_out / resid_out set, max_iter = the restart
+// period): the same grid again; the workgroup of a QP that the pass before left at its cap re-balances its rho from the maxima of its last check -- from the rho of
+// THAT pass -- and continues from its own (x, y), every other workgroup leaves at once.  No selection kernel and no list between the passes: a one-workgroup kernel
+// queued behind a chip-filling launch of another stream waits ~150 us for its turn at the dispatcher (rocprofv3 timeline, round 2), which cost more than the
+// pass itself.  *last_out: no further pass may follow (p = rcount, or the cap on the total comes first: oracle solve_with_restart).
+int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int maxs, bool signal, srbdqp_handle::StreamSlot* slot, int p, int rcount, bool* last_out) {
+    const int every = a1.max_iter;
+    const int done = p * every;                             // iterations of a QP that every pass so far left at its cap
+    const int left = h->cfg.max_iter - done;                // the cap is on the total
+    const bool last = p >= rcount || every >= left;
+    if (last_out) *last_out = last;
     KArgs a2 = a1;
     a2.resid_in = a1.resid_out;
     a2.warm_u = a1.u_out;                                   // newtons, as a caller's warm start would be
     a2.warm_y = a1.y_out;
-    a2.max_iter = h->cfg.max_iter - a1.max_iter;            // the cap is on the total
-    a2.iters_base = a1.max_iter;
-    a2.resid_out = nullptr;
+    a2.max_iter = last ? left : every;
+    a2.iters_base = done;
+    a2.resid_out = last ? nullptr : a1.resid_out;           // (a workgroup reads its entry when it starts and writes it when it ends)
+    a2.rho_qp = (p == 1) ? a1.rho_qp : slot->rhobuf[p % 2];
+    a2.rho_out = last ? nullptr : slot->rhobuf[(p + 1) % 2];
     if (signal) { a2.done_flag = h->done_dev; a2.done_count = h->done_count; a2.done_value = h->done_seq; }
     else { a2.done_flag = nullptr; a2.done_count = nullptr; }
     return launch(h, a2, st, maxs, 2);
@@ -881,15 +895,18 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     if (rc != SRBDQP_OK) return rc;
     rc = wait_done();
     if (rc != SRBDQP_OK) return rc;
-    if (h->lazy_pending) {          // the solve above was the first pass of a two-pass solve (not: restarted in place, or no restart at all)
+    if (h->lazy_pending) {          // the solve above was the first pass of a multi-pass solve (not: restarted in place, or no restart at all)
         h->lazy_pending = false;
-        bool capped = false;
-        for (int32_t q = 0; q < B; ++q) capped |= (h->stage_h.status[q] == SRBDQP_MAX_ITER);
-        if (capped) {
+        for (int p = 1; p <= h->lazy_rcount; ++p) {         // a further pass only when a status asks for it
+            bool capped = false;
+            for (int32_t q = 0; q < B; ++q) capped |= (h->stage_h.status[q] == SRBDQP_MAX_ITER);
+            if (!capped) break;
             if (spin) h->done_seq = (h->done_seq == INT32_MAX) ? 1 : h->done_seq + 1;
-            rc = srbdqp_restart_pass(h, h->last_args, h->stream, maxs, spin);
+            bool last = true;
+            rc = srbdqp_restart_pass(h, h->last_args, h->stream, maxs, spin, h->lazy_slot, p, h->lazy_rcount, &last);
             if (rc != SRBDQP_OK) return rc;
             rc = wait_done();
+            if (rc != SRBDQP_OK || last) break;
         }
     }
     return rc;
@@ -1086,7 +1103,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
     }
     if (!restart || wave) return launch(h, a, lst, maxs);
 
-    // ---- two passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those
+    // ---- several passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those (up to rcount times)
     auto* slot = stream_slot(h, lst);
     if (!slot) return SRBDQP_E_INVALID;
     const size_t m = 20 * (size_t)h->cfg.horizon;
@@ -1100,9 +1117,16 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
     if (!a1.status) a1.status = slot->stbuf;
     if (!lazy) { a1.done_flag = nullptr; a1.done_count = nullptr; }
     rc = launch(h, a1, lst, maxs, lazy ? 0 : 1);
-    if (lazy) { h->last_args = a1; h->lazy_pending = (rc == SRBDQP_OK); }
+    if (lazy) { h->last_args = a1; h->lazy_pending = (rc == SRBDQP_OK); h->lazy_rcount = rcount; h->lazy_slot = slot; }
     if (rc != SRBDQP_OK || lazy) return rc;
-    return srbdqp_restart_pass(h, a1, lst, maxs, a.done_flag != nullptr);
+    for (int p = 1; p <= rcount; ++p) {
+        bool last = true;
+        const int every = a1.max_iter;
+        const bool is_last = p >= rcount || every >= h->cfg.max_iter - p * every;
+        rc = srbdqp_restart_pass(h, a1, lst, maxs, is_last && a.done_flag != nullptr, slot, p, rcount, &last);
+        if (rc != SRBDQP_OK || last) break;
+    }
+    return rc;
 }
 
 // common body of the host-buffer entry points (esz = sizeof the caller's element type)
@@ -1377,6 +1401,7 @@ struct srbdqp_ragged {
     // rho restart of the long-horizon buckets: fp32 maxima of a QP's last check [cap][4], status when the caller passes none
     // [cap], duals of the first pass [row_cap][20] (the second pass warm-starts from them)
     float* d_resid = nullptr; int32_t* d_status = nullptr; double* d_y = nullptr; size_t row_cap = 0;
+    double* d_rho = nullptr;                  // [2][cap]: the rho a restart pass ran its QPs with, for the pass behind it
     char* ws = nullptr; size_t ws_bytes = 0;  // host-buffer entry point: device copies of the caller's arrays
     hipStream_t stream = nullptr;             // ... and the stream its copies run on
     std::string err;
@@ -1441,6 +1466,7 @@ int srbdqp_ragged_destroy(srbdqp_ragged* r) {
     if (r->d_off) (void)hipFree(r->d_off);
     if (r->d_resid) (void)hipFree(r->d_resid);
     if (r->d_status) (void)hipFree(r->d_status);
+    if (r->d_rho) (void)hipFree(r->d_rho);
     if (r->d_y) (void)hipFree(r->d_y);
     if (r->h_perm) (void)hipHostFree(r->h_perm);
     if (r->h_off) (void)hipHostFree(r->h_off);
@@ -1479,9 +1505,11 @@ int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, con
         RAG_TRY(r, hipHostMalloc(reinterpret_cast<void**>(&r->h_off), want * 4, hipHostMallocDefault));
         if (r->d_resid) (void)hipFree(r->d_resid);
         if (r->d_status) (void)hipFree(r->d_status);
-        r->d_resid = nullptr; r->d_status = nullptr;
+        if (r->d_rho) (void)hipFree(r->d_rho);
+        r->d_resid = nullptr; r->d_status = nullptr; r->d_rho = nullptr;
         RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_resid), want * 16));
         RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_status), want * 4));
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_rho), 2 * want * sizeof(double)));
         r->cap = want;
         r->ev_in_pending = false;
     }
@@ -1533,20 +1561,26 @@ int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, con
         a.status = status; a.iters = iters;
         a.perm = r->d_perm + start[i]; a.row_off = r->d_off;
         a.B = cnt[i]; a.mode = 0;
-        const int restart = restart_iter_of(bh, 4, cnt[i]);
+        int rcount = 1;
+        const int restart = restart_iter_of(bh, 4, cnt[i], false, &rcount);
         int rc;
-        if (restart > 0) {   // two passes over the bucket, as srbdqp_solve_batch_* does (the second one selects its QPs in-kernel)
+        if (restart > 0) {   // several passes over the bucket, as srbdqp_solve_batch_* does (the later ones select their QPs in-kernel)
             KArgs a1 = a;
             a1.max_iter = restart; a1.resid_out = r->d_resid;
-            if (!a1.y_out) { a1.y_out = r->d_y; a1.y_capped_only = 1; }   // (the second pass warm-starts from the first pass's duals)
+            if (!a1.y_out) { a1.y_out = r->d_y; a1.y_capped_only = 1; }   // (a later pass warm-starts from the duals of the pass before it)
             if (!a1.status) a1.status = r->d_status;
             rc = ragged_launch_bucket(bh, a1, bs, f32);
-            if (rc == SRBDQP_OK) {
+            for (int p = 1; rc == SRBDQP_OK && p <= rcount; ++p) {        // (srbdqp_restart_pass, on the ragged object's own buffers)
+                const int done = p * restart, left = bh->cfg.max_iter - done;
+                const bool last = p >= rcount || restart >= left;
                 KArgs a2 = a1;
-                a2.resid_in = r->d_resid; a2.resid_out = nullptr;
+                a2.resid_in = r->d_resid; a2.resid_out = last ? nullptr : r->d_resid;
                 a2.warm_u = a1.u_out; a2.warm_y = a1.y_out;
-                a2.max_iter = bh->cfg.max_iter - restart; a2.iters_base = restart;
+                a2.max_iter = last ? left : restart; a2.iters_base = done;
+                a2.rho_qp = (p == 1) ? nullptr : r->d_rho + (size_t)(p % 2) * r->cap;
+                a2.rho_out = last ? nullptr : r->d_rho + (size_t)((p + 1) % 2) * r->cap;
                 rc = ragged_launch_bucket(bh, a2, bs, f32);
+                if (last) break;
             }
         } else {
             rc = ragged_launch_bucket(bh, a, bs, f32);

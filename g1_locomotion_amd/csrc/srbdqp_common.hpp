@@ -44,7 +44,8 @@ struct KArgs {
     long long* stamps;       // diagnostic: [B][16] s_memtime stamps of the phase boundaries, or null
     double* ws;              // split mode: per-QP workspace between the set-up kernel and the ADMM kernel, or null
     // rho re-balancing (one OSQP-style restart of the QPs that reach the cap of the first pass, see srbdqp.hip)
-    const double* rho_qp;    // rho of QP b, or null (= rho)
+    const double* rho_qp;    // rho of QP b, or null (= rho); in a restart pass: the rho the pass BEFORE it ran QP b with
+    double* rho_out;         // restart pass that another one may follow: [B] receives the rho this pass runs QP b with (never the array rho_qp points to), or null
     const float* resid_in;   // second pass: the first pass's resid_out.  Workgroup of QP b leaves at once unless status[b] is
                              //   SRBDQP_MAX_ITER, and re-balances its rho from resid_in[b] (restart_rho_of) -- no list, no
                              //   selection kernel between the passes
@@ -132,7 +133,15 @@ __device__ __forceinline__ double restart_rho_of(double rho0, const float* r) {
 }
 // is QP b this workgroup's to solve in a second pass (resid_in set)?  Uniform over the workgroup.
 #define SRBDQP_RESTART_SKIP(a, b) ((a).resid_in && (a).status[(b)] != 2)
-#define SRBDQP_RHO_OF(a, b) ((a).resid_in ? restart_rho_of((a).rho, (a).resid_in + (size_t)(b) * 4) : ((a).rho_qp ? (a).rho_qp[(b)] : (a).rho))
+// rho of QP b in this launch: the caller's (rho_qp or rho); in a restart pass re-balanced from the maxima the pass before left, EACH TIME FROM THE RHO OF THAT PASS
+// (rho_qp = what it recorded; the first pass's rho is the caller's).  A pass that may be followed by another records its rho in rho_out.
+__device__ __forceinline__ double rho_of_qp(const KArgs& a, int b) {
+    const double r0 = a.rho_qp ? a.rho_qp[b] : a.rho;
+    const double r = a.resid_in ? restart_rho_of(r0, a.resid_in + (size_t)b * 4) : r0;
+    if (a.rho_out && threadIdx.x == 0) a.rho_out[b] = r;
+    return r;
+}
+#define SRBDQP_RHO_OF(a, b) rho_of_qp((a), (b))
 
 // a wave-uniform value, moved to scalar registers (the float constants of the iteration are converted from doubles by the
 // vector ALU and would otherwise each hold a vector register for the whole loop)

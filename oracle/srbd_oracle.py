@@ -374,11 +374,19 @@ def auto_rho_fz_scale(N: int) -> float:
 
 def default_restart(N: int, one_wave: bool = False):
     """(rho_restart_iter, rho_restart_count) the engine picks by default (srbdqp.hip restart_iter_of): N > 10: one re-balancing after 100 (125 above N = 16)
-    iterations; N <= 10: two, 55 iterations apart, where the one-wave kernel runs the solve of a large batch (one_wave: at most 2 stance contacts per step and
-    4096 QPs or more per call), none elsewhere."""
+    iterations; N <= 10: two, 55 iterations apart.  The same for every kernel and batch size since round 4 (one_wave is ignored: round 3 applied the N <= 10
+    rule only where the one-wave kernel ran a call of 4096 QPs or more)."""
     if N > 10:
         return (100 if N <= 16 else 125), 1
-    return (55, 2) if one_wave else (0, 1)
+    return 55, 2
+
+
+def default_params(N: int, **kw) -> "SrbdParams":
+    """SrbdParams as the engine runs horizon N when NOTHING is configured: params_for(N) plus the automatic rho restart."""
+    it, cnt = default_restart(N)
+    kw.setdefault("rho_restart_iter", it)
+    kw.setdefault("rho_restart_count", cnt)
+    return params_for(N, **kw)
 
 
 def params_for(N: int, **kw) -> SrbdParams:
@@ -572,14 +580,21 @@ def update_split(p: SrbdParams, x0, x_ref, foot_hor, contact_hor, pcom_hor=None,
         wr = wrench_reduce(p, x_ref, foot_hor, contact_hor, pcom_hor)
         xi, yi = (None, None) if warm is None else (np.asarray(warm[0])[vi], np.asarray(warm[1])[ri])
         args = (red["P"], red["q"], red["A"], red["l"], red["u"])
-        if 0 < p.rho_restart_iter < p.max_iter:   # the general kernel's in-kernel rho restart (same rule as solve_with_restart)
-            info = {}
-            xr_, _, yr_, iters, status = admm_solve_split(replace(p, max_iter=p.rho_restart_iter), *args, wr, xi, yi, dtype=dtype, info=info, tile_dtype=tile_dtype)
-            if status == STATUS_MAX_ITER:
-                p2 = replace(p, rho=restart_rho(p, info), max_iter=p.max_iter - p.rho_restart_iter)
-                wr2 = wrench_reduce(p2, x_ref, foot_hor, contact_hor, pcom_hor)
-                xr_, _, yr_, it2, status = admm_solve_split(p2, *args, wr2, xr_, yr_, dtype=dtype)
-                iters = p.rho_restart_iter + it2
+        if 0 < p.rho_restart_iter < p.max_iter:   # the general kernel's rho restart passes (same rule as solve_with_restart: up to rho_restart_count
+            # re-balancings, each from the rho of the pass before it, the cap on the total; every pass after the first factors in float64 tiles)
+            nre = max(int(p.rho_restart_count), 1)
+            pc, w, td, xs_, ys_, iters = p, wr, tile_dtype, xi, yi, 0
+            for k in range(nre + 1):
+                left = p.max_iter - iters
+                cap = p.rho_restart_iter if (k < nre and p.rho_restart_iter < left) else left
+                info = {}
+                xr_, _, yr_, it, status = admm_solve_split(replace(pc, max_iter=cap), *args, w, xs_, ys_, dtype=dtype, info=info, tile_dtype=td)
+                iters += it
+                if status != STATUS_MAX_ITER or cap == left:
+                    break
+                pc = replace(pc, rho=restart_rho(pc, info))
+                w = wrench_reduce(pc, x_ref, foot_hor, contact_hor, pcom_hor)
+                xs_, ys_, td = xr_, yr_, np.float64
         else:
             xr_, _, yr_, iters, status = admm_solve_split(p, *args, wr, xi, yi, dtype=dtype, tile_dtype=tile_dtype)
         uh[vi] = xr_

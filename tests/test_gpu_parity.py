@@ -800,8 +800,13 @@ def test_committed_golden_fixtures_gate_the_kernels(torch_first, built_lib, name
     x0, xr, ft, ct = (gold[f"{name}/{k}"] for k in ("x0", "x_ref", "foot", "contact"))
     u_exact, u_admm, it_admm = gold[f"{name}/u_exact"], gold[f"{name}/u_admm"], int(gold[f"{name}/iters_admm"])
     p = orc.SrbdParams()
-    capped = it_admm >= p.max_iter                                   # n10_mixed: the twin itself ends at the cap, 0.055 N from the optimum
+    capped = it_admm >= p.max_iter                                   # n10_mixed: the fixed-rho twin itself ends at the cap, 0.055 N from the optimum
     if path == "staged":
+        # MPC() runs the engine's defaults, i.e. WITH the automatic rho restart (every 55 iterations, up to twice): the twin of that is the oracle with
+        # default_params(); the case fixed-rho ADMM leaves at the cap (n10_mixed) is solved here
+        tw = orc.update(orc.default_params(N), x0, xr, ft, ct, pcom_hor=xr[:, 3:6])
+        u_admm, it_admm, capped = tw["u"], tw["iters"], tw["status"] == orc.STATUS_MAX_ITER
+        assert not capped
         M = mpc.MPC(dt=0.04, horizon=N, strict=False)
         M.init_matrices()
         M.x_ref_hor[:] = xr
@@ -820,7 +825,7 @@ def test_committed_golden_fixtures_gate_the_kernels(torch_first, built_lib, name
     assert status == (orc.STATUS_MAX_ITER if capped else orc.STATUS_SOLVED)
     assert abs(iters - it_admm) <= p.check_every, (iters, it_admm)
     assert np.abs(u - u_admm).max() <= (TOL_TWIN_N if not capped else 2e-2)
-    assert np.abs(u - u_exact).max() <= (TOL_EXACT_N if not capped else 0.1)
+    assert np.abs(u - u_exact).max() <= ((TOL_EXACT_N if iters <= 110 else 3 * TOL_EXACT_N) if not capped else 0.1)   # (re-balanced twice: stops further out)
     assert np.abs(x - gold[f"{name}/x_exact"]).max() <= (1e-4 if not capped else 1e-3)
     if y is not None:
         qp = orc.build_qp(p, x0, xr, ft, ct)
@@ -991,3 +996,76 @@ def test_deferred_tails_equal_the_restart_in_place(torch_first, built_lib, N, ev
         for j, (o, r) in enumerate(zip(outs, ref_outs)):
             assert torch.equal(o["st"], r["st"]) and torch.equal(o["it"], r["it"]), (j, streams, hint)
             assert float((o["u"] - r["u"]).abs().max()) <= 1e-9 and float((o["x"] - r["x"]).abs().max()) <= 1e-11, (j, float((o["u"] - r["u"]).abs().max()))
+
+
+def test_status_does_not_depend_on_the_batch_size(torch_first, built_lib):
+    """One restart rule for every kernel and batch size (round 4): the same 4096 single-support QPs through the staged batch-1 call (compact_*_lat, passes
+    started by the host when a status asks for them), in calls of 512 and in one call of 4096 (one-wave kernel, restart in place) end with identical
+    status[]; and the same for 1024 mixed-gait QPs through the staged call (wrench_*_lat), calls of 256 (4-wave kernel) and one call of 1024 (general
+    kernel, one launch per pass)."""
+    from g1_locomotion_amd import BatchMPC, _lib
+    import c_oracle
+    N = 10
+    for schedule, B, mid, names in (("single", 4096, 512, ("compact_f64_n10_s2_lat", "wave_f64_n10_s2", "wave_f64_n10_s2")),
+                                    ("mixed", 1024, 256, ("wrench_f64_n10_lat", "compact_f64_n10_s4", "wrench_f64_n10"))):
+        x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=1000, schedule=schedule)
+        ref = c_oracle.solve_batch(orc.default_params(N), x0, xr, ft, ct, nthreads=8)
+        with BatchMPC(horizon=N) as eng:                        # nothing configured: the defaults
+            big = eng.solve(x0, xr, ft, ct)
+            assert eng.kernel_name() == names[2], eng.kernel_name()
+            st_mid, it_mid, u_mid = [], [], []
+            for k in range(0, B, mid):
+                o = eng.solve(x0[k:k + mid], xr[k:k + mid], ft[k:k + mid], ct[k:k + mid])
+                st_mid.append(o["status"]); it_mid.append(o["iters"]); u_mid.append(o["u"])
+            assert eng.kernel_name() == names[1], eng.kernel_name()
+            st = eng.stage()
+            st_one, it_one, u_one = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, N, 12))
+            for b in range(B):
+                st["x0"][0] = x0[b]; st["x_ref"][0] = xr[b]; st["foot"][0] = ft[b]; st["contact"][0] = ct[b]
+                eng.solve_staged(1, want_x=False)
+                st_one[b], it_one[b], u_one[b] = st["status"][0], st["iters"][0], st["u"][0]
+                if b == 0:
+                    assert eng.kernel_name() == names[0], eng.kernel_name()
+        st_mid, it_mid, u_mid = np.concatenate(st_mid), np.concatenate(it_mid), np.concatenate(u_mid)
+        np.testing.assert_array_equal(big["status"], ref["status"])
+        np.testing.assert_array_equal(st_mid, big["status"])
+        np.testing.assert_array_equal(st_one, big["status"])
+        assert (big["status"] == orc.STATUS_SOLVED).mean() >= (0.999 if schedule == "single" else 0.998)
+        for it, u in ((it_mid, u_mid), (it_one, u_one)):
+            assert np.abs(it.astype(int) - big["iters"].astype(int)).max() <= 5
+            same = it == big["iters"]
+            assert same.mean() >= 0.97 and np.abs(u - big["u"])[same].max() <= 1e-3 and np.abs(u - big["u"]).max() <= 2 * TOL_TWIN_N
+
+
+def test_mpc_update_rarely_ends_at_the_iteration_cap(torch_first, built_lib):
+    """The reference's consumer has no status handling (ros_run_simulation.py:188-218): what MPC.update() returns goes straight to the WBID step.  10,000
+    consecutive control steps through MPC.update(): 400 segments of 25 steps, each starting from a synthetic state of the mixed gait (a large disturbance) and
+    then receding -- every state the previous plan's prediction, the contact schedule shifted by one step.  With the staged call's automatic rho restart
+    (every 55 iterations, up to twice, a further launch only when a status asks for it) fewer than 0.1 % of the solves end at the cap, and fewer than with
+    the restart switched off."""
+    from g1_locomotion_amd import MPC
+    N, SEG, L = 10, 400, 25
+    X0, XR, FT, CT = orc.synthetic_batch(SEG, N, seed=77, schedule="mixed")
+
+    def loop(**kw):
+        M = MPC(dt=0.04, horizon=N, strict=False, **kw)
+        M.init_matrices()
+        capped = failed = restarted = 0
+        for s in range(SEG):
+            x = X0[s].copy()
+            M.x_ref_hor[:] = XR[s]
+            c_h = list(FT[s])
+            for j in range(L):
+                u0, xo = M.update(list(np.roll(CT[s], -j, axis=0)), c_h, None, x_current=x.reshape(13, 1))
+                capped += M.status == orc.STATUS_MAX_ITER
+                failed += M.status < 0
+                restarted += M.iters > 55
+                x = xo[1].copy()
+        M.close()
+        return capped, failed, restarted
+
+    capped, failed, restarted = loop()
+    capped_off, failed_off, _ = loop(rho_restart_iter=-1)
+    assert failed == 0 and failed_off == 0
+    assert restarted >= 20                                      # the restart really runs in this loop
+    assert capped < 10 and capped < capped_off, (capped, capped_off)

@@ -169,7 +169,7 @@ def test_repeated_rho_restart_is_the_same_in_both_oracles_and_solves_the_slow_ta
     N, B = 10, 2048
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=1000, schedule="single")
     plain = c_oracle.solve_batch(orc.params_for(N), x0, xr, ft, ct, nthreads=8)
-    assert orc.default_restart(N, one_wave=True) == (55, 2)
+    assert orc.default_restart(N) == (55, 2)
     p = orc.params_for(N, rho_restart_iter=55, rho_restart_count=2)
     out = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     assert (plain["status"] == orc.STATUS_SOLVED).mean() < 0.995 <= 0.999 <= (out["status"] == orc.STATUS_SOLVED).mean()
