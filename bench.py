@@ -331,7 +331,7 @@ def isolated_kernel_ms(leg, torch, n_iso, k0):
     return float(np.mean(iso)), len(iso)
 
 
-def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step, S, N):
+def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step, S, N, defer=False):
     """`frac` = the flops the kernel really issues (PMC summary of the same kernel under profiles/) over the live kernel time
     and the dense peak; `frac_algorithmic` = SURVEY 8(d)'s W(N, K) over the same time."""
     alg_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
@@ -347,10 +347,10 @@ def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step
          "traffic": None,
          "traffic_unit": "HBM bytes per solve = per launch of this step's kernels (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
          "algorithmic_bytes_per_launch": abytes, "kernel": kname, "kernel_ms": kernel_ms,
-         "kernel_ms_note": ("average launch duration over a run of %d consecutive launches on ONE stream (HIP events on that stream around the whole run, "
-                            "flush included): with deferred tails every launch also runs the continuations of the launches before it, so a launch alone "
-                            "on an empty list is not the kernel's steady state.  The timed region overlaps consecutive steps on %d stream(s)" % (n_iso, S))
-                           if "defer" in kname else
+         "kernel_ms_note": ("average solve duration over a run of %d consecutive solves on ONE stream (HIP events on that stream around the whole run, "
+                            "flush included): with deferred tails (SRBDQP_FLAG_DEFER_TAIL) the continuations / restart passes of a solve run beside the solves "
+                            "behind it, so a solve alone on an idle device is not the kernel's steady state.  The timed region overlaps consecutive steps on %d stream(s)" % (n_iso, S))
+                           if defer else
                            ("mean of %d isolated solves, one at a time, after the warm-up steps and before the timed region (so the GPU is at its "
                             "sustained clocks when the timed steps start); HIP events on the launch stream; with the rho restart on, a solve = the "
                             "first pass + the pass in which the capped QPs continue; an _f32 solve of >= 512 QPs = the fp32-tile and the fp64-tile "
@@ -603,7 +603,7 @@ def main(argv=None):
             out[key] = total_qp / elapsed_other
         if kernel_ms is not None:
             fl, by = leg.flops_bytes(mean_iters)
-            out["roofline"] = roofline(kname, fl, by, B, kernel_ms, n_iso, peak, 1e3 * elapsed / max(steps, 1), S, N)
+            out["roofline"] = roofline(kname, fl, by, B, kernel_ms, n_iso, peak, 1e3 * elapsed / max(steps, 1), S, N, defer=leg.defer)
         if world == 1 and not args.no_latency and not stub and cid == 1:
             from g1_locomotion_amd import synth
             out["latency_batch1"] = latency_batch1(synth)
@@ -632,10 +632,12 @@ def also_legs(args, rank, local_rank, dev, torch, SOLVED):
             cfg = CONFIGS[cid]
             B = cfg["batch"]
             S = 2 if cid == 2 else 1
-            leg = Leg(cid, B, args, rank, local_rank, dev, torch, nb, max_streams=S) if cid != 4 else RaggedLeg(B, args, rank, local_rank, dev, torch, nb)
+            # configs[2]: the restart pass of a solve runs on the library's tail stream, beside the next solve (SRBDQP_FLAG_DEFER_TAIL; flushed inside the timed steps)
+            leg = Leg(cid, B, args, rank, local_rank, dev, torch, nb, max_streams=S, defer=True) if cid != 4 else RaggedLeg(B, args, rank, local_rank, dev, torch, nb)
             hint = "own" if cid != 4 else "none"
             for i in range(2 * leg.NO):
                 leg.step(i, S=S, hint="none" if i < leg.NO else hint)
+            leg.flush()
             torch.cuda.synchronize(dev)
             base = 2 * leg.NO
             base += (-base) % (S * leg.NO)
@@ -646,16 +648,18 @@ def also_legs(args, rank, local_rank, dev, torch, SOLVED):
             t0 = time.perf_counter()
             for k in range(base, base + steps):
                 leg.step(k, S=S, hint=hint)
+            leg.flush()
             torch.cuda.synchronize(dev)
             el = time.perf_counter() - t0
             mean_iters, solved_frac, _ = leg.stats(SOLVED)
             fl, by = leg.flops_bytes(mean_iters)
             peak = PEAK_FP32_TFLOPS if leg.f32 else PEAK_FP64_TFLOPS
             res["configs[%d]" % cid] = {
-                "workload": cfg["workload"].format(B=B) + f"; {steps} timed steps rotating over {nb} distinct device batches, {S} stream(s)",
+                "workload": cfg["workload"].format(B=B) + f"; {steps} timed steps rotating over {nb} distinct device batches, {S} stream(s)"
+                            + ("; restart passes on the library's tail stream beside the next solve, flushed inside the timed steps" if leg.defer else ""),
                 "value": B * steps / el, "unit": "QP/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "dtype": "f32" if leg.f32 else "f64",
                 "kernel": leg.kname, "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
-                "roofline": roofline(leg.kname, fl, by, B, kernel_ms, n, peak, 1e3 * el / steps, S, leg.N)}
+                "roofline": roofline(leg.kname, fl, by, B, kernel_ms, n, peak, 1e3 * el / steps, S, leg.N, defer=leg.defer)}
             leg.close()
         except Exception as e:      # a failed side leg must not take the headline down with it; it is reported, not hidden
             res["configs[%d]" % cid] = {"error": repr(e)}

@@ -51,6 +51,16 @@ struct srbdqp_handle {
         float* resid = nullptr; double* ybuf = nullptr;
         int32_t* stbuf = nullptr;
         double* rhobuf[2] = {nullptr, nullptr};   // rho a restart pass ran its QPs with, for the pass behind it (alternating)
+        // SRBDQP_FLAG_DEFER_TAIL on the kernels that restart by further LAUNCHES: three sets of the buffers above in rotation (a solve's restart passes run on
+        // tail_st, beside the next solves of this stream; a set is reused only behind the event that closes its last user's passes), + per set the lists through
+        // which a pass hands its capped QPs to the next one (so that the working workgroups of a pass come first in its grid)
+        struct RSet { float* resid = nullptr; double* ybuf = nullptr; int32_t* stbuf = nullptr; double* rhobuf[2] = {nullptr, nullptr};
+                      int32_t* list[4] = {nullptr, nullptr, nullptr, nullptr}; int32_t* cnt = nullptr; hipEvent_t ev_tail = nullptr; bool ev_used = false; };
+        RSet rsets[3];
+        int rs_nsets = 0;
+        unsigned long long rs_k = 0;
+        hipStream_t tail_st = nullptr; hipEvent_t ev_main = nullptr;
+        hipEvent_t last_tail = nullptr;    // closes the restart passes of the last deferred solve on this stream (srbdqp_flush waits for it), or null
         // deferred tails (SRBDQP_FLAG_DEFER_TAIL): three rotating lists of continuation records, their counts, and a GPU-mapped host word through
         // which every launch reports how many records it found (launch_wave_defer sizes the next launches' tail workgroups from it)
         char* tail = nullptr; int32_t* tail_cnt = nullptr; size_t tail_cap = 0;
@@ -616,14 +626,23 @@ inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B, bool wave = 
 }
 
 // per-stream restart buffers for batches of up to B QPs with m rows
-int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, size_t m) {
-    if (slot->rs && slot->rs_items >= B && slot->rs_rows >= m) return SRBDQP_OK;
+int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, size_t m, int nsets = 1) {
+    if (slot->rs && slot->rs_items >= B && slot->rs_rows >= m && slot->rs_nsets >= nsets) return SRBDQP_OK;
     HIP_TRY(h, hipStreamSynchronize(st));
+    if (slot->tail_st) HIP_TRY(h, hipStreamSynchronize(slot->tail_st));
     if (slot->rs) { HIP_TRY(h, hipFree(slot->rs)); slot->rs = nullptr; }
     auto carve = [&](Carver& c) {
-        slot->resid = c.take<float>(B * 4); slot->ybuf = c.take<double>(B * m); slot->stbuf = c.take<int32_t>(B);
-        slot->rhobuf[0] = c.take<double>(B); slot->rhobuf[1] = c.take<double>(B);
+        for (int i = 0; i < nsets; ++i) {
+            auto& r = slot->rsets[i];
+            r.resid = c.take<float>(B * 4); r.ybuf = c.take<double>(B * m); r.stbuf = c.take<int32_t>(B);
+            r.rhobuf[0] = c.take<double>(B); r.rhobuf[1] = c.take<double>(B);
+            if (nsets > 1) { for (int j = 0; j < 4; ++j) r.list[j] = c.take<int32_t>(B); r.cnt = c.take<int32_t>(16); }
+            r.ev_used = false;
+        }
+        const auto& r0 = slot->rsets[0];
+        slot->resid = r0.resid; slot->ybuf = r0.ybuf; slot->stbuf = r0.stbuf; slot->rhobuf[0] = r0.rhobuf[0]; slot->rhobuf[1] = r0.rhobuf[1];
     };
+    slot->rs_nsets = nsets; slot->last_tail = nullptr;
     Carver sz(nullptr);
     carve(sz);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&slot->rs), sz.off);
@@ -816,6 +835,9 @@ int srbdqp_destroy(srbdqp_handle* h) {
     for (auto& sl : h->slots) {
         if (sl.perm) (void)hipFree(sl.perm); if (sl.ws) (void)hipFree(sl.ws); if (sl.rs) (void)hipFree(sl.rs);
         if (sl.tail) (void)hipFree(sl.tail); if (sl.tail_cnt) (void)hipFree(sl.tail_cnt); if (sl.tail_seen_h) (void)hipHostFree(sl.tail_seen_h);
+        if (sl.tail_st) { (void)hipStreamSynchronize(sl.tail_st); (void)hipStreamDestroy(sl.tail_st); }
+        if (sl.ev_main) (void)hipEventDestroy(sl.ev_main);
+        for (auto& r : sl.rsets) if (r.ev_tail) (void)hipEventDestroy(r.ev_tail);
     }
     if (h->done_count) (void)hipFree(h->done_count);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -1018,8 +1040,10 @@ int srbdqp_flush(srbdqp_handle* h, void* stream) {
     if (!h) return SRBDQP_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     for (auto& sl : h->slots) {
-        if (!sl.used || !sl.tail_live) continue;
+        if (!sl.used) continue;
         if (stream && sl.st != reinterpret_cast<hipStream_t>(stream)) continue;
+        if (sl.last_tail) { HIP_TRY(h, hipStreamWaitEvent(sl.st, sl.last_tail, 0)); sl.last_tail = nullptr; }   // restart passes on the slot's tail stream
+        if (!sl.tail_live) continue;
         const int rc = flush_slot(h, &sl, sl.st);
         if (rc != SRBDQP_OK) return rc;
     }
@@ -1028,8 +1052,11 @@ int srbdqp_flush(srbdqp_handle* h, void* stream) {
 
 int srbdqp_synchronize(srbdqp_handle* h) {
     if (!h) return SRBDQP_E_INVALID;
-    for (auto& sl : h->slots)                      // deferred tails of the handle's own stream are part of "everything enqueued"
-        if (sl.used && sl.tail_live && sl.st == h->stream) { const int rc = flush_slot(h, &sl, sl.st); if (rc != SRBDQP_OK) return rc; }
+    for (auto& sl : h->slots) {                    // deferred tails of the handle's own stream are part of "everything enqueued"
+        if (!sl.used || sl.st != h->stream) continue;
+        if (sl.last_tail) { HIP_TRY(h, hipStreamWaitEvent(sl.st, sl.last_tail, 0)); sl.last_tail = nullptr; }
+        if (sl.tail_live) { const int rc = flush_slot(h, &sl, sl.st); if (rc != SRBDQP_OK) return rc; }
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SRBDQP_OK;
 }
@@ -1056,6 +1083,57 @@ int srbdqp_last_kernel_parts_ms(srbdqp_handle* h, double* setup_ms, double* admm
 }  // extern "C"
 
 namespace {
+
+// SRBDQP_FLAG_DEFER_TAIL on a kernel that restarts by further launches: the first pass on the caller's stream, the restart passes on the slot's own tail stream
+// behind an event -- beside whatever the caller enqueues next, e.g. the next batch's first pass -- each taking the list of QPs the pass before it left at its cap
+// as its dispatch order (working workgroups first; the rest of the grid leaves after one scalar load).  Outputs of the continued QPs arrive when the tail
+// stream gets there; srbdqp_flush() makes the caller's stream wait for it.
+int solve_deferred_passes(srbdqp_handle* h, const KArgs& a, hipStream_t lst, int maxs, int restart, int rcount) {
+    auto* slot = stream_slot(h, lst);
+    if (!slot) return SRBDQP_E_INVALID;
+    const size_t m = 20 * (size_t)h->cfg.horizon;
+    int rc = ensure_restart_buffers(h, slot, lst, (size_t)a.B, m, 3);
+    if (rc != SRBDQP_OK) return rc;
+    if (!slot->tail_st) {
+        int least = 0, greatest = 0;
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(h, hipStreamCreateWithPriority(&slot->tail_st, hipStreamNonBlocking, greatest));
+        HIP_TRY(h, hipEventCreateWithFlags(&slot->ev_main, hipEventDisableTiming));
+        for (auto& r : slot->rsets) HIP_TRY(h, hipEventCreateWithFlags(&r.ev_tail, hipEventDisableTiming));
+    }
+    auto& set = slot->rsets[slot->rs_k++ % 3];
+    if (set.ev_used) HIP_TRY(h, hipStreamWaitEvent(lst, set.ev_tail, 0));      // the set's last user (three solves ago) has finished its passes
+    HIP_TRY(h, hipMemsetAsync(set.cnt, 0, 16 * sizeof(int32_t), lst));
+    KArgs a1 = a;
+    a1.max_iter = restart;
+    a1.resid_out = set.resid;
+    if (!a1.y_out) { a1.y_out = set.ybuf; a1.y_capped_only = 1; }
+    if (!a1.status) a1.status = set.stbuf;
+    a1.cap_list = set.list[0]; a1.cap_count = set.cnt;
+    rc = launch(h, a1, lst, maxs, 1);
+    if (rc != SRBDQP_OK) return rc;
+    HIP_TRY(h, hipEventRecord(slot->ev_main, lst));
+    HIP_TRY(h, hipStreamWaitEvent(slot->tail_st, slot->ev_main, 0));
+    for (int p = 1; p <= rcount; ++p) {
+        const int done = p * restart, left = h->cfg.max_iter - done;
+        const bool last = p >= rcount || restart >= left;
+        KArgs a2 = a1;
+        a2.resid_in = set.resid; a2.resid_out = last ? nullptr : set.resid;
+        a2.warm_u = a1.u_out; a2.warm_y = a1.y_out;
+        a2.max_iter = last ? left : restart; a2.iters_base = done;
+        a2.rho_qp = (p == 1) ? a1.rho_qp : set.rhobuf[p % 2];
+        a2.rho_out = last ? nullptr : set.rhobuf[(p + 1) % 2];
+        a2.perm = set.list[p - 1]; a2.count_ptr = set.cnt + (p - 1);
+        a2.cap_list = last ? nullptr : set.list[p]; a2.cap_count = last ? nullptr : set.cnt + p;
+        rc = launch(h, a2, slot->tail_st, maxs, 2);
+        if (rc != SRBDQP_OK) return rc;
+        if (last) break;
+    }
+    HIP_TRY(h, hipEventRecord(set.ev_tail, slot->tail_st));
+    set.ev_used = true;
+    slot->last_tail = set.ev_tail;
+    return SRBDQP_OK;
+}
 
 // common body of the device-buffer entry points; the element type of the caller's buffers is h->io_f32 ? float : double
 int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x_ref, const void* foot, const uint8_t* contact,
@@ -1102,6 +1180,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
         return launch_wave_defer_any(h, a, lst, slot, maxs);
     }
     if (!restart || wave) return launch(h, a, lst, maxs);
+    if ((h->cfg.flags & SRBDQP_FLAG_DEFER_TAIL) && !h->lazy_restart && !a.stamps && !a.done_flag && rcount <= 3) return solve_deferred_passes(h, a, lst, maxs, restart, rcount);
 
     // ---- several passes: cap the first at rho_restart_iter, re-balance rho for the QPs that reach it, continue those (up to rcount times)
     auto* slot = stream_slot(h, lst);

@@ -52,6 +52,8 @@ struct KArgs {
     float* resid_out;        // first pass: [B][4] fp32 maxima (r_prim, n_prim, r_dual, n_dual) of the last check of a QP
                              //   that ends at the cap, or null
     const int32_t* count_ptr;   // second pass: number of valid entries of perm[]; workgroups beyond it exit at once
+    int32_t* cap_list;       // a pass that another one may follow: QP b appends itself here when it ends at its cap (cap_list[atomicAdd(cap_count, 1)] = b) -- the
+    int32_t* cap_count;      //   next pass takes the list as its perm[] / count_ptr, so that its working workgroups come first in the grid; or null
     int32_t iters_base;      // second pass: iterations of the first pass, added to iters[] on output
     int32_t restart_every;   // one-wave kernel, restart in place (srbdqp_setup1.hpp RST): re-balance rho every this many iterations ...
     int32_t restart_max;     //   ... at most this many times

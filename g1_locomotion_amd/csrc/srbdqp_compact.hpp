@@ -296,6 +296,7 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
     if (a.resid_out && status == 2 && t == 0) {
         float* ro = a.resid_out + (size_t)b * 4;
         ro[0] = lastv0; ro[1] = lastv1; ro[2] = lastv2; ro[3] = lastv3;
+        if (a.cap_list) a.cap_list[atomicAdd(a.cap_count, 1)] = b;
     }
     __syncthreads();
     *status_out = status;

@@ -170,6 +170,7 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, const QpIo&
         if (a.resid_out && status == 2 && lane == 0) {
             float* ro = a.resid_out + (size_t)b * 4;
             ro[0] = lastv0; ro[1] = lastv1; ro[2] = lastv2; ro[3] = lastv3;
+            if (a.cap_list) a.cap_list[atomicAdd(a.cap_count, 1)] = b;
         }
         if (status < 0) { x = 0.0; yA = 0.0; yB = 0.0; }                    // a numerical failure returns zero forces, never NaN
         if (active) xs_full[3 * gc + ax] = x;

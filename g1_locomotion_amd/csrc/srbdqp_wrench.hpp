@@ -1561,6 +1561,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         if (a.resid_out && status == 2 && t == 0) {   // for the rho restart (second launch over the capped QPs, srbdqp.hip)
             float* ro = a.resid_out + (size_t)b * 4;
             ro[0] = lastv0; ro[1] = lastv1; ro[2] = lastv2; ro[3] = lastv3;
+            if (a.cap_list) a.cap_list[atomicAdd(a.cap_count, 1)] = b;
         }
     }
     SRBDQP_STAMP(a, b, 8);

@@ -54,14 +54,15 @@ extern "C" {
                                      have 0 or >= 3 stance contacts; A/B and accuracy studies) */
 #define SRBDQP_FLAG_F32_TILES 16  /* _f32 calls: fp32 tiles for the eligible QPs of batches below 512 too (tests) */
 #define SRBDQP_FLAG_NO_LAT 32     /* staged calls on the general kernel: the batch instantiation instead of the low-latency one (A/B) */
-#define SRBDQP_FLAG_DEFER_TAIL 64 /* device-buffer solves on the one-wave kernel (N <= 10, at most 2 stance contacts per step) with the rho restart on:
-                                     a QP that reaches a restart mark unconverged is not continued by its own workgroup (a launch would last as
-                                     long as its slowest QP: up to three set-ups and 250 iterations) but handed, with its (x, y), to the NEXT solve
-                                     enqueued on the same stream, whose first workgroups run its next pass beside that solve's own QPs.  Same
-                                     passes, same results; the outputs of such a QP (about 4 % of a configs[1] batch) arrive one or two solves
-                                     later: its status[] reads SRBDQP_PENDING until then, and srbdqp_flush() completes what is left.  A caller
-                                     must not read a solve's outputs, nor hand its output arrays to another solve, before the flush (or before
-                                     rho_restart_count further solves on that stream).  For pipelines of independent batches; see srbdqp_flush */
+#define SRBDQP_FLAG_DEFER_TAIL 64 /* device-buffer solves with the rho restart on: a QP that reaches a restart mark unconverged does not hold its own
+                                     launch up (a launch lasts as long as its slowest QP: up to three set-ups and 250 iterations) -- its next pass runs
+                                     BESIDE the caller's next solve.  One-wave kernel (N <= 10, at most 2 stance contacts per step): the QP hands
+                                     itself, with its (x, y), to the next solve enqueued on the same stream, whose first workgroups run the pass.
+                                     Every other kernel: the restart passes run on a stream of the library's own behind an event.  Same passes,
+                                     same results; the outputs of such a QP (about 4 % of a configs[1] batch) arrive later: its status[] reads
+                                     SRBDQP_PENDING (one-wave kernel) or SRBDQP_MAX_ITER (the others: the pass it ended) until then, and
+                                     srbdqp_flush() completes / waits for what is left.  A caller must not read a solve's outputs, nor hand its
+                                     output arrays to another solve, before the flush.  For pipelines of independent batches; see srbdqp_flush */
 #define SRBDQP_FLAG_NO_SPIN 2     /* srbdqp_solve_staged_f64: wait with hipStreamSynchronize instead of spinning on the
                                      completion word the kernel writes to host memory */
 
@@ -264,11 +265,12 @@ int srbdqp_solve_ragged_warm_device_f32(srbdqp_ragged* r, int32_t B, const int32
  * pointer is read at every solve; results, status[] and iters[] stay in the caller's QP order. */
 int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev, int32_t length);
 
-/* SRBDQP_FLAG_DEFER_TAIL: run the continuations that earlier device-buffer solves on `stream` (a hipStream_t; NULL = every stream this
- * handle has launched on) handed on and nothing has picked up yet: at most rho_restart_count launches of the continuations alone,
- * enqueued on the stream(s) they belong to; returns without synchronising.  After it every output of every earlier solve on that
- * stream is complete in stream order.  A no-op without the flag or with nothing pending.  srbdqp_synchronize() flushes the handle's
- * own stream first. */
+/* SRBDQP_FLAG_DEFER_TAIL: complete what earlier device-buffer solves on `stream` (a hipStream_t; NULL = every stream this handle has
+ * launched on) left for later -- the one-wave kernel's continuations that no later solve has picked up (at most rho_restart_count
+ * launches of the continuations alone, enqueued on that stream), and the restart passes running on the library's own tail stream (the
+ * stream is made to wait for them through an event).  Returns without synchronising; after it every output of every earlier solve on
+ * that stream is complete in stream order.  A no-op without the flag or with nothing pending.  srbdqp_synchronize() flushes the
+ * handle's own stream first. */
 int srbdqp_flush(srbdqp_handle* h, void* stream);
 
 /* Low-latency path for small batches (the single-robot control loop, B = 1): the library owns pinned, GPU-mapped host

@@ -1069,3 +1069,37 @@ def test_mpc_update_rarely_ends_at_the_iteration_cap(torch_first, built_lib):
     assert failed == 0 and failed_off == 0
     assert restarted >= 20                                      # the restart really runs in this loop
     assert capped < 10 and capped < capped_off, (capped, capped_off)
+
+
+@pytest.mark.parametrize("N,schedule,B,f32,kname", [(10, "mixed", 1024, False, "wrench_f64_n10"), (10, "mixed", 256, False, "compact_f64_n10_s4"),
+                                                    (20, "double", 512, False, "wrench_f64_n20"), (20, "double", 512, True, "wrench_f32_n20"),
+                                                    (16, "single", 256, False, "compact_f64_n16_s2")])
+def test_deferred_restart_passes_on_the_tail_stream(torch_first, built_lib, N, schedule, B, f32, kname):
+    """SRBDQP_FLAG_DEFER_TAIL on the kernels that restart by further launches: the restart passes of a solve run on the library's tail stream beside the caller's
+    next solves (lists of capped QPs as their dispatch order, three buffer sets in rotation); after srbdqp_flush() every output equals the same solves with the
+    passes on the caller's stream, over a pipeline of five batches."""
+    torch = torch_first
+    from g1_locomotion_amd import BatchMPC, _lib
+    dev = torch.device("cuda", 0)
+    tdt = torch.float32 if f32 else torch.float64
+    kw = dict(rho_restart_iter=30, rho_restart_count=2) if N <= 10 else dict(rho_restart_iter=40, rho_restart_count=1)     # (early marks: many QPs pass them)
+    batches = [orc.synthetic_batch(B, N, seed=2000 + 7 * j, schedule=schedule) for j in range(5)]
+    d_in = [[torch.from_numpy(v).to(dev).to(tdt) if v.dtype == np.float64 else torch.from_numpy(v).to(dev) for v in hb] for hb in batches]
+
+    def run(flags):
+        outs = [dict(u=torch.zeros((B, N, 12), dtype=tdt, device=dev), x=torch.zeros((B, N + 1, 13), dtype=tdt, device=dev),
+                     st=torch.full((B,), -77, dtype=torch.int32, device=dev), it=torch.zeros(B, dtype=torch.int32, device=dev)) for _ in batches]
+        s0 = torch.cuda.Stream(device=dev)
+        with BatchMPC(horizon=N, flags=flags, max_contacts_per_step=2 if schedule == "single" else 4, **kw) as eng:
+            for d, o in zip(d_in, outs):
+                eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), o["u"].data_ptr(), x_out=o["x"].data_ptr(),
+                                 status=o["st"].data_ptr(), iters=o["it"].data_ptr(), stream=s0.cuda_stream, f32=f32)
+            assert eng.kernel_name() == kname, eng.kernel_name()
+            eng.flush()
+            s0.synchronize()
+        return outs
+    ref, got = run(0), run(_lib.FLAG_DEFER_TAIL)
+    assert sum(int((o["it"] > kw["rho_restart_iter"]).sum()) for o in ref) >= 8
+    for j, (o, r) in enumerate(zip(got, ref)):
+        assert torch.equal(o["st"], r["st"]) and torch.equal(o["it"], r["it"]), j
+        assert torch.equal(o["u"], r["u"]) and torch.equal(o["x"], r["x"]), j
