@@ -266,26 +266,29 @@ class RaggedLeg:
                 dst = (off[idx][:, None] + np.arange(N)[None, :]).reshape(-1)
                 xr[dst] = b_.reshape(-1, 13); ft[dst] = c.reshape(-1, 12); ct[dst] = d.reshape(-1, 4)
             dd = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x0, xr, ft, ct)]
-            self.sets.append(dict(Nq=Nq, rows=rows, d=dd,
-                                  u=torch.empty((rows, 12), dtype=torch.float64, device=dev),
-                                  x=torch.empty((rows + B, 13), dtype=torch.float64, device=dev),
-                                  st=torch.zeros(B, dtype=torch.int32, device=dev), it=torch.zeros(B, dtype=torch.int32, device=dev)))
+            # two output copies per input set: with the restart passes on the tail streams a call's outputs are written until the library lets its
+            # buffer set go (three calls later), so a call must not write where the call two before it may still be writing
+            outs = [dict(u=torch.empty((rows, 12), dtype=torch.float64, device=dev), x=torch.empty((rows + B, 13), dtype=torch.float64, device=dev),
+                         st=torch.zeros(B, dtype=torch.int32, device=dev), it=torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(2)]
+            self.sets.append(dict(Nq=Nq, rows=rows, d=dd, outs=outs, **outs[0]))
         self.NO = nb
-        self.eng = RaggedMPC(horizons=RAGGED_HORIZONS, device=local_rank)
+        from g1_locomotion_amd import _lib
+        self.defer = not getattr(args, "in_place", False)
+        # SRBDQP_FLAG_DEFER_TAIL: the restart passes of a bucket run on its tail stream beside the next call; flushed inside the timed steps
+        self.eng = RaggedMPC(horizons=RAGGED_HORIZONS, device=local_rank, **({"flags": _lib.FLAG_DEFER_TAIL} if self.defer else {}))
         self.streams = [torch.cuda.Stream(device=dev)]
         self.kname = "ragged_wrench_f64_n8_n12_n16_n24"
         self.d_u = [s["u"] for s in self.sets]
 
-    defer = False
-
     def flush(self):
-        pass
+        if self.defer:
+            self.eng.flush(self.streams[0].cuda_stream)
 
     def step(self, i, S=1, hint="none"):
         s = self.sets[i % self.nb]
-        d = s["d"]
-        self.eng.solve_device(self.B, s["Nq"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), s["u"].data_ptr(),
-                              x_out=s["x"].data_ptr(), status=s["st"].data_ptr(), iters=s["it"].data_ptr(), stream=self.streams[0].cuda_stream)
+        d, o = s["d"], s["outs"][(i // self.nb) % 2]
+        self.eng.solve_device(self.B, s["Nq"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), o["u"].data_ptr(),
+                              x_out=o["x"].data_ptr(), status=o["st"].data_ptr(), iters=o["it"].data_ptr(), stream=self.streams[0].cuda_stream)
 
     def stats(self, solved_code):
         it = np.concatenate([s["it"].cpu().numpy() for s in self.sets]); st = np.concatenate([s["st"].cpu().numpy() for s in self.sets])

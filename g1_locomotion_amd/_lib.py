@@ -32,7 +32,7 @@ EXPORTS = (
     "srbdqp_default_config", "srbdqp_create", "srbdqp_destroy", "srbdqp_last_error",
     "srbdqp_solve_batch_f64", "srbdqp_solve_batch_device_f64", "srbdqp_solve_batch_f32", "srbdqp_solve_batch_device_f32",
     "srbdqp_assemble_f64", "srbdqp_assemble_wrench_f64",
-    "srbdqp_ragged_create", "srbdqp_ragged_destroy", "srbdqp_ragged_last_error", "srbdqp_solve_ragged_device_f64", "srbdqp_solve_ragged_f64",
+    "srbdqp_ragged_create", "srbdqp_ragged_destroy", "srbdqp_ragged_last_error", "srbdqp_ragged_flush", "srbdqp_solve_ragged_device_f64", "srbdqp_solve_ragged_f64",
     "srbdqp_solve_ragged_device_f32", "srbdqp_solve_ragged_f32", "srbdqp_solve_ragged_warm_device_f64", "srbdqp_solve_ragged_warm_device_f32",
     "srbdqp_set_schedule_hint", "srbdqp_flush", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_update_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
     # include/srbdqp_cascade.h
@@ -135,6 +135,8 @@ def load():
     lib.srbdqp_ragged_create.restype = C.c_int
     lib.srbdqp_ragged_destroy.argtypes = [H]
     lib.srbdqp_ragged_destroy.restype = C.c_int
+    lib.srbdqp_ragged_flush.argtypes = [H, C.c_void_p]
+    lib.srbdqp_ragged_flush.restype = C.c_int
     lib.srbdqp_ragged_last_error.argtypes = [H]
     lib.srbdqp_ragged_last_error.restype = C.c_char_p
     lib.srbdqp_solve_ragged_device_f64.argtypes = [H, C.c_int32, C.c_void_p, dp, dp, dp, u8p, dp, dp, i32p, i32p, C.c_void_p]

@@ -1481,6 +1481,15 @@ struct srbdqp_ragged {
     // [cap], duals of the first pass [row_cap][20] (the second pass warm-starts from them)
     float* d_resid = nullptr; int32_t* d_status = nullptr; double* d_y = nullptr; size_t row_cap = 0;
     double* d_rho = nullptr;                  // [2][cap]: the rho a restart pass ran its QPs with, for the pass behind it
+    // SRBDQP_FLAG_DEFER_TAIL: every array above exists kSets times (set = call number mod kSets) and the restart passes of a bucket run on the bucket's own tail
+    // stream behind its first pass, beside the next calls; a set is reused only behind the events that close its last user's passes
+    static constexpr int kSets = 3;
+    bool defer = false;
+    unsigned long long call_k = 0;
+    std::vector<hipStream_t> tail_st;         // per bucket
+    std::vector<hipEvent_t> ev_tail;          // [kSets][nb]
+    std::vector<char> ev_tail_used;           // [kSets][nb]
+    std::vector<hipEvent_t> last_tail;        // per bucket: closes the passes of the last call that had any (srbdqp_ragged_flush), or null
     char* ws = nullptr; size_t ws_bytes = 0;  // host-buffer entry point: device copies of the caller's arrays
     hipStream_t stream = nullptr;             // ... and the stream its copies run on
     std::string err;
@@ -1530,6 +1539,23 @@ int srbdqp_ragged_create(const srbdqp_config* cfg, const int32_t* horizons, int3
     }
     if (hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming) != hipSuccess) return fail(SRBDQP_E_HIP, "hipEventCreate");
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return fail(SRBDQP_E_HIP, "hipStreamCreate");
+    r->defer = (cfg->flags & SRBDQP_FLAG_DEFER_TAIL) != 0;
+    if (r->defer) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return fail(SRBDQP_E_HIP, "hipDeviceGetStreamPriorityRange");
+        for (int i = 0; i < n_horizons; ++i) {
+            hipStream_t ts = nullptr;
+            if (hipStreamCreateWithPriority(&ts, hipStreamNonBlocking, greatest) != hipSuccess) return fail(SRBDQP_E_HIP, "hipStreamCreate");
+            r->tail_st.push_back(ts);
+            r->last_tail.push_back(nullptr);
+        }
+        for (int i = 0; i < srbdqp_ragged::kSets * n_horizons; ++i) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(SRBDQP_E_HIP, "hipEventCreate");
+            r->ev_tail.push_back(ev);
+            r->ev_tail_used.push_back(0);
+        }
+    }
     *out = r;
     return SRBDQP_OK;
 }
@@ -1538,6 +1564,8 @@ int srbdqp_ragged_destroy(srbdqp_ragged* r) {
     if (!r) return SRBDQP_OK;
     (void)hipSetDevice(r->device);
     for (auto* h : r->hs) srbdqp_destroy(h);
+    for (auto ts : r->tail_st) if (ts) { (void)hipStreamSynchronize(ts); (void)hipStreamDestroy(ts); }
+    for (auto ev : r->ev_tail) if (ev) (void)hipEventDestroy(ev);
     for (auto ev : r->ev_out) if (ev) (void)hipEventDestroy(ev);
     if (r->ev_in) (void)hipEventDestroy(r->ev_in);
     if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
@@ -1558,6 +1586,7 @@ const char* srbdqp_ragged_last_error(const srbdqp_ragged* r) { return r ? r->err
 
 }  // extern "C"
 
+extern "C" int srbdqp_ragged_flush(srbdqp_ragged* r, void* stream);
 namespace {
 // common body of the ragged device entry points; esz = element size of the caller's buffers (8 or 4)
 int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const void* x0, const void* x_ref, const void* foot,
@@ -1571,24 +1600,27 @@ int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, con
     const size_t nb = r->hs.size();
     if ((size_t)B > r->cap) {   // (re)allocate the index arrays: the only point that waits, and only for earlier solves of this object
         for (auto* h : r->hs) RAG_TRY(r, hipStreamSynchronize(h->stream));
+        for (auto ts : r->tail_st) RAG_TRY(r, hipStreamSynchronize(ts));
         RAG_TRY(r, hipStreamSynchronize(sin));
+        std::fill(r->ev_tail_used.begin(), r->ev_tail_used.end(), 0);
         if (r->d_perm) (void)hipFree(r->d_perm);
         if (r->d_off) (void)hipFree(r->d_off);
         if (r->h_perm) (void)hipHostFree(r->h_perm);
         if (r->h_off) (void)hipHostFree(r->h_off);
         r->d_perm = r->d_off = r->h_perm = r->h_off = nullptr; r->cap = 0;
         const size_t want = (size_t)B + (size_t)B / 4 + 64;
-        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_perm), want * 4));
-        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_off), want * 4));
+        const size_t ns = r->defer ? (size_t)srbdqp_ragged::kSets : 1;
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_perm), ns * want * 4));
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_off), ns * want * 4));
         RAG_TRY(r, hipHostMalloc(reinterpret_cast<void**>(&r->h_perm), want * 4, hipHostMallocDefault));
         RAG_TRY(r, hipHostMalloc(reinterpret_cast<void**>(&r->h_off), want * 4, hipHostMallocDefault));
         if (r->d_resid) (void)hipFree(r->d_resid);
         if (r->d_status) (void)hipFree(r->d_status);
         if (r->d_rho) (void)hipFree(r->d_rho);
         r->d_resid = nullptr; r->d_status = nullptr; r->d_rho = nullptr;
-        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_resid), want * 16));
-        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_status), want * 4));
-        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_rho), 2 * want * sizeof(double)));
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_resid), ns * want * 16));
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_status), ns * want * 4));
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_rho), ns * 2 * want * sizeof(double)));
         r->cap = want;
         r->ev_in_pending = false;
     }
@@ -1610,10 +1642,11 @@ int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, con
     for (size_t i = 0; i < nb; ++i) any_restart = any_restart || (cnt[i] > 0 && restart_iter_of(r->hs[i], 4, cnt[i]) > 0);
     if (any_restart && (size_t)rows > r->row_cap) {   // dual buffer of the restart (waits for earlier solves of this object only)
         for (auto* h : r->hs) RAG_TRY(r, hipStreamSynchronize(h->stream));
+        for (auto ts : r->tail_st) RAG_TRY(r, hipStreamSynchronize(ts));
         if (r->d_y) (void)hipFree(r->d_y);
         r->d_y = nullptr; r->row_cap = 0;
         const size_t want = (size_t)rows + (size_t)rows / 4 + 64;
-        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_y), want * 20 * sizeof(double)));
+        RAG_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->d_y), (r->defer ? (size_t)srbdqp_ragged::kSets : 1) * want * 20 * sizeof(double)));
         r->row_cap = want;
     }
     std::vector<int> fill(start.begin(), start.end() - 1);
@@ -1621,8 +1654,19 @@ int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, con
     // the index arrays (and the restart buffers) are shared by the calls of this object: the upload below must not overtake the
     // bucket kernels of an earlier call made on ANOTHER caller stream (calls on one stream are ordered through ev_out already)
     for (size_t i = 0; i < nb; ++i) if (r->ev_out_used[i]) RAG_TRY(r, hipStreamWaitEvent(sin, r->ev_out[i], 0));
-    RAG_TRY(r, hipMemcpyAsync(r->d_off, r->h_off, (size_t)B * 4, hipMemcpyHostToDevice, sin));
-    RAG_TRY(r, hipMemcpyAsync(r->d_perm, r->h_perm, (size_t)B * 4, hipMemcpyHostToDevice, sin));
+    // this call's set of the shared arrays (deferred restart passes: three in rotation; behind the passes of the set's last user)
+    const size_t set = r->defer ? (size_t)(r->call_k++ % srbdqp_ragged::kSets) : 0;
+    if (r->defer)
+        for (size_t i = 0; i < nb; ++i)
+            if (r->ev_tail_used[set * nb + i]) RAG_TRY(r, hipStreamWaitEvent(sin, r->ev_tail[set * nb + i], 0));
+    int32_t* const d_off = r->d_off + set * r->cap;
+    int32_t* const d_perm = r->d_perm + set * r->cap;
+    float* const d_resid = r->d_resid + set * r->cap * 4;
+    int32_t* const d_status = r->d_status + set * r->cap;
+    double* const d_rho = r->d_rho + set * 2 * r->cap;
+    double* const d_y = r->d_y ? r->d_y + set * r->row_cap * 20 : nullptr;
+    RAG_TRY(r, hipMemcpyAsync(d_off, r->h_off, (size_t)B * 4, hipMemcpyHostToDevice, sin));
+    RAG_TRY(r, hipMemcpyAsync(d_perm, r->h_perm, (size_t)B * 4, hipMemcpyHostToDevice, sin));
     RAG_TRY(r, hipEventRecord(r->ev_in, sin));
     r->ev_in_pending = true;
     // one launch per non-empty bucket, each on its engine's own stream behind the upload; the caller's stream then waits for all
@@ -1638,28 +1682,43 @@ int ragged_device_impl(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, con
         a.warm_u = static_cast<const double*>(warm_u); a.warm_y = static_cast<const double*>(warm_y);
         a.u_out = static_cast<double*>(u_out); a.x_out = static_cast<double*>(x_out); a.y_out = static_cast<double*>(y_out);
         a.status = status; a.iters = iters;
-        a.perm = r->d_perm + start[i]; a.row_off = r->d_off;
+        a.perm = d_perm + start[i]; a.row_off = d_off;
         a.B = cnt[i]; a.mode = 0;
         int rcount = 1;
         const int restart = restart_iter_of(bh, 4, cnt[i], false, &rcount);
         int rc;
         if (restart > 0) {   // several passes over the bucket, as srbdqp_solve_batch_* does (the later ones select their QPs in-kernel)
             KArgs a1 = a;
-            a1.max_iter = restart; a1.resid_out = r->d_resid;
-            if (!a1.y_out) { a1.y_out = r->d_y; a1.y_capped_only = 1; }   // (a later pass warm-starts from the duals of the pass before it)
-            if (!a1.status) a1.status = r->d_status;
+            a1.max_iter = restart; a1.resid_out = d_resid;
+            if (!a1.y_out) { a1.y_out = d_y; a1.y_capped_only = 1; }   // (a later pass warm-starts from the duals of the pass before it)
+            if (!a1.status) a1.status = d_status;
             rc = ragged_launch_bucket(bh, a1, bs, f32);
+            hipStream_t ps = bs;                                          // the stream the restart passes run on
+            if (r->defer && rc == SRBDQP_OK) {
+                // ... the bucket's tail stream, behind its first pass: the caller's stream waits for the first pass only, the passes run beside what it enqueues next
+                RAG_TRY(r, hipEventRecord(r->ev_out[i], bs));
+                r->ev_out_used[i] = 1;
+                RAG_TRY(r, hipStreamWaitEvent(sin, r->ev_out[i], 0));
+                ps = r->tail_st[i];
+                RAG_TRY(r, hipStreamWaitEvent(ps, r->ev_out[i], 0));
+            }
             for (int p = 1; rc == SRBDQP_OK && p <= rcount; ++p) {        // (srbdqp_restart_pass, on the ragged object's own buffers)
                 const int done = p * restart, left = bh->cfg.max_iter - done;
                 const bool last = p >= rcount || restart >= left;
                 KArgs a2 = a1;
-                a2.resid_in = r->d_resid; a2.resid_out = last ? nullptr : r->d_resid;
+                a2.resid_in = d_resid; a2.resid_out = last ? nullptr : d_resid;
                 a2.warm_u = a1.u_out; a2.warm_y = a1.y_out;
                 a2.max_iter = last ? left : restart; a2.iters_base = done;
-                a2.rho_qp = (p == 1) ? nullptr : r->d_rho + (size_t)(p % 2) * r->cap;
-                a2.rho_out = last ? nullptr : r->d_rho + (size_t)((p + 1) % 2) * r->cap;
-                rc = ragged_launch_bucket(bh, a2, bs, f32);
+                a2.rho_qp = (p == 1) ? nullptr : d_rho + (size_t)(p % 2) * r->cap;
+                a2.rho_out = last ? nullptr : d_rho + (size_t)((p + 1) % 2) * r->cap;
+                rc = ragged_launch_bucket(bh, a2, ps, f32);
                 if (last) break;
+            }
+            if (r->defer && rc == SRBDQP_OK) {
+                RAG_TRY(r, hipEventRecord(r->ev_tail[set * nb + i], ps));
+                r->ev_tail_used[set * nb + i] = 1;
+                r->last_tail[i] = r->ev_tail[set * nb + i];
+                continue;                                                 // (ev_out was recorded behind the first pass)
             }
         } else {
             rc = ragged_launch_bucket(bh, a, bs, f32);
@@ -1703,7 +1762,9 @@ int ragged_host_impl(srbdqp_ragged* r, int32_t B, size_t esz, const int32_t* N_p
     RAG_TRY(r, hipMemcpyAsync(dxr, x_ref, rows * 13 * esz, hipMemcpyHostToDevice, st));
     RAG_TRY(r, hipMemcpyAsync(dft, foot, rows * 12 * esz, hipMemcpyHostToDevice, st));
     RAG_TRY(r, hipMemcpyAsync(dct, contact, rows * 4, hipMemcpyHostToDevice, st));
-    const int rc = ragged_device_impl(r, B, N_per_qp, dx0, dxr, dft, dct, nullptr, nullptr, du, dx, nullptr, dst, dit, st, esz == 4);
+    int rc = ragged_device_impl(r, B, N_per_qp, dx0, dxr, dft, dct, nullptr, nullptr, du, dx, nullptr, dst, dit, st, esz == 4);
+    if (rc != SRBDQP_OK) return rc;
+    rc = srbdqp_ragged_flush(r, st);                     // (deferred restart passes: the copies below need every QP finished)
     if (rc != SRBDQP_OK) return rc;
     RAG_TRY(r, hipMemcpyAsync(u_out, du, rows * 12 * esz, hipMemcpyDeviceToHost, st));
     if (x_out) RAG_TRY(r, hipMemcpyAsync(x_out, dx, (rows + b) * 13 * esz, hipMemcpyDeviceToHost, st));
@@ -1715,6 +1776,15 @@ int ragged_host_impl(srbdqp_ragged* r, int32_t B, size_t esz, const int32_t* N_p
 }  // namespace
 
 extern "C" {
+
+int srbdqp_ragged_flush(srbdqp_ragged* r, void* stream) {
+    if (!r) return SRBDQP_E_INVALID;
+    RAG_TRY(r, hipSetDevice(r->device));
+    hipStream_t sin = stream ? reinterpret_cast<hipStream_t>(stream) : r->stream;
+    for (auto& ev : r->last_tail)
+        if (ev) { RAG_TRY(r, hipStreamWaitEvent(sin, ev, 0)); ev = nullptr; }
+    return SRBDQP_OK;
+}
 
 int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp, const double* x0, const double* x_ref,
                                    const double* foot, const uint8_t* contact, double* u_out, double* x_out, int32_t* status,

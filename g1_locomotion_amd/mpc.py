@@ -368,6 +368,11 @@ class RaggedMPC:
             fn = self._lib.srbdqp_solve_ragged_device_f32 if f32 else self._lib.srbdqp_solve_ragged_device_f64
             self._check(fn(self._h, int(B), _ptr(Nq), v(x0), v(x_ref), v(foot), v(contact), v(u_out), v(x_out), v(status), v(iters), v(stream)))
 
+    def flush(self, stream=0):
+        """flags=FLAG_DEFER_TAIL: make `stream` (0 = the object's own) wait for the restart passes still running on the buckets' tail streams
+        (srbdqp_ragged_flush).  Does not synchronise."""
+        self._check(self._lib.srbdqp_ragged_flush(self._h, C.c_void_p(int(stream)) if stream else None))
+
     def solve(self, problems):
         """problems: sequence of dicts(x0 (13,), x_ref (N,13), foot (N,12), contact (N,4)) with per-QP N.
         Returns a list of dicts(u (N,12), x (N+1,13), status, iters) in the input order."""

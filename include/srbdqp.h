@@ -236,6 +236,11 @@ int srbdqp_solve_ragged_device_f64(srbdqp_ragged* r, int32_t B, const int32_t* N
 int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,
                             const double* x0, const double* x_ref, const double* foot, const uint8_t* contact,
                             double* u_out, double* x_out, int32_t* status, int32_t* iters);
+/* cfg.flags & SRBDQP_FLAG_DEFER_TAIL at srbdqp_ragged_create: the restart passes of a bucket run on the bucket's own tail stream behind its first pass -- the
+ * caller's stream waits for the first passes only, the passes run beside what it enqueues next (e.g. the next call: every shared array exists three times, in
+ * rotation).  srbdqp_ragged_flush makes `stream` (NULL = the object's own) wait for the passes still running; before it the outputs of the QPs a first pass left
+ * at its cap (status SRBDQP_MAX_ITER at that point) are not final.  A no-op without the flag.  The host-buffer entry points flush by themselves. */
+int srbdqp_ragged_flush(srbdqp_ragged* r, void* stream);
 /* The same two calls with fp32 buffers and fp32 ADMM iterations (as srbdqp_solve_batch_device_f32 / _f32; every bucket factors
  * its T in fp64 tiles: a bucket's QPs are not split by tile precision). */
 int srbdqp_solve_ragged_device_f32(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp,

@@ -1103,3 +1103,48 @@ def test_deferred_restart_passes_on_the_tail_stream(torch_first, built_lib, N, s
     for j, (o, r) in enumerate(zip(got, ref)):
         assert torch.equal(o["st"], r["st"]) and torch.equal(o["it"], r["it"]), j
         assert torch.equal(o["u"], r["u"]) and torch.equal(o["x"], r["x"]), j
+
+
+def test_ragged_restart_passes_on_the_tail_streams(torch_first, built_lib):
+    """srbdqp_ragged_create with SRBDQP_FLAG_DEFER_TAIL: the restart passes of every bucket run on the bucket's tail stream beside the next calls (three sets of the
+    shared arrays in rotation); after srbdqp_ragged_flush() a pipeline of six calls (two fleets alternating, each with its own outputs) equals the same calls with
+    the passes on the buckets' own streams."""
+    torch = torch_first
+    from g1_locomotion_amd import RaggedMPC, _lib
+    dev = torch.device("cuda", 0)
+    HZ = (8, 12, 16, 24)
+    fleets = []
+    for j in range(2):
+        rng = np.random.default_rng(50 + j)
+        B = 600 + 100 * j
+        Nq = rng.choice(HZ, size=B).astype(np.int32)
+        rows = int(Nq.sum()); off = np.concatenate([[0], np.cumsum(Nq)])
+        x0 = np.empty((B, 13)); xr = np.empty((rows, 13)); ft = np.empty((rows, 12)); ct = np.empty((rows, 4), np.uint8)
+        for N in HZ:
+            idx = np.where(Nq == N)[0]
+            a, b_, c, d = orc.synthetic_batch(len(idx), N, seed=60 + N + j, schedule="mixed")
+            x0[idx] = a
+            dst = (off[idx][:, None] + np.arange(N)[None, :]).reshape(-1)
+            xr[dst] = b_.reshape(-1, 13); ft[dst] = c.reshape(-1, 12); ct[dst] = d.reshape(-1, 4)
+        fleets.append(dict(B=B, Nq=Nq, rows=rows, d=[torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x0, xr, ft, ct)]))
+
+    def run(flags):
+        outs = []
+        s0 = torch.cuda.Stream(device=dev)
+        eng = RaggedMPC(horizons=HZ, rho_restart_iter=40, rho_restart_count=2, **({"flags": flags} if flags else {}))
+        for k in range(6):
+            f = fleets[k % 2]
+            o = dict(u=torch.zeros((f["rows"], 12), dtype=torch.float64, device=dev), x=torch.zeros((f["rows"] + f["B"], 13), dtype=torch.float64, device=dev),
+                     st=torch.zeros(f["B"], dtype=torch.int32, device=dev), it=torch.zeros(f["B"], dtype=torch.int32, device=dev))
+            d = f["d"]
+            eng.solve_device(f["B"], f["Nq"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), o["u"].data_ptr(), x_out=o["x"].data_ptr(),
+                             status=o["st"].data_ptr(), iters=o["it"].data_ptr(), stream=s0.cuda_stream)
+            outs.append(o)
+        eng.flush(s0.cuda_stream)
+        s0.synchronize()
+        eng.close()
+        return outs
+    ref, got = run(0), run(_lib.FLAG_DEFER_TAIL)
+    assert sum(int((o["it"] > 40).sum()) for o in ref) >= 20
+    for k, (o, r) in enumerate(zip(got, ref)):
+        assert torch.equal(o["st"], r["st"]) and torch.equal(o["it"], r["it"]) and torch.equal(o["u"], r["u"]) and torch.equal(o["x"], r["x"]), k
