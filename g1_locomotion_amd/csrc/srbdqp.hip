@@ -677,8 +677,8 @@ int ensure_tail_lists(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStre
     return SRBDQP_OK;
 }
 
-// run what the lists of this launch stream still hold: every flush launch runs ONE pass of every record (one workgroup per record the lists can hold), so
-// rho_restart_count of them finish everything; enqueued on st, no host synchronisation
+// run what the lists of this launch stream still hold: one launch, one workgroup per record the lists can hold, each running every pass its QP has left;
+// enqueued on st, no host synchronisation
 int flush_slot(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st) {
     if (!slot->tail || !slot->tail_live) return SRBDQP_OK;
     int rcount = 1;
@@ -688,7 +688,7 @@ int flush_slot(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st
     std::memset(&a, 0, sizeof(a));
     fill_args(h->cfg, a);
     a.B = 0; a.restart_every = restart; a.restart_max = rcount;
-    for (int j = 0; j < rcount; ++j) {
+    {   // ONE launch: a flush workgroup runs every pass its QP has left (srbdqp_setup1.hpp, FLUSH)
         const int rc = launch_wave_defer_any(h, a, st, slot, maxs <= 2 ? 2 : 4);
         if (rc != SRBDQP_OK) return rc;
     }

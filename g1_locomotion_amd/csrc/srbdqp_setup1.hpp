@@ -583,7 +583,7 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const QpIo& io, cons
             rs.more = rs_pass < a.restart_max && a.restart_every < left;
             // deferred tails: the continuation goes to a list of tail_cap records; with less room than every wave in flight could claim at once, this QP
             // simply runs on at its rho (the host sizes the lists so that this cannot happen: (rho_restart_count + 1) records per QP of a launch)
-            if (a.tail_lists) rs.more = rs.more && (a.tail_cnt[a.tail_iout] + 4096 < a.tail_cap);
+            if (a.tail_lists && a.B > 0) rs.more = rs.more && (a.tail_cnt[a.tail_iout] + 4096 < a.tail_cap);      // (a.B = 0: a flush launch continues in place)
             rs.kcap = rs.more ? a.restart_every : left;
             rs.park = park;
             int status = -1, iters = 0;
@@ -662,7 +662,9 @@ __device__ __forceinline__ void tail_export(const KArgs& a, const QpIo& io, int 
     rec[16 + lane] = park[lane]; rec[80 + lane] = park[64 + lane]; rec[144 + lane] = park[128 + lane];
 }
 
-// FLUSH: the continuations alone (srbdqp_flush: a launch with no QPs of its own; a kernel of its own name, so that profiles keep the two apart)
+// FLUSH: the continuations alone (srbdqp_flush: a launch with no QPs of its own; a kernel of its own name, so that profiles keep the two apart).  Nothing comes
+// behind a flush that could pick a record up, so here a workgroup runs ALL the passes its QP has left, the later ones in place as the restart kernel does (the
+// loop's hoisted registers cost this instantiation only): one flush launch instead of rho_restart_count of them.
 template <int N, int MAXS, bool FLUSH = false>
 __global__ __launch_bounds__(64, 2) void srbdqp_wave_defer_kernel(KArgs a) {
     static_assert(Setup1Smem<N, MAXS>::supported && 4 * N <= 64, "the one-wave kernel's limits");
@@ -701,7 +703,12 @@ __global__ __launch_bounds__(64, 2) void srbdqp_wave_defer_kernel(KArgs a) {
         double rho_b = unis(hd->rho);
         park[lane] = rec[16 + lane]; park[64 + lane] = rec[80 + lane]; park[128 + lane] = rec[144 + lane];
         __syncthreads();
-        if (setup1_pass<N, MAXS, true, false, false, 3>(a, io, b, sm, rho_b, rs_pass, rs_done)) tail_export(a, io, b, rho_b, rs_pass, rs_done, park);
+        bool again = setup1_pass<N, MAXS, true, false, false, 3>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if constexpr (FLUSH) {
+            while (again) again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        } else {
+            if (again) tail_export(a, io, b, rho_b, rs_pass, rs_done, park);
+        }
     } else if constexpr (!FLUSH) {
         // ---- a QP of this launch: its first pass
         const int wg = (int)blockIdx.x - T;

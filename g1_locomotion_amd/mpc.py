@@ -467,6 +467,7 @@ class MPC:
         eng = self._engine
         st = eng.stage()
         self._s_x0, self._s_xref, self._s_pcom = st["x0"][0], st["x_ref"][0], st["pcom"][0]
+        self._s_x0c = st["x0"][0].reshape(NX, 1)        # the reference passes MPC.x0, a (13, 1) column (run_simulation.py:73-77,106): same-shape assignment is the cheapest copy
         self._s_foot2, self._s_ct2 = st["foot"][0], st["contact"][0]
         self._s_foot, self._s_ct = st["foot"][0].reshape(-1), st["contact"][0].reshape(-1)
         self._s_u, self._s_x = st["u"][0], st["x"][0]
@@ -585,7 +586,11 @@ class MPC:
                 return self._update_general(contact_horizon, c_horizon, p_com_horizon, x_current, one_rollout)
             upd = self._bind()
         try:
-            self._s_x0[:] = (self.x0 if x_current is None else x_current).reshape(NX)
+            x_cur = self.x0 if x_current is None else x_current
+            try:
+                self._s_x0c[...] = x_cur
+            except ValueError:                     # not a (13, 1) column: (13,) and the like
+                self._s_x0[:] = x_cur.reshape(NX)
             self._s_xref[:] = self.x_ref_hor
             if type(c_horizon) is np.ndarray:
                 self._s_foot2[:] = c_horizon

@@ -271,8 +271,8 @@ int srbdqp_solve_ragged_warm_device_f32(srbdqp_ragged* r, int32_t B, const int32
 int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev, int32_t length);
 
 /* SRBDQP_FLAG_DEFER_TAIL: complete what earlier device-buffer solves on `stream` (a hipStream_t; NULL = every stream this handle has
- * launched on) left for later -- the one-wave kernel's continuations that no later solve has picked up (at most rho_restart_count
- * launches of the continuations alone, enqueued on that stream), and the restart passes running on the library's own tail stream (the
+ * launched on) left for later -- the one-wave kernel's continuations that no later solve has picked up (one launch of the
+ * continuations alone, enqueued on that stream, in which every such QP runs all the passes it has left), and the restart passes running on the library's own tail stream (the
  * stream is made to wait for them through an event).  Returns without synchronising; after it every output of every earlier solve on
  * that stream is complete in stream order.  A no-op without the flag or with nothing pending.  srbdqp_synchronize() flushes the
  * handle's own stream first. */
