@@ -820,8 +820,8 @@ def cpu_baseline(config, N, batch):
     r_iter, r_count = orc.default_restart(N)
     p = orc.params_for(N, rho_restart_iter=r_iter, rho_restart_count=r_count)    # as the engine runs the config by default
     cores = _cpu_share()
-    # sized for ~10-30 s of CPU work: N = 10 -> 4096 QPs x 24 (0.15 ms per QP and thread), N = 20 -> 1024 QPs x 2 (dense
-    # 240-variable factor: several ms per QP and thread)
+    # sized for ~10-30 s of CPU WORK (thread-seconds, not wall time: ~1 s of wall on the box's 16 granted threads): N = 10 -> 4096 QPs x 24 (0.15 ms per QP and
+    # thread = 15 thread-seconds), N = 20 -> 1024 QPs x 2 (dense 240-variable factor: several ms per QP and thread)
     Sall, reps, S1 = (min(4096, x0.shape[0]), 24, min(2048, x0.shape[0])) if N <= 10 else (min(1024, x0.shape[0]), 2, 64)
     a = [v[:Sall] for v in (x0, xr, ft, ct)]
     t = time.perf_counter()

@@ -146,4 +146,19 @@ __device__ __forceinline__ float wave_maxf_nonneg(float v) {
     return v;                          // lane 63 holds the wave maximum
 }
 
+// Four wave maxima at once (the four fp32 maxima of a convergence check), every step ONE v_max_f32 with a DPP source operand, in place: a lane whose DPP source is
+// shifted in from outside its row (bound_ctrl off) or whose row the step masks out is simply not written and keeps its value -- max(v, 0) = v for the non-negative
+// values these are.  Written out by the compiler from dpp_maxf_step a step was v_mov_b32 0 + v_mov_b32_dpp + a canonicalising v_max_f32 v, v, v + the v_max_f32 itself
+// and, one value at a time, an s_nop for the DPP read-after-write hazard: 96 vector instructions and 18 s_nop per check against 24 here (the four chains interleaved
+// put three instructions between a write and its DPP read: no wait states needed).  Inputs must not be NaN (the callers map a NaN residual to a huge number first).
+// Results valid in lane 63.
+#define SRBDQP_MAX4(CTRL) "v_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\tv_max_f32_dpp %2, %2, %2 " CTRL "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\t"
+__device__ __forceinline__ void wave_maxf4_nonneg(float& v0, float& v1, float& v2, float& v3) {
+    asm volatile("s_nop 1\n\t"
+                 SRBDQP_MAX4("row_shr:1 row_mask:0xf bank_mask:0xf") SRBDQP_MAX4("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 SRBDQP_MAX4("row_shr:4 row_mask:0xf bank_mask:0xf") SRBDQP_MAX4("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 SRBDQP_MAX4("row_bcast:15 row_mask:0xa bank_mask:0xf") SRBDQP_MAX4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+}
+
 }  // namespace srbdqp

@@ -268,7 +268,8 @@ __device__ int admm_loop_compact(const KArgs& a, int b, double* sm, double* rhsb
                 const float v0 = (float)(rowm * rp), v1 = (float)(rowm * fmax(fabs(axr), fabs(z)));
                 const bool varlane = active && prim;            // lanes on which A'(.) is the variable's value
                 const float v2 = varlane ? (float)rd : 0.0f, v3 = varlane ? (float)fmax(fabs(px), fabs(aty)) : 0.0f;
-                const float m0 = wave_maxf_nonneg(v0), m1 = wave_maxf_nonneg(v1), m2 = wave_maxf_nonneg(v2), m3 = wave_maxf_nonneg(v3);
+                float m0 = v0, m1 = v1, m2 = v2, m3 = v3;
+                wave_maxf4_nonneg(m0, m1, m2, m3);
                 if (lane == 63) {
                     float* buf = redf + (nchk & 1) * 16 + 4 * w;
                     buf[0] = m0; buf[1] = m1; buf[2] = m2; buf[3] = m3;

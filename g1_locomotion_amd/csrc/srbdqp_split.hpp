@@ -155,10 +155,12 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, const QpIo&
                 const double nr = fmax(rowA ? fmax(fabs(axA), fabs(zA)) : 0.0, rowB ? fmax(fabs(axB), fabs(zB)) : 0.0);
                 const float v0 = (float)rp, v1 = (float)nr;
                 const float v2 = active ? (float)rd : 0.0f, v3 = active ? (float)fmax(fabs(px), fabs(aty)) : 0.0f;
-                const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg(v0)), 63));
-                const float m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg(v1)), 63));
-                const float m2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg(v2)), 63));
-                const float m3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_maxf_nonneg(v3)), 63));
+                float r0 = v0, r1 = v1, r2 = v2, r3 = v3;
+                wave_maxf4_nonneg(r0, r1, r2, r3);
+                const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0), 63));
+                const float m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1), 63));
+                const float m2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2), 63));
+                const float m3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r3), 63));
                 const double e_prim = a.eps_abs + a.eps_rel * (double)m1;
                 const double e_dual = a.eps_abs + a.eps_rel * fmax((double)m3, (double)qnf);
                 e_prim_last = e_prim;

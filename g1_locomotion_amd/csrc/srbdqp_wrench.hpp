@@ -1542,7 +1542,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const R nr = rmax(rowA ? rmax(rabs(axA), rabs(zA)) : R(0), rowB ? rmax(rabs(axB), rabs(zB)) : R(0));
                 const float v0 = (float)rp, v1 = (float)nr;
                 const float v2 = active_u ? (float)rd : 0.0f, v3 = active_u ? (float)rmax(rabs(cc - (R)qv), rabs(aty)) : 0.0f;
-                const float m0 = wave_maxf_nonneg(v0), m1 = wave_maxf_nonneg(v1), m2 = wave_maxf_nonneg(v2), m3 = wave_maxf_nonneg(v3);
+                float m0 = v0, m1 = v1, m2 = v2, m3 = v3;
+                wave_maxf4_nonneg(m0, m1, m2, m3);
                 if (lane == 63) {
                     float* buf = redf + (nchk & 1) * 4 * NWS + 4 * w;
                     buf[0] = m0; buf[1] = m1; buf[2] = m2; buf[3] = m3;

@@ -221,3 +221,27 @@ def test_closed_form_assembly_equals_the_dense_products(N, schedule, seed):
     np.testing.assert_array_equal(vi, vi2)
     assert np.abs(P - red["P"]).max() <= 1e-12 * np.abs(red["P"]).max()
     assert np.abs(q - red["q"]).max() <= 1e-12 * max(1.0, np.abs(red["q"]).max())
+
+
+def test_split_oracle_runs_the_same_restart_passes_as_the_dense_one():
+    """Round 4: one restart rule for every kernel, so the general kernel's twin (update_split) runs up to rho_restart_count re-balancings too, each from the rho
+    of the pass before it.  In float64 its iterates are the dense path's: same statuses, same iteration counts, same forces, with the marks early enough that
+    most of these QPs pass one or two of them; and default_params() is what the engine resolves rho_restart_iter = 0 to."""
+    assert orc.default_restart(10) == (55, 2) and orc.default_restart(8) == (55, 2) and orc.default_restart(16) == (100, 1) and orc.default_restart(24) == (125, 1)
+    p0 = orc.default_params(10)
+    assert (p0.rho_restart_iter, p0.rho_restart_count, p0.rho, p0.rho_fz_scale) == (55, 2, orc.auto_rho(10), orc.auto_rho_fz_scale(10))
+    N = 10
+    x0, xr, ft, ct = orc.synthetic_batch(12, N, seed=91, schedule="mixed")
+    p = orc.params_for(N, rho_restart_iter=15, rho_restart_count=2)
+    passed = 0
+    for b in range(12):
+        a = orc.update(p, x0[b], xr[b], ft[b], ct[b])
+        s = orc.update_split(p, x0[b], xr[b], ft[b], ct[b], dtype=np.float64)
+        assert a["status"] == s["status"] and abs(a["iters"] - s["iters"]) <= p.check_every, (b, a["iters"], s["iters"])
+        if a["iters"] == s["iters"]:
+            assert np.abs(a["u"] - s["u"]).max() < 1e-5
+        passed += a["iters"] > 15
+        one = orc.update(orc.params_for(N, rho_restart_iter=15, rho_restart_count=1), x0[b], xr[b], ft[b], ct[b])
+        if a["iters"] <= 30:                                       # never reached the second mark: the count does not matter
+            assert one["iters"] == a["iters"] and np.array_equal(one["u"], a["u"])
+    assert passed >= 2
