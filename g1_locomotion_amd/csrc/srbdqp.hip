@@ -597,9 +597,10 @@ struct Carver {
 
 // Iteration at which a solve of this handle re-balances rho (0 = never), and how many times it may (*count).  srbdqp_config.rho_restart_iter: > 0 that
 // iteration, < 0 off, 0 = automatic:
-//  * N > 10: once after 100 (125 above N = 16) iterations -- the long horizons have a 1 - 3 % tail of slow QPs (N = 20 single support: 98.4 % solved without,
-//    99.3 % with; N = 20 double support with the (0.7, 4) penalties: 17 % of the QPs run past 80 iterations, 8 % past 100, 3 % past 125 -- an earlier restart sends
-//    too many through a second set-up: 80 instead of 125 cost configs[2] 10 % for 99.90 % instead of 99.89 % solved);
+//  * N > 10: the long horizons have a 1 - 3 % tail of slow QPs and a set-up that is two thirds of a solve: N = 12: 70 x 2, N = 16: 80 x 3, N = 20: 125 x 1,
+//    N = 24: 100 x 2 (below) -- N = 20 single support: 98.4 % solved without, 99.3 % with; N = 20 double support with the (0.7, 4) penalties: 17 % of the QPs run past
+//    80 iterations, 8 % past 100, 3 % past 125 -- an earlier restart sends too many through a second set-up: 80 instead of 125 cost configs[2] 10 % for 99.90 %
+//    instead of 99.89 % solved;
 //  * N <= 10: every 55 iterations, up to twice, each time from the rho of the pass before it -- 99.3 % -> 99.93 % of the configs[1] QPs solved inside the same
 //    250-iteration cap, at fewer iterations in total (34.8 -> 33.8).  Measured on the one-wave kernel (configs[1], 4 x 4096 QPs; M QP/s, solved, duration of one
 //    isolated launch): off 30.6, 0.9929, 0.19 ms; 80 x 1 30.2, 0.9981, 0.21; 65 x 2 30.0, 0.9991, 0.24; 55 x 2 29.6, 0.9993, 0.24; 70 x 3 29.2, 0.9996, 0.27;
@@ -620,8 +621,13 @@ inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B, bool wave = 
     if (rk != SRBDQP_KERNEL_COMPACT && rk != SRBDQP_KERNEL_WRENCH) return 0;   // v0 / v1 have no restart
     int r = c.rho_restart_iter;
     const bool automatic = r == 0;
-    if (automatic) r = (c.horizon > 10) ? (c.horizon <= 16 ? 100 : 125) : 55;
-    if (count) *count = c.rho_restart_count > 0 ? c.rho_restart_count : ((automatic && c.horizon <= 10) ? 2 : 1);
+    // automatic, by horizon (C oracle sweeps, 768 - 1024 QPs per case, round 4; solved share and restart events -- i.e. repeated set-ups -- per QP):
+    //   N <= 10  55 x 2;   N = 12  70 x 2 (mixed 99.6 -> 100 %, single 99.3 -> 99.9 %, 0.025 -> 0.05 events);   N = 16  80 x 3 (99.4 -> 100 %, 0.04 -> 0.08);
+    //   N = 20  125 x 1 (more re-balancings buy nothing inside the 250-iteration cap);   N = 24  100 x 2 (mixed 98.05 -> 98.96 %, double 99.6 -> 99.7 %,
+    //   0.13 -> 0.22 events; 80 x 3 would give 99.6 / 99.9 % for 0.32 events: a set-up is two thirds of a solve there)
+    const int N = c.horizon;
+    if (automatic) r = (N <= 10) ? 55 : (N == 12 ? 70 : (N == 16 ? 80 : (N == 24 ? 100 : 125)));
+    if (count) *count = c.rho_restart_count > 0 ? c.rho_restart_count : (!automatic ? 1 : ((N <= 12) ? 2 : (N == 16 ? 3 : (N == 24 ? 2 : 1))));
     return (r > 0 && r < c.max_iter) ? r : 0;
 }
 

@@ -95,14 +95,15 @@ typedef struct srbdqp_config {
     int32_t rho_restart_iter;     /* OSQP-style re-balancing of rho: a QP that has not converged after this many iterations is
                                    * re-factored with rho' = rho sqrt((r_prim/n_prim)/(r_dual/n_dual)) (clipped to [rho/10, 5 rho]) and
                                    * continues from its own (x, y) until max_iter iterations in total; iters[] counts every pass.
-                                   * < 0 or >= max_iter = off; 0 (default) = automatic: 55 at N <= 10, 100 at N = 12 / 16, 125 beyond --
+                                   * < 0 or >= max_iter = off; 0 (default) = automatic, by horizon: 55 (N <= 10), 70 (12), 80 (16), 125 (20), 100 (24) --
                                    * the same rule for every kernel and batch size (a QP ends with the same status alone in a staged
                                    * call and inside a batch of 65,536).  How a pass runs: in place inside the one-wave kernel (or handed
                                    * to the next solve on the stream, SRBDQP_FLAG_DEFER_TAIL); one more launch over the same grid per
                                    * pass everywhere else (only the workgroups of the QPs the pass before left at its cap do anything);
                                    * the staged batch-1 call launches a further pass only when a status[] asks for it. */
     int32_t rho_restart_count;    /* at most this many re-balancings, one every rho_restart_iter iterations, each from the rho of the
-                                   * pass before it.  0 (default) = automatic: 2 with the automatic rho_restart_iter at N <= 10, else 1 */
+                                   * pass before it.  0 (default) = automatic: with the automatic rho_restart_iter 2 (N <= 12), 3 (N = 16),
+                                   * 1 (N = 20), 2 (N = 24); with an explicit rho_restart_iter 1 */
     double dt;                    /* run_simulation.py:169 */
     double mass;                  /* wbid.py:291 model.getMass() */
     double inertia[3];            /* wbid.py:261-266 torso inertia diagonal */

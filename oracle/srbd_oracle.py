@@ -373,12 +373,13 @@ def auto_rho_fz_scale(N: int) -> float:
 
 
 def default_restart(N: int, one_wave: bool = False):
-    """(rho_restart_iter, rho_restart_count) the engine picks by default (srbdqp.hip restart_iter_of): N > 10: one re-balancing after 100 (125 above N = 16)
-    iterations; N <= 10: two, 55 iterations apart.  The same for every kernel and batch size since round 4 (one_wave is ignored: round 3 applied the N <= 10
-    rule only where the one-wave kernel ran a call of 4096 QPs or more)."""
-    if N > 10:
-        return (100 if N <= 16 else 125), 1
-    return 55, 2
+    """(rho_restart_iter, rho_restart_count) the engine picks by default (srbdqp.hip restart_iter_of), by horizon: N <= 10: 55 x 2, N = 12: 70 x 2, N = 16: 80 x 3,
+    N = 20: 125 x 1, N = 24: 100 x 2 (each re-balancing from the rho of the pass before it; the cap max_iter is on the total).  The same for every kernel and batch
+    size since round 4 (one_wave is ignored: round 3 applied the N <= 10 rule only where the one-wave kernel ran a call of 4096 QPs or more, and one re-balancing
+    after 100 / 125 iterations at N > 10)."""
+    if N <= 10:
+        return 55, 2
+    return {12: (70, 2), 16: (80, 3), 24: (100, 2)}.get(N, (125, 1))
 
 
 def default_params(N: int, **kw) -> "SrbdParams":

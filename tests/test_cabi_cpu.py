@@ -39,7 +39,7 @@ def test_config_struct_and_defaults_match_the_oracle(built_lib):
     p = orc.SrbdParams()
     assert cfg.horizon == 10 and cfg.max_iter == p.max_iter and cfg.check_every == p.check_every and cfg.rho_restart_iter == p.rho_restart_iter
     assert cfg.rho_restart_count == 0 and orc.default_restart(10) == (55, 2) and orc.default_restart(4) == (55, 2)   # 0 = automatic (srbdqp.h): one rule for every kernel and batch size
-    assert orc.default_restart(12) == (100, 1) and orc.default_restart(20) == (125, 1)
+    assert orc.default_restart(12) == (70, 2) and orc.default_restart(16) == (80, 3) and orc.default_restart(20) == (125, 1) and orc.default_restart(24) == (100, 2)
     for k in ("dt", "mass", "mu", "fz_min", "fz_max", "r_diag", "force_scale", "rho_eq_scale", "sigma", "alpha", "eps_abs", "eps_rel"):
         assert getattr(cfg, k) == getattr(p, k), k
     assert cfg.rho == 0.0 and orc.auto_rho(cfg.horizon) == p.rho          # 0 = chosen from the horizon (oracle auto_rho)

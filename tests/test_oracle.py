@@ -227,7 +227,7 @@ def test_split_oracle_runs_the_same_restart_passes_as_the_dense_one():
     """Round 4: one restart rule for every kernel, so the general kernel's twin (update_split) runs up to rho_restart_count re-balancings too, each from the rho
     of the pass before it.  In float64 its iterates are the dense path's: same statuses, same iteration counts, same forces, with the marks early enough that
     most of these QPs pass one or two of them; and default_params() is what the engine resolves rho_restart_iter = 0 to."""
-    assert orc.default_restart(10) == (55, 2) and orc.default_restart(8) == (55, 2) and orc.default_restart(16) == (100, 1) and orc.default_restart(24) == (125, 1)
+    assert orc.default_restart(10) == (55, 2) and orc.default_restart(8) == (55, 2) and orc.default_restart(16) == (80, 3) and orc.default_restart(24) == (100, 2) and orc.default_restart(20) == (125, 1)
     p0 = orc.default_params(10)
     assert (p0.rho_restart_iter, p0.rho_restart_count, p0.rho, p0.rho_fz_scale) == (55, 2, orc.auto_rho(10), orc.auto_rho_fz_scale(10))
     N = 10
