@@ -1264,6 +1264,10 @@ int solve_host_impl(srbdqp_handle* h, int32_t B, size_t esz, const void* x0, con
     h->sched_hint = hint_keep;
     h->maxs_override = 0;
     if (rc != SRBDQP_OK) return rc;
+    if (h->cfg.flags & SRBDQP_FLAG_DEFER_TAIL) {            // a host-buffer call returns finished results: whatever was deferred runs now
+        rc = srbdqp_flush(h, st);
+        if (rc != SRBDQP_OK) return rc;
+    }
     HIP_TRY(h, hipMemcpyAsync(u_out, du, b * n * esz, hipMemcpyDeviceToHost, st));
     if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, dx, b * (N + 1) * 13 * esz, hipMemcpyDeviceToHost, st));
     if (y_out) HIP_TRY(h, hipMemcpyAsync(y_out, dy, b * m * esz, hipMemcpyDeviceToHost, st));

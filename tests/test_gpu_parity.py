@@ -1148,3 +1148,21 @@ def test_ragged_restart_passes_on_the_tail_streams(torch_first, built_lib):
     assert sum(int((o["it"] > 40).sum()) for o in ref) >= 20
     for k, (o, r) in enumerate(zip(got, ref)):
         assert torch.equal(o["st"], r["st"]) and torch.equal(o["it"], r["it"]) and torch.equal(o["u"], r["u"]) and torch.equal(o["x"], r["x"]), k
+
+
+@pytest.mark.parametrize("schedule,B,mcs", [("single", 1024, 2), ("mixed", 1024, 4), ("single", 64, 2)])
+def test_host_buffer_calls_flush_deferred_work_themselves(torch_first, built_lib, schedule, B, mcs):
+    """An engine created with SRBDQP_FLAG_DEFER_TAIL and used through the HOST-buffer call: the call returns finished results (it flushes before it copies back)."""
+    from g1_locomotion_amd import BatchMPC, _lib
+    N = 10
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=3100, schedule=schedule)
+    kw = dict(rho_restart_iter=25, rho_restart_count=3, max_contacts_per_step=mcs)
+    with BatchMPC(horizon=N, **kw) as eng:
+        ref = eng.solve(x0, xr, ft, ct, want_y=True)
+    with BatchMPC(horizon=N, flags=_lib.FLAG_DEFER_TAIL, **kw) as eng:
+        got = eng.solve(x0, xr, ft, ct, want_y=True)
+        again = eng.solve(x0, xr, ft, ct, want_y=True)             # (the lists are empty again: the second call equals the first)
+    assert (ref["iters"] > 25).sum() >= 8 and (ref["status"] != _lib.PENDING).all()
+    for o in (got, again):
+        np.testing.assert_array_equal(o["status"], ref["status"]); np.testing.assert_array_equal(o["iters"], ref["iters"])
+        assert np.abs(o["u"] - ref["u"]).max() <= 1e-9 and np.abs(o["x"] - ref["x"]).max() <= 1e-11 and np.abs(o["y"] - ref["y"]).max() <= 1e-9
