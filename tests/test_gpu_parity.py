@@ -952,7 +952,7 @@ def test_deferred_tails_equal_the_restart_in_place(torch_first, built_lib, N, ev
     kw = dict(max_contacts_per_step=2 if schedule == "single" else 4, kernel=_lib.KERNEL_WAVE)
     if every:
         kw.update(rho_restart_iter=every, rho_restart_count=count)
-    sizes = [B, B, B // 2, B, B]
+    sizes = [B // 2, B, B // 2, B, B]               # (the second solve outgrows the lists the first one allocated: flushed, re-allocated, carried on)
     batches = [orc.synthetic_batch(sizes[j], N, seed=1000 + 7 * j, schedule=schedule) for j in range(len(sizes))]
     d_in = [[torch.from_numpy(v).to(dev) for v in hb] for hb in batches]
 
@@ -963,8 +963,8 @@ def test_deferred_tails_equal_the_restart_in_place(torch_first, built_lib, N, ev
     def run(eng, outs, streams, hint):
         for j, (d, o) in enumerate(zip(d_in, outs)):
             s = streams[j % len(streams)]
-            if hint and j > 0 and sizes[j] == sizes[0]:
-                eng.set_schedule_hint(ref_outs[0]["it"].data_ptr(), sizes[0])
+            if hint and j > 1 and sizes[j] == sizes[1]:
+                eng.set_schedule_hint(ref_outs[1]["it"].data_ptr(), sizes[1])
             else:
                 eng.set_schedule_hint(0, 0)
             eng.solve_device(sizes[j], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), o["u"].data_ptr(), x_out=o["x"].data_ptr(),
