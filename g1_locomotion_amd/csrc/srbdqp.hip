@@ -347,9 +347,12 @@ int launch_wave_defer(srbdqp_handle* h, KArgs a, hipStream_t st, srbdqp_handle::
         if (T > (long long)slot->tail_cap) T = (long long)slot->tail_cap;
     }
     a.tail_wgs = (int32_t)T;
+    const bool timing = (h->cfg.flags & SRBDQP_FLAG_TIMING) != 0;          // (srbdqp_last_kernel_ms: this launch, continuations of earlier solves included)
+    if (timing) { HIP_TRY(h, hipEventRecord(h->ev0, st)); h->ev_mid_valid = false; }
     if (a.B > 0) hipLaunchKernelGGL((srbdqp::srbdqp_wave_defer_kernel<N, MAXS, false>), dim3((unsigned)(T + a.B)), dim3(64), lds1, st, a);
     else hipLaunchKernelGGL((srbdqp::srbdqp_wave_defer_kernel<N, MAXS, true>), dim3((unsigned)T), dim3(64), lds1, st, a);
     HIP_TRY(h, hipGetLastError());
+    if (timing) { HIP_TRY(h, hipEventRecord(h->ev1, st)); h->ev_valid = true; }
     slot->tail_live = true;
     return SRBDQP_OK;
 }
