@@ -180,15 +180,17 @@ int set_lds_once(srbdqp_handle* h, K kernel, size_t lds) {
 }
 
 // Batches of at least this many QPs of the small instantiations (<= 64 presolved variables) run with one wave per QP
-// (launch_wave); smaller ones, the staged path and the big instantiations use the 4-wave kernel.  Measured cross-over of
-// the per-call time (tools/threshold_probe.py): 512.
-constexpr int kSplitMinBatch = 512;
+// (launch_wave); the staged (completion-word) path and the big instantiations use the 4-wave kernel.  Until round 4 the cross-over of the per-call time was 512
+// QPs; with the rho restart on at every batch size (in place on the one-wave kernel, one more launch per pass on the 4-wave one) the one-wave kernel is the
+// faster one at EVERY size (tools/threshold_probe.py, us per synchronised call, 4-wave / one-wave: B = 1 60 / 55, 32 67 / 61, 128 72 / 64, 256 163 / 149,
+// 512 238 / 192, 4096 483 / 289).
+constexpr int kSplitMinBatch = 1;
 
 // Batches of at least this many QPs with more than 2 stance contacts in a step go to the general kernel at N <= 10 too
 // (measured, tools/schedule_bench.py, 4096 QPs: N = 10 double support 13.5 M QP/s against 4.2 M on the 4-wave compact kernel,
 // mixed gait 13.9 M against 6.5 M); smaller ones stay on the 4-wave kernel (lowest latency).
-constexpr int kWrenchMinBatch = 768;      // re-measured at the end of round 2 (mixed gait, N = 10): 512 QPs 4.43 M QP/s compact / 4.17 M general,
-                                          // 1024 QPs 6.12 M / 7.57 M -- up to two QPs per CU the 4-wave kernel's shorter set-up wins
+constexpr int kWrenchMinBatch = 512;      // re-measured in round 4 (uniform rho restart; tools/schedule_bench.py, M QP/s 4-wave / general): N = 10 mixed gait 256 QPs 1.72 / 1.63,
+                                          // 512 3.10 / 3.28, 768 3.98 / 4.67, 1024 4.63 / 6.06; double support 256 1.70 / 2.45, 512 2.61 / 4.28 (round 2: 768)
 constexpr int kRestartMinBatch = 4096;         // the one-wave kernel's automatic rho restart in place: batches that fill the chip twice over (restart_iter_of)
 constexpr int kTail1MaxBatch = 8;              // staged calls of up to this many QPs on <= 2 stance contacts per step: the 4-wave set-up + one-wave iteration kernel
 constexpr int kStagedWrenchMinVars = 60;   // staged call: presolved variables (3 per stance contact) above which the wrench-space kernel's low-latency

@@ -73,11 +73,13 @@ extern "C" {
 #define SRBDQP_KERNEL_SPLIT 4     /* two kernels, one wave per QP each: set-up, then ADMM + roll-out, K^-1 handed over through
                                      HBM (<= 64 presolved variables, otherwise falls back to COMPACT); kept for A/B */
 #define SRBDQP_KERNEL_WAVE 5      /* the whole solve on one wave per QP, K tiles register-resident, no barrier, no hand-over;
-                                     AUTO picks it for batches >= 512 of the instantiations with <= 64 presolved variables */
+                                     AUTO picks it for the instantiations with <= 64 presolved variables (N <= 10 with at most 2 stance
+                                     contacts per step, N = 4) at every batch size; the staged batch-1 call runs the 4-wave kernel's
+                                     low-latency form */
 #define SRBDQP_KERNEL_WRENCH 6    /* the general kernel: any contact pattern at every horizon (4 ... 24), wrench-space presolve
                                      (a step with >= 3 stance contacts contributes 6 coordinates instead of 3 per contact),
-                                     fp64 or fp32 iterations; AUTO picks it for > 2 stance contacts per step at N > 10, for
-                                     N = 24 and for every _f32 call */
+                                     fp64 or fp32 iterations; AUTO picks it for > 2 stance contacts per step at N > 10 and -- batches of
+                                     512 QPs and more, and the staged batch-1 call -- at N <= 10, for N = 24 and for every _f32 call */
 
 /* Everything `MPC.__init__(dt)` / `MPC.init_matrices()` hold (run_simulation.py:169-170).  Values the
  * reference keeps inside the absent module are this build's documented choices. */

@@ -71,7 +71,9 @@ def test_solve_matches_oracle_and_exact_optimum(torch_first, built_lib, kernel, 
         out = eng.solve(x0, xr, ft, ct, want_y=True)
         # wave = the whole solve on one wave per QP, split = the same as two kernels with a hand-over through HBM; both
         # exist for <= 64 presolved variables, else fall back to compact
-        assert eng.kernel_name().startswith({"auto": ("compact_",), "split": ("split_", "compact_"), "wave": ("wave_", "compact_")}[kernel]), eng.kernel_name()
+        assert eng.kernel_name().startswith({"auto": ("compact_", "wave_"), "split": ("split_", "compact_"), "wave": ("wave_", "compact_")}[kernel]), eng.kernel_name()
+        if kernel == "auto":     # (round 4: AUTO runs <= 64 presolved variables on the one-wave kernel at every batch size, the rest of these small batches on the 4-wave one)
+            assert eng.kernel_name().startswith("wave_" if (schedule == "single" or N == 4) else "compact_"), eng.kernel_name()
         if kernel in ("split", "wave") and (schedule == "single" or N == 4):     # <= 64 presolved variables
             assert eng.kernel_name().startswith(kernel + "_")
     p = orc.SrbdParams(eliminate_swing=presolved)
@@ -817,7 +819,7 @@ def test_committed_golden_fixtures_gate_the_kernels(torch_first, built_lib, name
     else:
         if path == "wave" and not (name.startswith("n10_single") or N == 4):
             pytest.skip("the one-wave kernel holds at most 64 presolved variables")
-        kid = {"batch": _lib.KERNEL_AUTO, "wave": _lib.KERNEL_WAVE, "wrench": _lib.KERNEL_WRENCH}[path]
+        kid = {"batch": _lib.KERNEL_COMPACT, "wave": _lib.KERNEL_WAVE, "wrench": _lib.KERNEL_WRENCH}[path]
         with _engine(N, kernel=kid) as eng:
             out = eng.solve(x0[None], xr[None], ft[None], ct[None], want_y=True)
             assert eng.kernel_name().startswith({"batch": "compact_", "wave": "wave_", "wrench": "wrench_"}[path]), eng.kernel_name()
@@ -909,7 +911,7 @@ def test_staged_call_after_an_in_place_restart_does_not_replay_a_stale_second_pa
         assert first[1].max() <= p.max_iter
         assert np.abs(first[0] - ref["u"][hard]).max() <= 5e-3
     # the same through a handle that HAS a stale lazy first pass behind it (4-wave kernel, two-pass restart), then the wave kernel
-    with BatchMPC(horizon=N, flags=_lib.FLAG_NO_SPIN, rho_restart_iter=60, rho_restart_count=1) as eng:
+    with BatchMPC(horizon=N, kernel=_lib.KERNEL_COMPACT, flags=_lib.FLAG_NO_SPIN, rho_restart_iter=60, rho_restart_count=1) as eng:
         st = eng.stage()
         cap = st["capacity"]
         hard = np.argsort(-ref["iters"])[:cap]
