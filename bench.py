@@ -453,8 +453,8 @@ def main(argv=None):
         SOLVED = _lib.SOLVED
     # deferred tails (round 4): configs[1] on one GPU, on the one-wave kernel with its automatic rho restart.  Not with several ranks: the all-gather of
     # u_opt0 behind every step needs that step's forces complete, and at 65,536 QPs per launch the tail is a tenth of the launch anyway.
-    defer = (cid == 1 and world == 1 and not stub and not args.in_place and args.kernel in ("auto", "wave") and B >= 4096
-             and args.rho_restart >= 0 and not args.same_batch)
+    defer = (cid in (1, 2) and world == 1 and not stub and not args.in_place and args.rho_restart >= 0 and not args.same_batch
+             and (cid == 2 or (args.kernel in ("auto", "wave") and B >= 4096)))      # (configs[2]: the general kernel's restart pass on the library's tail stream)
     if cid == 4:
         leg = RaggedLeg(B, args, rank, local_rank, dev, torch, nb)
         S = 1
@@ -462,7 +462,7 @@ def main(argv=None):
         leg = Leg(cid, B, args, rank, local_rank, dev, torch, nb, stub=stub, max_streams=S, defer=defer)
     N, f32 = leg.N, leg.f32
     NO = leg.NO
-    hint = "none" if (args.no_sched_hint or cid == 4 or defer) else "own"
+    hint = "none" if (args.no_sched_hint or cid == 4 or (defer and cid == 1)) else "own"      # (deferred tails on the one-wave kernel: nothing left for a hint to do)
     d_u0_all = [torch.empty((world * B, 12), dtype=torch.float32 if f32 else torch.float64, device=dev) for _ in range(NO)] if (world > 1 and cid != 4) else None
 
     def u0_of(o):
@@ -538,7 +538,7 @@ def main(argv=None):
         el_stale = timed(lg, base, steps, False, S, "stale")
         return B * steps / el_plain, B * steps / el_stale
 
-    if world == 1 and not stub and cid in (1, 3) and not args.no_also and (hint == "own" or defer):
+    if world == 1 and not stub and cid in (1, 3) and not args.no_also and (hint == "own" or defer):     # (configs[1] / the configs[3] shard on one GPU)
         extra["value_plain"], extra["value_stale_hint"] = variants(leg)
         if defer:
             extra["value_variants_note"] = ("value: %d streams, natural QP order, tails deferred to the next solve on the stream (SRBDQP_FLAG_DEFER_TAIL), flushed inside "

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <atomic>
@@ -61,11 +62,11 @@ struct srbdqp_handle {
         unsigned long long rs_k = 0;
         hipStream_t tail_st = nullptr; hipEvent_t ev_main = nullptr;
         hipEvent_t last_tail = nullptr;    // closes the restart passes of the last deferred solve on this stream (srbdqp_flush waits for it), or null
-        // deferred tails (SRBDQP_FLAG_DEFER_TAIL): three rotating lists of continuation records, their counts, and a GPU-mapped host word through
-        // which every launch reports how many records it found (launch_wave_defer sizes the next launches' tail workgroups from it)
+        // deferred tails (SRBDQP_FLAG_DEFER_TAIL): three rotating lists of continuation records and their counts
         char* tail = nullptr; int32_t* tail_cnt = nullptr; size_t tail_cap = 0;
-        int32_t* tail_seen_h = nullptr; int32_t* tail_seen_d = nullptr;
         unsigned long long tail_k = 0;     // launches so far: list k % 3 is appended to, (k + 2) % 3 read, (k + 1) % 3 zeroed
+        static constexpr int kTailHist = 8;
+        long long tail_hist[kTailHist] = {0, 0, 0, 0, 0, 0, 0, 0};   // batch sizes of the last launches on this stream, newest first (bounds the records a launch can find)
         bool tail_live = false;            // records may be pending (a solve since the last flush)
     };
     static constexpr int kMaxSlots = 8;
@@ -338,16 +339,23 @@ int launch_wave_defer(srbdqp_handle* h, KArgs a, hipStream_t st, srbdqp_handle::
     static const std::string nm = "wave_defer_f64_n" + std::to_string(N) + "_s" + std::to_string(MAXS);
     h->kname = nm.c_str();
     const unsigned long long k = slot->tail_k++;
-    a.tail_lists = slot->tail; a.tail_cnt = slot->tail_cnt; a.tail_seen = slot->tail_seen_d; a.tail_cap = (int32_t)slot->tail_cap;
+    a.tail_lists = slot->tail; a.tail_cnt = slot->tail_cnt; a.tail_cap = (int32_t)slot->tail_cap;
     a.tail_iout = (int32_t)(k % 3); a.tail_iin = (int32_t)((k + 2) % 3); a.tail_izero = (int32_t)((k + 1) % 3);
-    long long T = (long long)slot->tail_cap;
-    if (a.B > 0) {   // twice what the last launch that reported found (stale by a launch or two: a record beyond tail_wgs just moves on to the next launch)
-        const long long seen = *reinterpret_cast<volatile int32_t*>(slot->tail_seen_h);
-        T = 2 * seen + 64;
-        const long long lo = a.B / 16 > 64 ? a.B / 16 : 64;
-        if (T < lo) T = lo;
-        if (T > (long long)slot->tail_cap) T = (long long)slot->tail_cap;
-    }
+    // tail workgroups: one per record the list this launch reads CAN hold -- a bound the host knows without asking the device: a record was written by the launch
+    // before this one on the stream, as a first pass that reached its mark (at most that launch's QPs) or as a continuation that reached another (at most the QPs
+    // of the launches before it that may still re-balance): the sum of the last rho_restart_count batch sizes.  Workgroups without a record leave after one
+    // scalar load; 8192 of them in front of a 4096-QP launch cost 0.7 % (16,384: 1.5 %, tools/defer_bench.py with SRBDQP_TAIL_WGS_MIN).  A first version sized
+    // this from the record count the device reported through a host-mapped word and moved surplus records on to the next list: the report is stale by however
+    // far the host runs ahead of the device, and with 95 % of every batch continuing and the host 300 launches ahead the lists overflowed (tools/defer_fuzz.py).
+    long long T = 0;
+    const int rmax = a.restart_max > 0 ? a.restart_max : 1;
+    for (int j = 0; j < rmax && j < srbdqp_handle::StreamSlot::kTailHist; ++j) T += slot->tail_hist[j];
+    if (T < 64) T = 64;
+    if (const char* e = getenv("SRBDQP_TAIL_WGS_MIN")) { const long long m = atoll(e); if (a.B > 0 && T < m) T = m; }   // (experiments: the cost of empty tail workgroups)
+    if (T > (long long)slot->tail_cap) T = (long long)slot->tail_cap;
+    for (int j = srbdqp_handle::StreamSlot::kTailHist - 1; j > 0; --j) slot->tail_hist[j] = slot->tail_hist[j - 1];
+    slot->tail_hist[0] = a.B;
+    if (a.B == 0) for (auto& v : slot->tail_hist) v = 0;      // (a flush launch finishes every record in place: the lists are empty behind it)
     a.tail_wgs = (int32_t)T;
     const bool timing = (h->cfg.flags & SRBDQP_FLAG_TIMING) != 0;          // (srbdqp_last_kernel_ms: this launch, continuations of earlier solves included)
     if (timing) { HIP_TRY(h, hipEventRecord(h->ev0, st)); h->ev_mid_valid = false; }
@@ -675,15 +683,13 @@ int ensure_tail_lists(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStre
     }
     if (!slot->tail_cnt) {
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&slot->tail_cnt), 64));
-        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&slot->tail_seen_h), 64, hipHostMallocMapped | hipHostMallocCoherent));
-        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&slot->tail_seen_d), slot->tail_seen_h, 0));
-        *slot->tail_seen_h = 0;
     }
     const size_t cap = want + want / 4;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&slot->tail), 3 * cap * srbdqp::kTailRecDoubles * sizeof(double));
     if (e != hipSuccess) { h->err = std::string("hipMalloc tail lists: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
     slot->tail_cap = cap;
     slot->tail_k = 0;
+    for (auto& v : slot->tail_hist) v = 0;
     HIP_TRY(h, hipMemsetAsync(slot->tail_cnt, 0, 64, st));
     return SRBDQP_OK;
 }
@@ -845,7 +851,7 @@ int srbdqp_destroy(srbdqp_handle* h) {
     if (h->ws) (void)hipFree(h->ws);
     for (auto& sl : h->slots) {
         if (sl.perm) (void)hipFree(sl.perm); if (sl.ws) (void)hipFree(sl.ws); if (sl.rs) (void)hipFree(sl.rs);
-        if (sl.tail) (void)hipFree(sl.tail); if (sl.tail_cnt) (void)hipFree(sl.tail_cnt); if (sl.tail_seen_h) (void)hipHostFree(sl.tail_seen_h);
+        if (sl.tail) (void)hipFree(sl.tail); if (sl.tail_cnt) (void)hipFree(sl.tail_cnt);
         if (sl.tail_st) { (void)hipStreamSynchronize(sl.tail_st); (void)hipStreamDestroy(sl.tail_st); }
         if (sl.ev_main) (void)hipEventDestroy(sl.ev_main);
         for (auto& r : sl.rsets) if (r.ev_tail) (void)hipEventDestroy(r.ev_tail);
@@ -1182,7 +1188,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
     int rcount = 1;
     const int restart = (h->stamps || B < 1) ? 0 : restart_iter_of(h, maxs, B, wave, &rcount);
     if (restart && wave) { a.restart_every = restart; a.restart_max = rcount; }   // the one-wave kernel restarts in place
-    if (restart && wave && (h->cfg.flags & SRBDQP_FLAG_DEFER_TAIL) && !a.stamps && !a.done_flag && !h->io_f32) {
+    if (restart && wave && (h->cfg.flags & SRBDQP_FLAG_DEFER_TAIL) && !a.stamps && !a.done_flag && !h->io_f32 && rcount <= srbdqp_handle::StreamSlot::kTailHist) {
         // ... or not at all: continuations deferred to the next launch on this stream (srbdqp_flush() completes them)
         auto* slot = stream_slot(h, lst);
         if (!slot) return SRBDQP_E_INVALID;

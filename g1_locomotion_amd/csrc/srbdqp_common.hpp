@@ -67,7 +67,6 @@ struct KArgs {
     // from list tail_iin, appends to list tail_iout and zeroes the count of list tail_izero (the one the next launch appends to).
     char* tail_lists;        // [3][tail_cap] records of kTailRecDoubles doubles, or null (no deferral)
     int32_t* tail_cnt;       // [3] record counts
-    int32_t* tail_seen;      // GPU-mapped host word: the number of records this launch found (the host sizes tail_wgs of later launches from it)
     int32_t tail_cap, tail_wgs, tail_iin, tail_iout, tail_izero;
     int32_t* done_flag;      // low-latency completion: GPU-mapped host word that receives done_value once every QP of the
     int32_t* done_count;     //   launch has stored its outputs (done_count: device counter of finished workgroups), or null

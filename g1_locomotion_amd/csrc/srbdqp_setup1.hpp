@@ -678,19 +678,9 @@ __global__ __launch_bounds__(64, 2) void srbdqp_wave_defer_kernel(KArgs a) {
         const int i = blockIdx.x;
         int cnt = a.tail_cnt[a.tail_iin];
         cnt = cnt < a.tail_cap ? cnt : a.tail_cap;
-        if (i == 0 && lane == 0) {
-            a.tail_cnt[a.tail_izero] = 0;                                                  // the list the NEXT launch appends to
-            __hip_atomic_store(a.tail_seen, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host sizes later launches' tail_wgs from this
-        }
+        if (i == 0 && lane == 0) a.tail_cnt[a.tail_izero] = 0;                             // the list the NEXT launch appends to
+        // (cnt <= T: the host launches one tail workgroup per record the list can hold -- a bound it knows, srbdqp.hip launch_wave_defer)
         const double* lin = reinterpret_cast<const double*>(a.tail_lists) + (size_t)a.tail_iin * (size_t)a.tail_cap * kTailRecDoubles;
-        for (int r = i + T; r < cnt; r += T) {   // more records than tail workgroups (the host's estimate was low): they move on to the next launch unchanged
-            double* dst = tail_claim(a);
-            const double* src = lin + (size_t)r * kTailRecDoubles;
-            if (dst) {
-                dst[lane] = src[lane]; dst[64 + lane] = src[64 + lane]; dst[128 + lane] = src[128 + lane];
-                if (lane < kTailRecDoubles - 192) dst[192 + lane] = src[192 + lane];
-            }
-        }
         if (i >= cnt) return;
         const double* rec = lin + (size_t)i * kTailRecDoubles;
         const TailRecHead* hd = reinterpret_cast<const TailRecHead*>(rec);

@@ -8,6 +8,8 @@ Tolerances (fp64 path), stated once:
   * forces vs the independent exact QP optimum:  <= 5e-2 N  (2.5e-4 of a nominal 200 N stance force; ADMM stops
                                                  at eps_abs = eps_rel = 1e-6 in the scaled variables)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1168,3 +1170,15 @@ def test_host_buffer_calls_flush_deferred_work_themselves(torch_first, built_lib
     for o in (got, again):
         np.testing.assert_array_equal(o["status"], ref["status"]); np.testing.assert_array_equal(o["iters"], ref["iters"])
         assert np.abs(o["u"] - ref["u"]).max() <= 1e-9 and np.abs(o["x"] - ref["x"]).max() <= 1e-11 and np.abs(o["y"] - ref["y"]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 3])
+def test_deferred_tails_survive_a_host_far_ahead_of_the_device(seed):
+    """tools/defer_fuzz.py: 150 solves of random size on random streams with random hints and flushes, restart marks low enough that most of every batch
+    continues (seeds 1 and 3 draw restart 20 x 1: ~95 % continue) and no synchronisation in between, so the host is a hundred launches ahead of the device.
+    Every status, iteration count and force must equal the restart in place (a first version of the tail-workgroup sizing lost records here)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "defer_fuzz.py"), "150", str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatching solves" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
