@@ -197,6 +197,64 @@ __device__ __forceinline__ void mt_tables(const double* CP, const double* T1, co
     }
 }
 
+// ---- rank-6 form of the closed-form Hessian (round 4) ---------------------------------------------------------------------------------------------------------
+// M(j, m) above is D_m - C_j' E_m with  D_m = dt^4 (T2(m) + C_m' W T1(m)) + (N - m) dt^2 W_w,  E_m = dt^4 W T1(m)  -- one 3 x 3 pair per STEP instead of one
+// matrix per step PAIR -- so the torque part of the entry of variables r (contact e1 of step j, axis x) and c (contact e2 of step m >= j, axis y),
+//     [J_e1' M(j, m) J_e2]_xy = J_e1[:, x] . (D_m J_e2)[:, y] - (C_j J_e1)[:, x] . (E_m J_e2)[:, y],
+// is the dot product of a 6-vector of r with a 6-vector of c, and the force part (x == y): fa_x (alpha_m + (m - j) beta_m) + fb_x (N - m) = f0_c - j f1_c.  One table
+// row per presolved variable (kasm_rows: [a(6), g, -g j | s^2 b(6), f0, f1], g = 0 on padding rows), and every lane forms its own C-layout entries from the row of
+// its r and the row of its c: 6 + 3 multiply-adds per entry, the rows of a lane's four columns read once, no staging tile, no scatter.  The contact-pair blocks
+// through a staging tile (27 LDS reads and 54 multiply-adds per 3 x 3 block, tile by tile with 36 of 64 lanes busy, nine address selects and stores per block)
+// were 11 % of the one-wave kernel's time on configs[1] (tools/fixed_iter_rate.py with the block computation stubbed out), the M table another 2 %.
+// Valid for step(r) <= step(c): the upper triangle; the entries of a diagonal tile below the diagonal are never read (diag16_invert reads the upper triangle).
+constexpr int kAbStride = 18;   // doubles per table row (16 + 2: rows 144 bytes apart, 16-byte aligned)
+template <int N>
+__device__ __forceinline__ void de_tables(const double* CP, const double* T1, const double* T2, const double* SQ, const double dt2, double* DE, const int t, const int nthreads) {
+    for (int it = t; it < 9 * N; it += nthreads) {
+        const int m = it / 9, k = it - 9 * m, p = k / 3, q = k - 3 * p;
+        const double* Cm = CP + 9 * m;
+        const double* t1 = T1 + 9 * m;
+        const double d4 = dt2 * dt2;
+        const double e0 = SQ[0] * SQ[0] * t1[q], e1 = SQ[1] * SQ[1] * t1[3 + q], e2 = SQ[2] * SQ[2] * t1[6 + q];
+        double v = T2[9 * m + k] + Cm[p] * e0 + Cm[3 + p] * e1 + Cm[6 + p] * e2;
+        v *= d4;
+        v += (p == q) ? (double)(N - m) * dt2 * SQ[6 + p] * SQ[6 + p] : 0.0;
+        DE[18 * m + k] = v;                                                  // D_m[p][q]
+        DE[18 * m + 9 + k] = d4 * ((p == 0) ? e0 : (p == 1) ? e1 : e2);      // E_m[p][q]
+    }
+}
+// Jb: the strip's J (36 doubles per step); act: the stance contacts in presolved order (step * 4 + contact); rows >= n_eff are zero
+template <int N>
+__device__ __forceinline__ void kasm_rows(const double* Jb, const double* CP, const double* DE, const double* SQ, const uint8_t* act, const int n_eff, const double s,
+                                          const double dt2m, const double dtm, double* AB, const int t, const int nthreads, const int nrows) {
+    const double s2 = s * s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
+    for (int r = t; r < nrows; r += nthreads) {
+        const bool on = r < n_eff;
+        const int rr = on ? r : 0;
+        const int e = rr / 3, x = rr - 3 * e, gc = act[e], j = gc >> 2;
+        const double* Jp = Jb + j * 36 + 3 * (gc & 3) + x;
+        const double J0 = Jp[0], J1 = Jp[12], J2 = Jp[24];
+        const double* C = CP + 9 * j;
+        const double* D = DE + 18 * j;
+        double v[16];
+        v[0] = J0; v[1] = J1; v[2] = J2;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) v[3 + l] = -(C[3 * l] * J0 + C[3 * l + 1] * J1 + C[3 * l + 2] * J2);
+        v[6] = 1.0; v[7] = -(double)j;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) v[8 + l] = s2 * (D[3 * l] * J0 + D[3 * l + 1] * J1 + D[3 * l + 2] * J2);      // D_m J (3), E_m J (3)
+        const int Ls = N - j;
+        const double al = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6), be = (double)(((Ls - 1) * Ls) / 2);
+        const double fa = SQ[3 + x] * SQ[3 + x] * dt4m2, fb = SQ[9 + x] * SQ[9 + x] * dt2m2;
+        v[14] = s2 * (fa * (al + (double)j * be) + fb * (double)Ls);
+        v[15] = s2 * fa * be;
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2* row = reinterpret_cast<d2*>(AB + kAbStride * r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[i] = on ? (d2){v[2 * i], v[2 * i + 1]} : (d2){0.0, 0.0};
+    }
+}
+
 // diagnostic phase stamp (thread 0 only; leaves the kernel through a buffer nothing else reads)
 #define SRBDQP_STAMP(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 

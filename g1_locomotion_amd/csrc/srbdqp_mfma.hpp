@@ -152,4 +152,76 @@ __device__ __forceinline__ v4d diag16_invert_mfma(v4d s, int lane, bool& ok) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// The same inversion without the matrix cores and without v_readlane: one COLUMN per lane.  Lane c of every 16-lane DPP row holds column c of S
+// (16 registers S_i = S[i][c]) and of R (R_i, the identity at the start).  Pivot k: d = S[k][k] is a row_newbcast of register S_k, u = S_k / sqrt(d)
+// is row k of L' (own lane: L[c][k]), W_k = R_k / sqrt(d) is row k of L^-1, and every row below takes ONE DPP multiply-add per matrix,
+//     S_i -= L[i][k] u,   R_i -= L[i][k] W_k     with L[i][k] = u in lane i = the instruction's row_newbcast:i source operand,
+// 240 v_fmac_f64_dpp + 16 x 9 instructions of pivot chain (the next pivot's chain depends on the first multiply-add of a pivot only: the
+// scheduler runs it beside the rest).  The blocked routine above is as many instructions but spends half its time waiting on dependent MFMAs and
+// on v_readlane hazards: 3285 cycles a tile alone on its SIMD (tools/diag_probe.hip).  In and out through a 16 x 16 LDS tile of the caller's
+// (C layout -> columns; W back row-major, XOR-swizzled as the consumers read it); the four DPP rows work redundantly.
+// ---------------------------------------------------------------------------------------------------------
+template <int I>
+__device__ __forceinline__ void fmac_newbcast(double& acc, double nu, double m) {   // acc += nu[lane I of the row] * m
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(nu), "v"(m), "n"(I));
+}
+template <int K>
+__device__ __forceinline__ double mov_newbcast(double v) {   // (the source may come out of one of the asm statements above, which the hazard recognizer does not see into: the two wait states by hand)
+    double d;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "n"(K));
+    return d;
+}
+template <int K, int I>
+struct Diag16Rows {
+    static __device__ __forceinline__ void run(double (&S)[16], double (&R)[16], double nu, double u, double wk) {
+        if constexpr (I < 16) {
+            fmac_newbcast<I>(S[I], nu, u);
+            fmac_newbcast<I>(R[I], nu, wk);
+            Diag16Rows<K, I + 1>::run(S, R, nu, u, wk);
+        }
+    }
+};
+template <int K>
+__device__ __forceinline__ void diag16_pivot(double (&S)[16], double (&R)[16], bool& ok) {
+    const double d = mov_newbcast<K>(S[K]);
+    ok = ok && (d > 0.0);                         // (a NaN pivot fails the comparison too)
+    const double r = fast_rsqrt(d);
+    const double u = S[K] * r;
+    const double wk = R[K] * r;
+    R[K] = wk;
+    if constexpr (K < 15) {
+        double nu;
+        asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(nu) : "v"(S[K]), "v"(-r));       // -u, two wait states before its first DPP read
+        Diag16Rows<K, K + 1>::run(S, R, nu, u, wk);
+        diag16_pivot<K + 1>(S, R, ok);
+    }
+}
+// tile: 256 doubles of LDS owned by this wave; on return it holds W = L^-1 row-major with the column XOR-swizzled (tile[row * 16 + (col ^ row)]), exact zeros
+// above the diagonal; the return value is the same W in C layout.
+__device__ __forceinline__ v4d diag16_invert_dpp(v4d s, int lane, bool& ok, double* tile) {
+    const int col = lane & 15, g = lane >> 4;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(g + 4 * r) * 16 + col] = s[r];
+    asm volatile("" ::: "memory");
+    double S[16], R[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = tile[i * 16 + col]; R[i] = (i == col) ? 1.0 : 0.0; }     // (row i of the upper triangle; below the diagonal the lanes carry values nobody reads)
+    asm volatile("" ::: "memory");
+    ok = true;
+    diag16_pivot<0>(S, R, ok);
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tile[i * 16 + (col ^ i)] = R[i];
+    }
+    asm volatile("" ::: "memory");
+    v4d w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int row = g + 4 * q; w[q] = tile[row * 16 + (col ^ row)]; }
+    asm volatile("" ::: "memory");
+    return w;
+}
+
+
 }  // namespace srbdqp

@@ -38,7 +38,8 @@ struct Setup1Smem {
     static constexpr int up2(int v) { return (v + 1) & ~1; }
     static constexpr int o_x0 = S::o_x0, o_tm = S::o_tm, o_J = S::o_J;   // strip offsets used by the shared helpers
     static constexpr int o_cp = S::o_R;                    // 9N   prefix sums C_k
-    static constexpr int o_mt = o_cp + up2(9 * N);         // 9 NPAIR  M(j, m)
+    static constexpr int o_mt = o_cp + up2(9 * N);         // 18N  D_m, E_m of the rank-6 assembly (srbdqp_common.hpp, de_tables; until round 4: the 9 NPAIR doubles of M(j, m))
+    static constexpr int o_ab = o_mt + 18 * N;             // the assembly's table rows, one per presolved variable: over everything below, which is dead by then
     static constexpr int o_gv = o_mt + up2(9 * S::NPAIR);  // 9N   G'v tables
     static constexpr int o_t1 = o_gv + up2(9 * N);         // 9N   T1(m)          | later: x0c (nmax + 16), tf (6N)
     static constexpr int o_t2 = o_t1 + up2(9 * N);         // 9N   T2(m)
@@ -55,7 +56,9 @@ struct Setup1Smem {
     static constexpr int endIn2 = (endIn > o_scr + 258) ? endIn : o_scr + 258;   // the tile + the spare slot of the K assembly
     static constexpr int kStgRow = 18;                    // row stride of the K^-1 staging tiles (16 + 2: the 16-byte row reads of 16 lanes hit 64 different banks)
     static constexpr int kStgTile = 16 * kStgRow;
-    static constexpr int o_end = (endIn2 > o_cp + S::NT * kStgTile) ? endIn2 : o_cp + S::NT * kStgTile;   // K^-1 block-column staging (wave kernel)
+    static constexpr int endStg = (endIn2 > o_cp + S::NT * kStgTile) ? endIn2 : o_cp + S::NT * kStgTile;   // K^-1 block-column staging (wave kernel)
+    static constexpr int endAb = o_ab + 16 * S::NT * kAbStride;
+    static constexpr int o_end = endStg > endAb ? endStg : endAb;
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr bool supported = SplitWs<N, MAXS>::supported && S::NT <= 4;
     static_assert(n + 6 * N <= o_end - o_eh || true, "");
@@ -194,7 +197,7 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const QpIo& io, cons
     const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = dt2 * a.inv_mass;
     double* T1 = sm + L1::o_t1;
     double* T2 = sm + L1::o_t2;
-    double* MT = sm + L1::o_mt;
+    double* DE = sm + L1::o_mt;
     double* GV = sm + L1::o_gv;
     if constexpr (RP != 2) {
         for (int k = lane; k < n; k += 64) {
@@ -270,7 +273,7 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const QpIo& io, cons
         return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
     };
     if constexpr (RP != 2) gt_tables(sm + L1::o_eh);
-    mt_tables<N>(CP, T1, T2, SQ, dt2, MT, lane, 64);
+    de_tables<N>(CP, T1, T2, SQ, dt2, DE, lane, 64);
     __syncthreads();
     WSTAMP(a, b, 2);
     if constexpr (RP != 2) for (int c = lane; c < n_eff; c += 64) sm[S::o_q + c] = gt_eval(c);      // (a continued pass: q stays)
@@ -348,75 +351,49 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const QpIo& io, cons
         __syncthreads();
     }
     WSTAMP(a, b, 3);
-    // ================= K = G'G + R s^2 + sigma + A' rho A, tile by tile through the 2 KB scratch tile ====================
-    // Per upper tile (ta, tb): at most 6 x 6 contacts overlap its rows / columns; lane (i1, i2) of an 8 x 8 grid forms
-    // the 3 x 3 block of its contact pair, J_lo' M(j_lo, m_hi) J_hi (27 LDS reads for 9 entries), and drops the entries
-    // that fall into the tile into the scratch tile; every lane then picks up its 4 C-layout elements.  (Until late in
-    // round 1 every lane computed its own 40 entries, 9 LDS reads each: 2 % slower as benchmarked.)
+    // ================= K = G'G + R s^2 + sigma + A' rho A: the rank-6 form, every lane its own C-layout entries (srbdqp_common.hpp) ====================
     v4d Kt[NT][NT];
-    __syncthreads();   // the inputs / error vector under the scratch tile are dead
+    __syncthreads();   // the inputs / error vector / warm-start vectors under the table rows are dead
     {
-        const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
-        double* tile = sm + L1::o_scr;
-        const int i1 = lane >> 3, i2 = lane & 7;
-        // the per-axis factors of the force term and the diagonal shifts, once, in scalar registers (inside the tile loop they were
-        // re-read from LDS and re-multiplied for every tile: the stores into the scratch tile keep the compiler from hoisting them)
-        const double fa0 = uni(SQ[3] * SQ[3] * dt4m2), fa1 = uni(SQ[4] * SQ[4] * dt4m2), fa2 = uni(SQ[5] * SQ[5] * dt4m2);
-        const double fb0 = uni(SQ[9] * SQ[9] * dt2m2), fb1 = uni(SQ[10] * SQ[10] * dt2m2), fb2 = uni(SQ[11] * SQ[11] * dt2m2);
+        double* AB = sm + L1::o_ab;
+        kasm_rows<N>(sm + S::o_J, CP, DE, SQ, act, n_eff, a.s, dt2m, dtm, AB, lane, 64, 16 * NT);
+        __syncthreads();
+        typedef double d2 __attribute__((ext_vector_type(2)));
         const double dgxy = uni(a.rs2 + a.sigma + 2.0 * rho_b), dgz = uni(a.rs2 + a.sigma + (4.0 * a.mu * a.mu + a.rho_fz) * rho_b);
-        // the stance-contact ids of the lane's row / column contact per tile row / column, read once (inside the loop the stores into
-        // the scratch tile made every tile re-read them)
-        int gr[NT], gc[NT];
+        // same axis <=> r = c (mod 3); r = 16 ta + kq + 4 q = ta + q + kq, c = 16 tb + mcol = tb + mcol (mod 3): per lane ONE residue decides, per entry a compile-time one
+        const int d3 = (mcol - kq + 3) % 3;
+        const double ind[3] = {d3 == 0 ? 1.0 : 0.0, d3 == 1 ? 1.0 : 0.0, d3 == 2 ? 1.0 : 0.0};
+        double eqd[4];                                       // the lane's entry q of a diagonal tile is ON the diagonal
 #pragma unroll
-        for (int tq = 0; tq < NT; ++tq) {
-            const int er = (16 * tq) / 3 + i1, ec = (16 * tq) / 3 + i2;
-            gr[tq] = act[er < na ? er : 0];
-            gc[tq] = act[ec < na ? ec : 0];
+        for (int q = 0; q < 4; ++q) eqd[q] = (kq + 4 * q == mcol) ? 1.0 : 0.0;
+        double Bv[NT][8], dcol[NT];
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb) {
+            const int c = 16 * tb + mcol;
+            const d2* row = reinterpret_cast<const d2*>(AB + kAbStride * c + 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const d2 v = row[i]; Bv[tb][2 * i] = v[0]; Bv[tb][2 * i + 1] = v[1]; }
+            dcol[tb] = (c < n_eff) ? (((tb + mcol) % 3 < 2) ? dgxy : dgz) : 1.0;       // (c mod 3 = the axis; padding -> identity)
         }
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
-            for (int tb = ta; tb < NT; ++tb) {
-                const int e1 = (16 * ta) / 3 + i1, e2 = (16 * tb) / 3 + i2;
-                if (e1 < na && e2 < na && 3 * e1 <= 16 * ta + 15 && 3 * e2 <= 16 * tb + 15) {
-                    const bool fwd = (ta < tb) || e1 <= e2;         // (an off-diagonal tile has e1 <= e2 throughout: folded at compile time)
-                    const int glo = fwd ? gr[ta] : gc[tb], ghi = fwd ? gc[tb] : gr[ta], jlo = glo >> 2, mhi = ghi >> 2;
-                    const double* Jl = sm + S::o_J + jlo * 36 + 3 * (glo & 3);
-                    const double* Jh = sm + S::o_J + mhi * 36 + 3 * (ghi & 3);
-                    const double* M = MT + 9 * (mhi * (mhi + 1) / 2 + jlo);
-                    double Bm[3][3];                                   // M J_hi
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * ta + kq + 4 * q;
+                const d2* row = reinterpret_cast<const d2*>(AB + kAbStride * r);
+                double Av[8];
 #pragma unroll
-                    for (int l = 0; l < 3; ++l)
+                for (int i = 0; i < 4; ++i) { const d2 v = row[i]; Av[2 * i] = v[0]; Av[2 * i + 1] = v[1]; }
 #pragma unroll
-                        for (int c2 = 0; c2 < 3; ++c2) Bm[l][c2] = M[3 * l] * Jh[c2] + M[3 * l + 1] * Jh[12 + c2] + M[3 * l + 2] * Jh[24 + c2];
-                    const int Ls = N - mhi, d = mhi - jlo;
-                    const double sp = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2)), ls = (double)Ls;
+                for (int tb = ta; tb < NT; ++tb) {
+                    double v = Av[0] * Bv[tb][0];
 #pragma unroll
-                    for (int x = 0; x < 3; ++x) {                      // axis of the earlier contact
-                        const double j0 = Jl[x], j1 = Jl[12 + x], j2 = Jl[24 + x];
-                        const double same = ((x == 0) ? fa0 : (x == 1) ? fa1 : fa2) * sp + ((x == 0) ? fb0 : (x == 1) ? fb1 : fb2) * ls;
-#pragma unroll
-                        for (int y = 0; y < 3; ++y) {                  // axis of the later contact
-                            double v = j0 * Bm[0][y] + j1 * Bm[1][y] + j2 * Bm[2][y];
-                            if (x == y) v += same;
-                            v *= s2;
-                            if (e1 == e2 && x == y) v += (x < 2) ? dgxy : dgz;
-                            const int a1 = fwd ? x : y, a2 = fwd ? y : x;   // entry (3 e1 + a1, 3 e2 + a2)
-                            const int r = 3 * e1 + a1 - 16 * ta, c = 3 * e2 + a2 - 16 * tb;
-                            // entries outside the tile go to a spare slot behind it: an address select instead of nine
-                            // exec-mask regions per tile (cmp + saveexec + branch + restore each)
-                            tile[((unsigned)r < 16u && (unsigned)c < 16u) ? r * 16 + c : 256] = v;
-                        }
-                    }
+                    for (int i = 1; i < 6; ++i) v = fma(Av[i], Bv[tb][i], v);
+                    const double ft = fma(Av[7], Bv[tb][7], Av[6] * Bv[tb][6]);
+                    v = fma(ind[((ta + q - tb) % 3 + 3) % 3], ft, v);
+                    if (ta == tb) v = fma(eqd[q], dcol[tb], v);
+                    Kt[ta][tb][q] = v;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: its LDS operations complete in order
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = 16 * ta + kq + 4 * q, c = 16 * tb + mcol;
-                    const double v = tile[(kq + 4 * q) * 16 + mcol];
-                    Kt[ta][tb][q] = (r < n_eff && c < n_eff) ? v : ((r == c) ? 1.0 : 0.0);   // padding -> identity
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next tile is written
             }
         }
     }
@@ -430,7 +407,8 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const QpIo& io, cons
 #pragma unroll
                 for (int tb = ta; tb < NT; ++tb)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) put(16 * ta + kq + 4 * q, 16 * tb + mcol, Kt[ta][tb][q]);
+                    for (int q = 0; q < 4; ++q)
+                        if (16 * ta + kq + 4 * q <= 16 * tb + mcol) put(16 * ta + kq + 4 * q, 16 * tb + mcol, Kt[ta][tb][q]);   // (the upper triangle: put() mirrors it)
         });
         return false;
     }
