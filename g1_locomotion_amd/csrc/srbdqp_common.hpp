@@ -255,6 +255,37 @@ __device__ __forceinline__ void kasm_rows(const double* Jb, const double* CP, co
     }
 }
 
+// the four C-layout entries of upper tile (ta, tb) of lane (mcol, kq) from the table rows; ta, tb may be wave-uniform run-time values (the 4-wave kernel's tile slots)
+__device__ __forceinline__ void kasm_tile(const double* AB, const int ta, const int tb, const int mcol, const int kq, const int n_eff, const double dgxy, const double dgz,
+                                          double (&out)[4]) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int c = 16 * tb + mcol;
+    double Bv[8];
+    {
+        const d2* row = reinterpret_cast<const d2*>(AB + kAbStride * c + 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const d2 v = row[i]; Bv[2 * i] = v[0]; Bv[2 * i + 1] = v[1]; }
+    }
+    const int cm3 = c - 3 * ((c * 0xAAAB) >> 17);                       // c mod 3 = the column's axis (c < 2^15)
+    const double dcol = (c < n_eff) ? ((cm3 < 2) ? dgxy : dgz) : 1.0;   // (padding -> identity)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 16 * ta + kq + 4 * q;
+        const d2* row = reinterpret_cast<const d2*>(AB + kAbStride * r);
+        double Av[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const d2 v = row[i]; Av[2 * i] = v[0]; Av[2 * i + 1] = v[1]; }
+        double v = Av[0] * Bv[0];
+#pragma unroll
+        for (int i = 1; i < 6; ++i) v = fma(Av[i], Bv[i], v);
+        const double ft = fma(Av[7], Bv[7], Av[6] * Bv[6]);
+        const int d = r + 3 * 1024 - c, dm3 = d - 3 * ((d * 0xAAAB) >> 17);
+        v += (dm3 == 0) ? ft : 0.0;                                     // same axis
+        v += (r == c) ? dcol : 0.0;
+        out[q] = v;
+    }
+}
+
 // diagnostic phase stamp (thread 0 only; leaves the kernel through a buffer nothing else reads)
 #define SRBDQP_STAMP(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 

@@ -71,16 +71,16 @@ struct CompactSmem {
     static constexpr int o_eh = o_cp + up2(N * 9);        // n: Q^1/2 (A_qp x0 - x_ref)
     static constexpr int o_t1 = o_eh + n;                 // 9N: T1(m)
     static constexpr int o_t2 = o_t1 + up2(9 * N);        // 9N: T2(m)
-    static constexpr int o_mt = o_t2 + up2(9 * N);        // 9 NPAIR: M(j, m) at 9 (m (m + 1) / 2 + j), j <= m
-    static constexpr int o_gv = o_mt + up2(9 * NPAIR);    // 9N: G'v tables
+    static constexpr int o_mt = o_t2 + up2(9 * N);        // 18N: D_m, E_m of the rank-6 assembly (srbdqp_common.hpp; the region keeps the 9 NPAIR doubles the M(j, m) table had)
+    static constexpr int o_gv = o_mt + up2(18 * N);       // 9N: G'v tables
     static constexpr int o_gx = o_gv + up2(9 * N);        // n: G x^0 (warm start)
     static constexpr int o_tf = o_gx + n;                 // 6N: per-step torque / force sums of x^0
     static constexpr int o_x0c = o_tf + 6 * N;            // nmax (+16): compact warm start
-    static constexpr int endA = o_x0c + up2(nmax) + 16;
-    // phase B.  Small problems (<= 4 x 4 tiles) assemble K contact pair by contact pair straight into the tile store,
-    // which then sits behind the phase-A arrays; the big ones build their entries in registers and re-use region R.
-    static constexpr bool STAGE = (NT <= 4);
-    static constexpr int o_T = STAGE ? endA : o_R;
+    static constexpr int o_ab = o_x0c + up2(nmax) + 16;   // 16 NT rows of the K assembly's table, one per presolved variable
+    static constexpr int endA = o_ab + 16 * NT * kAbStride;
+    // phase B.  Every lane builds its K entries in registers from the table rows; the tile store re-uses region R.  (Until round 4 the small problems
+    // assembled K contact pair by contact pair straight into a tile store behind the phase-A arrays.)
+    static constexpr int o_T = o_R;
     static constexpr int endB = o_T + NTT * 256;
     // phase C
     static constexpr int o_rhs = o_R;                     // 2 x (LPR CHMAX + 8)
@@ -460,7 +460,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
     const double dt = a.dt, dt2 = a.dt * a.dt, dtm = a.dt * a.inv_mass, dt2m = dt2 * a.inv_mass;
     double* T1 = sm + S::o_t1;
     double* T2 = sm + S::o_t2;
-    double* MT = sm + S::o_mt;
+    double* DE = sm + S::o_mt;
     double* GV = sm + S::o_gv;
     const double* CP = sm + S::o_cp;
     const double* SQ = sm + S::o_sq;
@@ -525,7 +525,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
         return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + ax] * dt2m * g[3 + ax] + SQ[9 + ax] * dtm * g[6 + ax]);
     };
     gt_tables(sm + S::o_eh);
-    mt_tables<N>(CP, T1, T2, SQ, dt2, MT, t, kThreads);
+    de_tables<N>(CP, T1, T2, SQ, dt2, DE, t, kThreads);
     __syncthreads();
     SRBDQP_STAMP(a, b, 2);
     for (int c = t; c < n_eff; c += kThreads) sm[S::o_q + c] = gt_eval(c);
@@ -596,89 +596,18 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
 
     // ================= phase H: K = G'G + R s^2 + sigma + A' rho A, entry by entry into the C-layout register tiles ====
     v4d acc[TS];
-    if constexpr (S::STAGE) {
-        // one thread per contact pair (e1 <= e2): 3x3 block = J_e1' M(j, m) J_e2 (27 LDS reads for 9 entries), written
-        // into the row-major 16x16 tiles (upper tiles; both orders inside a diagonal tile), then every wave pulls its
-        // tiles into C-layout registers.  Rows / columns past n_eff are patched to the identity at that load.
-        const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
-        const int npair = (na * (na + 1)) >> 1;
-        for (int pr = t; pr < npair; pr += kThreads) {
-            int e2 = (int)((sqrtf(8.0f * (float)pr + 1.0f) - 1.0f) * 0.5f);
-            e2 += ((e2 + 1) * (e2 + 2) / 2 <= pr) ? 1 : 0;
-            e2 -= (e2 * (e2 + 1) / 2 > pr) ? 1 : 0;
-            const int e1 = pr - e2 * (e2 + 1) / 2;
-            const int g1 = act[e1], g2 = act[e2], j = g1 >> 2, mm = g2 >> 2;
-            const double* J1 = sm + S::o_J + j * 36 + 3 * (g1 & 3);
-            const double* J2 = sm + S::o_J + mm * 36 + 3 * (g2 & 3);
-            const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
-            double Bm[3][3];                                   // M J_e2
-#pragma unroll
-            for (int l = 0; l < 3; ++l)
-#pragma unroll
-                for (int c2 = 0; c2 < 3; ++c2) Bm[l][c2] = M[3 * l] * J2[c2] + M[3 * l + 1] * J2[12 + c2] + M[3 * l + 2] * J2[24 + c2];
-            const int Ls = N - mm, d = mm - j;
-            const double sp = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2)), ls = (double)Ls;
-#pragma unroll
-            for (int a1 = 0; a1 < 3; ++a1) {
-                const double j0 = J1[a1], j1 = J1[12 + a1], j2 = J1[24 + a1];
-                const double same = SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls;
-#pragma unroll
-                for (int a2 = 0; a2 < 3; ++a2) {
-                    const int R = 3 * e1 + a1, Cc = 3 * e2 + a2, tr = R >> 4, tc = Cc >> 4;
-                    double v = j0 * Bm[0][a2] + j1 * Bm[1][a2] + j2 * Bm[2][a2];
-                    if (a1 == a2) v += same;
-                    v *= s2;
-                    if (R == Cc) v += a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + a.rho_fz) * rho_b);
-                    if (tr <= tc) T[tile_id(tr, tc) * 256 + (R & 15) * 16 + (Cc & 15)] = v;
-                    if (e1 != e2 && tc <= tr) T[tile_id(tc, tr) * 256 + (Cc & 15) * 16 + (R & 15)] = v;
-                }
-            }
-        }
+    {   // the rank-6 form (srbdqp_common.hpp): a table row per presolved variable, then every lane its own C-layout entries
+        double* AB = sm + S::o_ab;
+        kasm_rows<N>(sm + S::o_J, CP, DE, SQ, act, n_eff, a.s, dt2m, dtm, AB, t, kThreads, 16 * NT);
         __syncthreads();
+        const double dgxy = a.rs2 + a.sigma + 2.0 * rho_b, dgz = a.rs2 + a.sigma + (4.0 * a.mu * a.mu + a.rho_fz) * rho_b;
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
             if (ta[s] >= 0) {
-                const double* tl = T + tile_id(ta[s], tb[s]) * 256;
-                const int c = 16 * tb[s] + mcol;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = 16 * ta[s] + kq + 4 * q;
-                    const double v = tl[(kq + 4 * q) * 16 + mcol];
-                    acc[s][q] = (r < n_eff && c < n_eff) ? v : ((r == c) ? 1.0 : 0.0);
-                }
-            }
-        }
-    } else {
-        const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
-#pragma unroll
-        for (int s = 0; s < TS; ++s) {
-            acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
-            if (ta[s] >= 0) {
-                const int c = 16 * tb[s] + mcol;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // branch-free (clamped indices, selects) so that the LDS reads of the 12 entries of a thread overlap
-                    const int r = 16 * ta[s] + kq + 4 * q;
-                    const bool in = (r < n_eff) && (c < n_eff);
-                    const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;   // contact order = index order
-                    const int e1 = lo / 3, a1 = lo - 3 * e1, e2 = hi / 3, a2 = hi - 3 * e2;
-                    const int g1 = act[e1], g2 = act[e2], j = g1 >> 2, mm = g2 >> 2;
-                    const double* J1 = sm + S::o_J + j * 36 + 3 * (g1 & 3) + a1;
-                    const double* J2 = sm + S::o_J + mm * 36 + 3 * (g2 & 3) + a2;
-                    const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
-                    const double x0 = J2[0], x1 = J2[12], x2 = J2[24];
-                    double v = J1[0] * (M[0] * x0 + M[1] * x1 + M[2] * x2) + J1[12] * (M[3] * x0 + M[4] * x1 + M[5] * x2) +
-                               J1[24] * (M[6] * x0 + M[7] * x1 + M[8] * x2);
-                    const int Ls = N - mm, d = mm - j;
-                    const int sp = ((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2);
-                    const double same = (a1 == a2) ? 1.0 : 0.0;
-                    v = fma(same, SQ[3 + a1] * SQ[3 + a1] * dt4m2 * (double)sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * (double)Ls, v);
-                    double val = s2 * v;
-                    val += (r == c) ? a.rs2 + a.sigma + ((a1 < 2) ? 2.0 * rho_b : (4.0 * a.mu * a.mu + a.rho_fz) * rho_b) : 0.0;
-                    val = in ? val : ((r == c) ? 1.0 : 0.0);                // padding -> identity
-                    acc[s][q] = val;
-                }
+                double o[4];
+                kasm_tile(AB, ta[s], tb[s], mcol, kq, n_eff, dgxy, dgz, o);
+                acc[s] = (v4d){o[0], o[1], o[2], o[3]};
             }
         }
     }
@@ -691,7 +620,8 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
             for (int s = 0; s < TS; ++s)
                 if (ta[s] >= 0) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) put(16 * ta[s] + kq + 4 * q, 16 * tb[s] + mcol, acc[s][q]);
+                    for (int q = 0; q < 4; ++q)
+                        if (16 * ta[s] + kq + 4 * q <= 16 * tb[s] + mcol) put(16 * ta[s] + kq + 4 * q, 16 * tb[s] + mcol, acc[s][q]);   // (the upper triangle: put() mirrors it)
                 }
         });
         return;
