@@ -102,8 +102,12 @@ struct WrenchSmem {
     static constexpr int o_gx = GX_LATE ? up2(endC) + 6 * n : o_gv + up2(9 * N);
     static constexpr int o_tf = GX_LATE ? o_gv + up2(9 * N) : o_gx + n;   // 6N
     static constexpr int o_x0c = o_eh;                    // 12N  warm start in the scaled variables (the gradient is done with o_eh by then)
-    static constexpr int o_zt = o_tf + 6 * N;             // 6 NG: wrench-space 6-vector of every g coordinate
+    static constexpr int o_ab = o_mt + 18 * N;            // (see below)
+    static constexpr int o_zt = cmax(o_tf + 6 * N, o_ab + 8 * 16 * NT);   // 6 NG: wrench-space 6-vector of every g coordinate (N = 4: behind the T assembly's rows)
     static constexpr int o_ei = o_zt + 6 * NG;            // 36N  E^-1 per step
+    // rank-6 T assembly (round 4): D_m, E_m (18N doubles, srbdqp_common.hpp de_tables) at o_mt where the 9 NPAIR doubles of M(j, m) were, and behind them -- over
+    // the rest of that table, the G'v tables and the warm-start vectors, all dead by then -- one 8-double row per g coordinate [z_ang(3), -C_j z_ang(3), z_lin, 4096 j + 36 j + 6 l]
+    static_assert(o_ab + 8 * 16 * NT <= o_zt, "the T assembly's rows fit between the D / E tables and the 6-vectors");
     static constexpr int o_gs = o_ei + 36 * N;            // NG bytes: step of every g coordinate
     static constexpr int endA = o_gs + up2((NG + 7) / 8);
     // ---- phase B (tiles)
@@ -653,10 +657,10 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     };
     if constexpr (TSPLIT) {
         if (tab_a) gt_tables_wave(sm + S::o_eh);
-        if (tab_b) mt_tables<N>(CP, T1, T2, SQ, dt2, MT, lane, 64);
+        if (tab_b) de_tables<N>(CP, T1, T2, SQ, dt2, MT, lane, 64);
     } else {
         gt_tables(sm + S::o_eh);
-        mt_tables<N>(CP, T1, T2, SQ, dt2, MT, t, BT);
+        de_tables<N>(CP, T1, T2, SQ, dt2, MT, t, BT);
         __syncthreads();
     }
     SRBDQP_STAMP(a, b, 1);
@@ -972,70 +976,66 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     }
     v4t acc[TS];
     {
+        // The rank-6 form of srbdqp_common.hpp in the g coordinates: S(r, c) = z_r' [M(j, m), same(j, m)] z_c with M(j, m) = D_m - C_j' E_m, so with a row
+        // [z_ang, -C_j z_ang, z_lin] per g coordinate (built once, below) and [D_m z_ang, E_m z_ang, f0, f1] of the lane's column (formed per tile slot) an entry
+        // is 6 + 2 multiply-adds and one E^-1 look-up.  The entry-by-entry loops this replaces spent most of their time on three levels of dependent index reads
+        // per entry (the step of a coordinate, its offset, the step pair's table) and, for a pair of force variables, 21 LDS reads.
         const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
         const double* ZT = sm + S::o_zt;
-        if ((sizeof(TT) == 4 || XW > 0) && iwr[N] != 0) {   // (fp32 tiles and the low-latency instantiation: in the fp64 batch instantiations the second copy of the loop gained nothing)
-            // every step in wrench coordinates (full double support, configs[2]): step and coordinate of a g row are r / 6 and
-            // r % 6, every entry is a table look-up -- no index tables, no 6-vectors (the general loop below spends most of its
-            // 38 k cycles on three levels of dependent LDS index reads per entry)
-#pragma unroll
-            for (int s = 0; s < TS; ++s) {
-                acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
-                if (ta[s] >= 0) {
-                    const int c = 16 * tb[s] + mcol;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = 16 * ta[s] + crow<TT>(kq, q);
-                        const bool in = (r < n_g) && (c < n_g);
-                        const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;
-                        const int j = lo / 6, mm = hi / 6, l1 = lo - 6 * j, l2 = hi - 6 * mm;
-                        const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
-                        const int Ls = N - mm, d = mm - j;
-                        const double sp = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2)), ls = (double)Ls;
-                        const int a1 = (l1 >= 3) ? l1 - 3 : 0;
-                        const double dg = SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls;
-                        const double v = (l1 < 3 && l2 < 3) ? M[3 * l1 + l2] : ((l1 >= 3 && l1 == l2) ? dg : 0.0);
-                        double val = s2 * v;
-                        if (j == mm) val += sm[S::o_ei + 36 * j + 6 * l1 + l2];
-                        acc[s][q] = (TT)(in ? val : ((r == c) ? 1.0 : 0.0));     // padding -> identity
-                    }
-                }
-            }
-        } else
+        const double* DE = MT;
+        double* AB = sm + S::o_ab;
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        for (int r = t; r < 16 * S::NT; r += BT) {
+            const bool on = r < n_g;
+            const int rr = on ? r : 0, j = gstep[rr], l = rr - igoff[j];
+            const double* z = ZT + 6 * rr;
+            const double* C = CP + 9 * j;
+            const double z0 = z[0], z1 = z[1], z2 = z[2];
+            const int rm3 = rr - 3 * ((rr * 0xAAAB) >> 17);
+            const double gl = (rm3 == 0) ? z[3] : (rm3 == 1) ? z[4] : z[5];
+            const double code = on ? (double)(4096 * j + 36 * j + 6 * l) : -4096.0;     // (step, offset of the coordinate's row in the step's E^-1) as one exact integer
+            d2* row = reinterpret_cast<d2*>(AB + 8 * r);
+            row[0] = on ? (d2){z0, z1} : (d2){0.0, 0.0};
+            row[1] = on ? (d2){z2, -(C[0] * z0 + C[1] * z1 + C[2] * z2)} : (d2){0.0, 0.0};
+            row[2] = on ? (d2){-(C[3] * z0 + C[4] * z1 + C[5] * z2), -(C[6] * z0 + C[7] * z1 + C[8] * z2)} : (d2){0.0, 0.0};
+            row[3] = (d2){on ? gl : 0.0, code};
+        }
+        __syncthreads();
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
             if (ta[s] >= 0) {
                 const int c = 16 * tb[s] + mcol;
+                const bool cin = c < n_g;
+                const int cc = cin ? c : 0, mm = gstep[cc], l2 = cc - igoff[mm];
+                const double* zc = ZT + 6 * cc;
+                const double* D = DE + 18 * mm;
+                const double c0 = zc[0], c1 = zc[1], c2 = zc[2];
+                double Bv[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Bv[i] = s2 * (D[3 * i] * c0 + D[3 * i + 1] * c1 + D[3 * i + 2] * c2);      // D_m z_ang (3), E_m z_ang (3)
+                const int cm3 = cc - 3 * ((cc * 0xAAAB) >> 17);
+                const double gc = s2 * ((cm3 == 0) ? zc[3] : (cm3 == 1) ? zc[4] : zc[5]);
+                const int Ls = N - mm;
+                const double al = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6), be = (double)(((Ls - 1) * Ls) / 2);
+                const double fa = SQ[3 + cm3] * SQ[3 + cm3] * dt4m2, fb = SQ[9 + cm3] * SQ[9 + cm3] * dt2m2;
+                const double f0 = gc * (fa * (al + (double)mm * be) + fb * (double)Ls), f1 = gc * fa * be;
+                const double* EI = sm + S::o_ei + l2;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = 16 * ta[s] + crow<TT>(kq, q);
-                    const bool in = (r < n_g) && (c < n_g);
-                    const int lo = in ? ((r < c) ? r : c) : 0, hi = in ? ((r < c) ? c : r) : 0;
-                    const int j = gstep[lo], mm = gstep[hi];
-                    const double* M = MT + 9 * (mm * (mm + 1) / 2 + j);
-                    const int Ls = N - mm, d = mm - j;
-                    const double sp = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6 + d * (((Ls - 1) * Ls) / 2)), ls = (double)Ls;
-                    const int l1 = lo - igoff[j], l2 = hi - igoff[mm];
-                    double v;
-                    if (iwr[j] & iwr[mm]) {
-                        // both are wrench coordinates (unit vectors): the entry is a table look-up
-                        const int a1 = (l1 >= 3) ? l1 - 3 : 0;
-                        const double dg = SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls;
-                        v = (l1 < 3 && l2 < 3) ? M[3 * l1 + l2] : ((l1 >= 3 && l1 == l2) ? dg : 0.0);
-                    } else {
-                        const double* z1 = ZT + 6 * lo;
-                        const double* z2 = ZT + 6 * hi;
-                        const double x0 = z2[0], x1 = z2[1], x2 = z2[2];
-                        v = z1[0] * (M[0] * x0 + M[1] * x1 + M[2] * x2) + z1[1] * (M[3] * x0 + M[4] * x1 + M[5] * x2) +
-                            z1[2] * (M[6] * x0 + M[7] * x1 + M[8] * x2);
-#pragma unroll
-                        for (int a1 = 0; a1 < 3; ++a1)
-                            v = fma(z1[3 + a1] * z2[3 + a1], SQ[3 + a1] * SQ[3 + a1] * dt4m2 * sp + SQ[9 + a1] * SQ[9 + a1] * dt2m2 * ls, v);
-                    }
-                    double val = s2 * v;
-                    if (j == mm) val += sm[S::o_ei + 36 * j + 6 * l1 + l2];
-                    acc[s][q] = (TT)(in ? val : ((r == c) ? 1.0 : 0.0));         // padding -> identity
+                    const d2* row = reinterpret_cast<const d2*>(AB + 8 * r);
+                    const d2 a01 = row[0], a23 = row[1], a45 = row[2], a67 = row[3];
+                    const int cw = (int)a67[1], cj = cw >> 12, ce = cw & 4095;
+                    double v = a01[0] * Bv[0];
+                    v = fma(a01[1], Bv[1], v); v = fma(a23[0], Bv[2], v); v = fma(a23[1], Bv[3], v); v = fma(a45[0], Bv[4], v); v = fma(a45[1], Bv[5], v);
+                    const double ft = a67[0] * fma(-(double)cj, f1, f0);
+                    const int d = r + 3 * 1024 - c, dm3 = d - 3 * ((d * 0xAAAB) >> 17);
+                    v += (dm3 == 0) ? ft : 0.0;                                   // same axis
+                    const bool same_step = cj == mm;
+                    const double ei = EI[same_step ? ce : 0];
+                    v += same_step ? ei : 0.0;
+                    acc[s][q] = (TT)((r < n_g && cin) ? v : ((r == c) ? 1.0 : 0.0));   // padding -> identity
                 }
             }
         }
@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = 16 * ta[s] + kq + 4 * q;
-                    if (r < S::NG && c < S::NG) {
+                    if (r < S::NG && c < S::NG && r <= c) {          // (the upper triangle: the entries of a diagonal tile below it are never formed)
                         const double v = (r < n_g && c < n_g) ? acc[s][q] : 0.0;
                         out[r * S::NG + c] = v;
                         out[c * S::NG + r] = v;
