@@ -458,8 +458,11 @@ __device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_ou
     // phase A2: omega_k, v_k for k = 1..N  (scratch[(k-1)*6 + comp]); same summation order as before
     for (int idx = t; idx < 6 * N; idx += BT) {
         const int k = idx / 6 + 1, comp = idx % 6;
+        // (every loop of the roll-out runs over all N steps with the later ones adding exact zeros: with a trip count per lane it is not unrolled and every
+        // trip waits for its own LDS reads -- 3 us of a batch-1 call went into these three loops; this way the reads of all trips are in flight together)
         double acc = 0.0;
-        for (int j = 0; j < k; ++j) acc += sj[6 * j + comp];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { const double sv = sj[6 * j + comp]; acc += (j < k) ? sv : 0.0; }
         double v = x0[6 + comp] + a.dt * a.s * acc;
         if (comp == 5) v += (double)k * a.dt * x0[12];
         scratch[idx] = v;
@@ -474,14 +477,17 @@ __device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_ou
         else if (comp >= 6) v = scratch[(k - 1) * 6 + comp - 6];
         else if (comp >= 3) {   // p_k = p_0 + dt sum_{l<k} v_l
             double acc = x0[6 + comp];
-            for (int l = 1; l < k; ++l) acc += scratch[(l - 1) * 6 + comp];
+#pragma unroll
+            for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc += (l < k) ? sv : 0.0; }
             v = x0[comp] + a.dt * acc;
         } else {                // theta_k = theta_0 + dt sum_{l<k} T_l omega_l
             double acc = 0.0;
-            for (int l = 0; l < k; ++l) {
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
                 const double* T = sm + S::o_tm + l * 9 + comp * 3;
                 const double* w = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
-                acc += T[0] * w[0] + T[1] * w[1] + T[2] * w[2];
+                const double term = T[0] * w[0] + T[1] * w[1] + T[2] * w[2];
+                acc += (l < k) ? term : 0.0;
             }
             v = x0[comp] + a.dt * acc;
         }

@@ -1618,8 +1618,9 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             __syncthreads();
             for (int idx = t; idx < 6 * N; idx += LT) {
                 const int k = idx / 6 + 1, comp = idx % 6;
-                double acc2 = 0.0;
-                for (int j = 0; j < k; ++j) acc2 += sj[6 * j + comp];
+                double acc2 = 0.0;   // (all N steps, the later ones adding exact zeros: the reads of all trips in flight together, srbdqp_common.hpp rollout_and_store_to)
+#pragma unroll
+                for (int j = 0; j < N; ++j) { const double sv = sj[6 * j + comp]; acc2 += (j < k) ? sv : 0.0; }
                 double v = x0[6 + comp] + a.dt * a.s * acc2;
                 if (comp == 5) v += (double)k * a.dt * x0[12];
                 scratch[idx] = v;
@@ -1634,14 +1635,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 else if (comp >= 6) v = scratch[(k - 1) * 6 + comp - 6];
                 else if (comp >= 3) {
                     double acc2 = x0[6 + comp];
-                    for (int l = 1; l < k; ++l) acc2 += scratch[(l - 1) * 6 + comp];
+#pragma unroll
+                    for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc2 += (l < k) ? sv : 0.0; }
                     v = x0[comp] + a.dt * acc2;
                 } else {
                     double acc2 = 0.0;
-                    for (int l = 0; l < k; ++l) {
+#pragma unroll
+                    for (int l = 0; l < N; ++l) {
                         const double* Tm = sm + S::o_tm + l * 9 + comp * 3;
                         const double* wv2 = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
-                        acc2 += Tm[0] * wv2[0] + Tm[1] * wv2[1] + Tm[2] * wv2[2];
+                        const double term = Tm[0] * wv2[0] + Tm[1] * wv2[1] + Tm[2] * wv2[2];
+                        acc2 += (l < k) ? term : 0.0;
                     }
                     v = x0[comp] + a.dt * acc2;
                 }
