@@ -286,6 +286,34 @@ __device__ __forceinline__ void kasm_tile(const double* AB, const int ta, const 
     }
 }
 
+// Row kk of step i of G x (the warm start's P x^0, the rho-restart passes, the fp32-tile kernel's refinement of x_q), before the Q^1/2 s scaling, from the per-step
+// torque / force sums TF: prefix sums over the steps j <= i.  Every loop runs over ALL N steps with the later ones adding exact zeros (same summation order): with
+// a trip count per lane the loops were not unrolled and every trip waited for its own LDS reads.
+template <int N>
+__device__ __forceinline__ double gx_row(const double* CP, const double* TF, const int i, const int kk, const double dt, const double dt2, const double dtm, const double dt2m) {
+    double acc = 0.0;
+    if (kk < 3) {
+        const double* Ci = CP + i * 9 + kk * 3;
+        const double c0 = Ci[0], c1 = Ci[1], c2 = Ci[2];
+#pragma unroll 4
+        for (int j = 0; j < N; ++j) {
+            const double* Cj = CP + j * 9 + kk * 3;
+            const double* tau = TF + 6 * j;
+            const double term = (c0 - Cj[0]) * tau[0] + (c1 - Cj[1]) * tau[1] + (c2 - Cj[2]) * tau[2];
+            acc += (j <= i) ? term : 0.0;
+        }
+        return acc * dt2;
+    } else if (kk < 6) {
+#pragma unroll 4
+        for (int j = 0; j < N; ++j) { const double v = TF[6 * j + kk]; acc += (j <= i) ? (double)(i - j) * v : 0.0; }
+        return acc * dt2m;
+    } else {
+#pragma unroll 4
+        for (int j = 0; j < N; ++j) { const double v = TF[6 * j + kk - 6]; acc += (j <= i) ? v : 0.0; }
+        return acc * ((kk < 9) ? dt : dtm);
+    }
+}
+
 // diagnostic phase stamp (thread 0 only; leaves the kernel through a buffer nothing else reads)
 #define SRBDQP_STAMP(a, b, idx) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(b) * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
@@ -460,9 +488,14 @@ __device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_ou
         const int k = idx / 6 + 1, comp = idx % 6;
         // (every loop of the roll-out runs over all N steps with the later ones adding exact zeros: with a trip count per lane it is not unrolled and every
         // trip waits for its own LDS reads -- 3 us of a batch-1 call went into these three loops; this way the reads of all trips are in flight together)
+        // (long horizons keep the trip count per lane: k grows with the wave there, and the waves of the early steps are done after a few trips)
         double acc = 0.0;
+        if constexpr (N <= 12) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) { const double sv = sj[6 * j + comp]; acc += (j < k) ? sv : 0.0; }
+            for (int j = 0; j < N; ++j) { const double sv = sj[6 * j + comp]; acc += (j < k) ? sv : 0.0; }
+        } else {
+            for (int j = 0; j < k; ++j) acc += sj[6 * j + comp];
+        }
         double v = x0[6 + comp] + a.dt * a.s * acc;
         if (comp == 5) v += (double)k * a.dt * x0[12];
         scratch[idx] = v;
@@ -477,17 +510,25 @@ __device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_ou
         else if (comp >= 6) v = scratch[(k - 1) * 6 + comp - 6];
         else if (comp >= 3) {   // p_k = p_0 + dt sum_{l<k} v_l
             double acc = x0[6 + comp];
+            if constexpr (N <= 12) {
 #pragma unroll
-            for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc += (l < k) ? sv : 0.0; }
+                for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc += (l < k) ? sv : 0.0; }
+            } else {
+                for (int l = 1; l < k; ++l) acc += scratch[(l - 1) * 6 + comp];
+            }
             v = x0[comp] + a.dt * acc;
         } else {                // theta_k = theta_0 + dt sum_{l<k} T_l omega_l
             double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l < N; ++l) {
+            auto term_of = [&](int l) {
                 const double* T = sm + S::o_tm + l * 9 + comp * 3;
                 const double* w = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
-                const double term = T[0] * w[0] + T[1] * w[1] + T[2] * w[2];
-                acc += (l < k) ? term : 0.0;
+                return T[0] * w[0] + T[1] * w[1] + T[2] * w[2];
+            };
+            if constexpr (N <= 12) {
+#pragma unroll
+                for (int l = 0; l < N; ++l) { const double term = term_of(l); acc += (l < k) ? term : 0.0; }
+            } else {
+                for (int l = 0; l < k; ++l) acc += term_of(l);
             }
             v = x0[comp] + a.dt * acc;
         }

@@ -551,25 +551,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
         __syncthreads();
         for (int k = t; k < n; k += kThreads) {   // G x^0, row kk of step i
             const int i = k / 12, kk = k - 12 * i;
-            double acc = 0.0;
-            if (kk < 3) {
-                const double* Ci = CP + i * 9 + kk * 3;
-                for (int j = 0; j <= i; ++j) {
-                    const double* Cj = CP + j * 9 + kk * 3;
-                    const double* tau = TF + 6 * j;
-                    acc += (Ci[0] - Cj[0]) * tau[0] + (Ci[1] - Cj[1]) * tau[1] + (Ci[2] - Cj[2]) * tau[2];
-                }
-                acc *= dt2;
-            } else if (kk < 6) {
-                for (int j = 0; j <= i; ++j) acc += (double)(i - j) * TF[6 * j + kk];
-                acc *= dt2m;
-            } else if (kk < 9) {
-                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
-                acc *= dt;
-            } else {
-                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
-                acc *= dtm;
-            }
+            const double acc = gx_row<N>(CP, TF, i, kk, dt, dt2, dtm, dt2m);
             sm[S::o_gx + k] = SQ[kk] * a.s * acc;
         }
         __syncthreads();

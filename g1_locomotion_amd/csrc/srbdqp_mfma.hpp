@@ -159,8 +159,10 @@ __device__ __forceinline__ v4d diag16_invert_mfma(v4d s, int lane, bool& ok) {
 //     S_i -= L[i][k] u,   R_i -= L[i][k] W_k     with L[i][k] = u in lane i = the instruction's row_newbcast:i source operand,
 // 240 v_fmac_f64_dpp + 16 x 9 instructions of pivot chain (the next pivot's chain depends on the first multiply-add of a pivot only: the
 // scheduler runs it beside the rest).  The blocked routine above is as many instructions but spends half its time waiting on dependent MFMAs and
-// on v_readlane hazards: 3285 cycles a tile alone on its SIMD (tools/diag_probe.hip).  In and out through a 16 x 16 LDS tile of the caller's
-// (C layout -> columns; W back row-major, XOR-swizzled as the consumers read it); the four DPP rows work redundantly.
+// on v_readlane hazards: 3309 cycles a tile alone on its SIMD against 2888 here, 3571 against 2961 with two waves per SIMD (tools/diag_probe.hip; a DPP
+// multiply-add of doubles issues every 8 cycles from one wave alone).  In and out through a 16 x 16 LDS tile of the caller's (C layout -> columns; W back
+// row-major, XOR-swizzled as the consumers read it); the four DPP rows work redundantly.  NOT USED by the kernels: its 64 live registers beside the ten
+// register tiles of the one-wave kernel end in scratch memory there (256 VGPRs + 88 bytes; configs[1] at 35 fixed iterations 1.775 -> 1.852 ms per 65,536 QPs).
 // ---------------------------------------------------------------------------------------------------------
 template <int I>
 __device__ __forceinline__ void fmac_newbcast(double& acc, double nu, double m) {   // acc += nu[lane I of the row] * m

@@ -690,25 +690,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         __syncthreads();
         for (int k = t; k < n; k += BT) {   // G x^0, row kk of step i
             const int i = k / 12, kk = k - 12 * i;
-            double acc = 0.0;
-            if (kk < 3) {
-                const double* Ci = CP + i * 9 + kk * 3;
-                for (int j = 0; j <= i; ++j) {
-                    const double* Cj = CP + j * 9 + kk * 3;
-                    const double* tau = TF + 6 * j;
-                    acc += (Ci[0] - Cj[0]) * tau[0] + (Ci[1] - Cj[1]) * tau[1] + (Ci[2] - Cj[2]) * tau[2];
-                }
-                acc *= dt2;
-            } else if (kk < 6) {
-                for (int j = 0; j <= i; ++j) acc += (double)(i - j) * TF[6 * j + kk];
-                acc *= dt2m;
-            } else if (kk < 9) {
-                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
-                acc *= dt;
-            } else {
-                for (int j = 0; j <= i; ++j) acc += TF[6 * j + kk - 6];
-                acc *= dtm;
-            }
+            const double acc = gx_row<N>(CP, TF, i, kk, dt, dt2, dtm, dt2m);
             sm[S::o_gx + k] = SQ[kk] * a.s * acc;
         }
         __syncthreads();
@@ -1619,8 +1601,12 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             for (int idx = t; idx < 6 * N; idx += LT) {
                 const int k = idx / 6 + 1, comp = idx % 6;
                 double acc2 = 0.0;   // (all N steps, the later ones adding exact zeros: the reads of all trips in flight together, srbdqp_common.hpp rollout_and_store_to)
+                if constexpr (N <= 12) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) { const double sv = sj[6 * j + comp]; acc2 += (j < k) ? sv : 0.0; }
+                    for (int j = 0; j < N; ++j) { const double sv = sj[6 * j + comp]; acc2 += (j < k) ? sv : 0.0; }
+                } else {   // (long horizons: k grows with the wave, and the waves of the early steps are done after a few trips)
+                    for (int j = 0; j < k; ++j) acc2 += sj[6 * j + comp];
+                }
                 double v = x0[6 + comp] + a.dt * a.s * acc2;
                 if (comp == 5) v += (double)k * a.dt * x0[12];
                 scratch[idx] = v;
@@ -1635,17 +1621,25 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 else if (comp >= 6) v = scratch[(k - 1) * 6 + comp - 6];
                 else if (comp >= 3) {
                     double acc2 = x0[6 + comp];
+                    if constexpr (N <= 12) {
 #pragma unroll
-                    for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc2 += (l < k) ? sv : 0.0; }
+                        for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc2 += (l < k) ? sv : 0.0; }
+                    } else {
+                        for (int l = 1; l < k; ++l) acc2 += scratch[(l - 1) * 6 + comp];
+                    }
                     v = x0[comp] + a.dt * acc2;
                 } else {
                     double acc2 = 0.0;
-#pragma unroll
-                    for (int l = 0; l < N; ++l) {
+                    auto term_of = [&](int l) {
                         const double* Tm = sm + S::o_tm + l * 9 + comp * 3;
                         const double* wv2 = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
-                        const double term = Tm[0] * wv2[0] + Tm[1] * wv2[1] + Tm[2] * wv2[2];
-                        acc2 += (l < k) ? term : 0.0;
+                        return Tm[0] * wv2[0] + Tm[1] * wv2[1] + Tm[2] * wv2[2];
+                    };
+                    if constexpr (N <= 12) {
+#pragma unroll
+                        for (int l = 0; l < N; ++l) { const double term = term_of(l); acc2 += (l < k) ? term : 0.0; }
+                    } else {
+                        for (int l = 0; l < k; ++l) acc2 += term_of(l);
                     }
                     v = x0[comp] + a.dt * acc2;
                 }
