@@ -47,10 +47,13 @@ run ${RR}_cascade_kernels_hbm.json 100 python tools/cascade_bench.py
 fi
 if [ "$PART" = all ] || [ "$PART" = profile ]; then
 # rocprofv3: kernel trace + stats, then the PMC passes (one counter group per run), both configs
-bash tools/profile_config.sh $RR 1 wave_f64_n10_s2 4096 10 8 1 > $O/profile_c1.log 2>&1 || { echo "FAILED: profile config 1"; FAILED="$FAILED profile1"; }
-bash tools/profile_config.sh $RR 2 wrench_f32_n20 65536 20 4 1 > $O/profile_c2.log 2>&1 || { echo "FAILED: profile config 2"; FAILED="$FAILED profile2"; }
+# (round 4: configs[1] runs the deferred-tail kernel; configs[2] is profiled with --in-place -- with deferred restart passes on the tail stream the per-kernel durations
+#  of rocprofv3 overlap and do not add up; configs[4] counts per CALL: 3 launches of a bucket's kernel per call, mean horizon 15)
+bash tools/profile_config.sh $RR 1 wave_defer_f64_n10_s2 4096 10 8 1 > $O/profile_c1.log 2>&1 || { echo "FAILED: profile config 1"; FAILED="$FAILED profile1"; }
+bash tools/profile_config.sh $RR 2 wrench_f32_n20 65536 20 4 1 --in-place > $O/profile_c2.log 2>&1 || { echo "FAILED: profile config 2"; FAILED="$FAILED profile2"; }
+bash tools/profile_config.sh $RR 4 ragged_wrench_f64_n8_n12_n16_n24 16384 15 8 3 > $O/profile_c4.log 2>&1 || { echo "FAILED: profile config 4"; FAILED="$FAILED profile4"; }
 bash tools/profile_config.sh $RR 1 compact_f64_n10_s2 4096 10 8 1 --kernel compact > $O/profile_c1_compact.log 2>&1 || { echo "FAILED: profile config 1 (compact)"; FAILED="$FAILED profile1c"; }
-cp $R/gpurun_out/prof_${RR}_c1/${RR}_* $R/gpurun_out/prof_${RR}_c2/${RR}_* $R/gpurun_out/prof_${RR}_c1_compact_f64_n10_s2/${RR}_* $O/ 2>/dev/null
+cp $R/gpurun_out/prof_${RR}_c1/${RR}_* $R/gpurun_out/prof_${RR}_c2_wrench_f32_n20/${RR}_* $R/gpurun_out/prof_${RR}_c4/${RR}_* $R/gpurun_out/prof_${RR}_c1_compact_f64_n10_s2/${RR}_* $O/ 2>/dev/null
 fi
 ls -la $O | grep ${RR}_
 [ -z "$FAILED" ] || { echo "steps that failed:$FAILED"; exit 1; }
