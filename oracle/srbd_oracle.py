@@ -258,6 +258,56 @@ def closed_form_hessian_gradient(p: SrbdParams, x0, x_ref, foot_hor, contact_hor
     return P, q, vi
 
 
+def closed_form_hessian_rank6(p: SrbdParams, x_ref, foot_hor, contact_hor, pcom_hor=None):
+    """The form of closed_form_hessian_gradient()'s P that the HIP kernels assemble since round 4 (srbdqp_common.hpp: de_tables, kasm_rows,
+    kasm_tile), restated in NumPy for the tests.  M(j, m) = D_m - C_j' E_m with ONE pair of 3 x 3 matrices per step,
+        D_m = dt^4 (T2(m) + C_m' W_th T1(m)) + (N - m) dt^2 W_om,     E_m = dt^4 W_th T1(m),
+    and Sp(j, m) = alpha_m + (m - j) beta_m (alpha_m = sum_{i>=m} (i - m)^2, beta_m = sum_{i>=m} (i - m)), so for variables r = (contact e of
+    step j, axis x) and c = (contact e' of step m >= j, axis y)
+        P[r, c] = a_r . b_c + [x == y] (f0_c - j f1_c),
+        a_r = [J_e[:, x]; -C_j J_e[:, x]],   b_c = s^2 [D_m J_e'[:, y]; E_m J_e'[:, y]],
+        f0_c = s^2 (fa_y (alpha_m + m beta_m) + fb_y (N - m)),   f1_c = s^2 fa_y beta_m,   fa = W_p dt^4 / mass^2,  fb = W_v dt^2 / mass^2:
+    one table row (a, b, f0, f1, j) per presolved variable, an entry = 6 + 2 multiply-adds.  Only the upper triangle is formed that way (the
+    kernels never read the rest); it is mirrored here.  Returns P (n_eff, n_eff) without the R s^2 term's partner terms changed: the same matrix
+    as closed_form_hessian_gradient()[0]."""
+    x_ref = np.asarray(x_ref, dtype=np.float64)
+    N = x_ref.shape[0]
+    foot_hor = np.asarray(foot_hor, dtype=np.float64).reshape(N, NC, 3)
+    contact_hor = np.asarray(contact_hor).reshape(N, NC) != 0
+    pcom = x_ref[:, 3:6] if pcom_hor is None else np.asarray(pcom_hor, dtype=np.float64).reshape(N, 3)
+    dt, s, inv_m = p.dt, p.force_scale, 1.0 / p.mass
+    w = np.asarray(p.q_diag, dtype=np.float64)
+    W_th, W_p, W_om, W_v = np.diag(w[0:3]), w[3:6], np.diag(w[6:9]), w[9:12]
+    T = [rot_z(float(x_ref[k, 2])).T for k in range(N)]
+    C = np.cumsum(np.array(T), axis=0)
+    Ib_inv = np.diag(1.0 / np.asarray(p.inertia, dtype=np.float64))
+    contacts = [(k, i) for k in range(N) for i in range(NC) if contact_hor[k, i]]
+    T1 = [sum((C[i] - C[m] for i in range(m, N)), np.zeros((3, 3))) for m in range(N)]
+    T2 = [sum(((C[i] - C[m]).T @ W_th @ (C[i] - C[m]) for i in range(m, N)), np.zeros((3, 3))) for m in range(N)]
+    D = [dt ** 4 * (T2[m] + C[m].T @ W_th @ T1[m]) + (N - m) * dt ** 2 * W_om for m in range(N)]
+    E = [dt ** 4 * W_th @ T1[m] for m in range(N)]
+    fa, fb = W_p * dt ** 4 * inv_m ** 2, W_v * dt ** 2 * inv_m ** 2
+    rows = []                                           # (a, b, f0, f1, j, axis) per presolved variable
+    for k, i in contacts:
+        Rz = T[k].T
+        Jk = Rz @ Ib_inv @ Rz.T @ skew(foot_hor[k, i] - pcom[k])
+        L = N - k
+        alpha, beta = (L - 1) * L * (2 * L - 1) // 6, (L - 1) * L // 2
+        for ax in range(3):
+            a = np.concatenate([Jk[:, ax], -(C[k] @ Jk[:, ax])])
+            b = s * s * np.concatenate([D[k] @ Jk[:, ax], E[k] @ Jk[:, ax]])
+            rows.append((a, b, s * s * (fa[ax] * (alpha + k * beta) + fb[ax] * L), s * s * fa[ax] * beta, k, ax))
+    n = len(rows)
+    P = np.zeros((n, n))
+    for r in range(n):
+        for c in range(r, n):
+            v = rows[r][0] @ rows[c][1]
+            if rows[r][5] == rows[c][5]:
+                v += rows[c][2] - rows[r][4] * rows[c][3]
+            P[r, c] = P[c, r] = v
+    return P + p.r_diag * s * s * np.eye(n)
+
+
 def wrench_reduce(p: SrbdParams, x_ref, foot_hor, contact_hor, pcom_hor=None, rho=None):
     """The presolve of the general (any contact pattern) HIP kernel, restated in NumPy for the tests: the reduced-KKT
     matrix K = P + sigma I + A' rho A of the stance-contact QP, inverted through the rank structure of the SRBD.

@@ -223,6 +223,23 @@ def test_closed_form_assembly_equals_the_dense_products(N, schedule, seed):
     assert np.abs(q - red["q"]).max() <= 1e-12 * max(1.0, np.abs(red["q"]).max())
 
 
+@pytest.mark.parametrize("N,schedule,seed", [(10, "single", 5), (10, "mixed", 6), (8, "double", 7), (16, "single", 8), (24, "mixed", 9), (4, "three", 10)])
+def test_rank6_assembly_equals_the_contact_pair_form(N, schedule, seed):
+    """Round 4: the kernels assemble K (and the general kernel T) in the rank-6 form -- M(j, m) = D_m - C_j' E_m, an entry = a 6-vector of its row variable times a
+    6-vector of its column variable plus a rank-2 force term (srbdqp_common.hpp).  Its NumPy restatement reproduces the contact-pair form -- hence, by the test
+    above, the dense products -- to the 1e-12 the pair form itself holds; the one digit the form gives away (C_m' W T1 - C_j' W T1 at the entry instead of
+    (C_m - C_j)' W T1) shows as a few 1e-15 here."""
+    p = orc.SrbdParams()
+    x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed, schedule))
+    P, _, _ = orc.closed_form_hessian_gradient(p, x0, xr, ft, ct)
+    P6 = orc.closed_form_hessian_rank6(p, xr, ft, ct)
+    assert P6.shape == P.shape
+    assert np.abs(P6 - P).max() <= 1e-12 * np.abs(P).max()
+    qp = orc.build_qp(p, x0, xr, ft, ct)
+    red, _, _ = orc.presolve(qp, ct)
+    assert np.abs(P6 - red["P"]).max() <= 2e-12 * np.abs(red["P"]).max()
+
+
 def test_split_oracle_runs_the_same_restart_passes_as_the_dense_one():
     """Round 4: one restart rule for every kernel, so the general kernel's twin (update_split) runs up to rho_restart_count re-balancings too, each from the rho
     of the pass before it.  In float64 its iterates are the dense path's: same statuses, same iteration counts, same forces, with the marks early enough that
