@@ -152,9 +152,6 @@ __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// M(j, m), j <= m, of the closed-form assembly (derivation: srbdqp_compact.hpp, phase A) at MT[9 (m (m + 1) / 2 + j)]: one step
-// pair = one thread = its 9 entries (the index inversion, the 18 prefix-sum values and the 9 T1 entries are read once per pair;
-// entry by entry over all threads it was 4 x the instructions: 9.8 k -> 3.6 k cycles at N = 20 with three QPs per CU)
 // ... and cut loose from the vector register it was computed in: the compiler otherwise keeps using that copy (a vector operand needs no
 // constant-bus slot), i.e. holds a vector register -- or a scratch slot -- for a uniform constant across the whole kernel
 __device__ __forceinline__ double unis(double v) {
@@ -166,39 +163,9 @@ __device__ __forceinline__ double unis(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int N>
-__device__ __forceinline__ void mt_tables(const double* CP, const double* T1, const double* T2, const double* SQ, const double dt2,
-                                          double* MT, const int t, const int nthreads) {
-    constexpr int NPAIR = N * (N + 1) / 2;
-    for (int pair = t; pair < NPAIR; pair += nthreads) {
-        int mm = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
-        mm += ((mm + 1) * (mm + 2) / 2 <= pair) ? 1 : 0;
-        mm -= (mm * (mm + 1) / 2 > pair) ? 1 : 0;
-        const int j = pair - mm * (mm + 1) / 2;
-        const double* Cm = CP + mm * 9;
-        const double* Cj = CP + j * 9;
-        const double* t1 = T1 + mm * 9;
-        const double* t2 = T2 + mm * 9;
-        const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2], d4 = dt2 * dt2, dl = (double)(N - mm) * dt2;
-        double dC[9], tt[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { dC[i] = Cm[i] - Cj[i]; tt[i] = t1[i]; }
-        double* out = MT + 9 * pair;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                double v = t2[3 * p + q];
-                v += dC[p] * w0 * tt[q] + dC[3 + p] * w1 * tt[3 + q] + dC[6 + p] * w2 * tt[6 + q];
-                v *= d4;
-                if (p == q) v += dl * SQ[6 + p] * SQ[6 + p];
-                out[3 * p + q] = v;
-            }
-    }
-}
-
 // ---- rank-6 form of the closed-form Hessian (round 4) ---------------------------------------------------------------------------------------------------------
-// M(j, m) above is D_m - C_j' E_m with  D_m = dt^4 (T2(m) + C_m' W T1(m)) + (N - m) dt^2 W_w,  E_m = dt^4 W T1(m)  -- one 3 x 3 pair per STEP instead of one
+// M(j, m) = dt^4 (T2(m) + (C_m - C_j)' W T1(m)) + (N - m) dt^2 W_w of the closed-form assembly (derivation: srbdqp_compact.hpp, phase A; until round 4 a table of one
+// matrix per step pair, mt_tables) is D_m - C_j' E_m with  D_m = dt^4 (T2(m) + C_m' W T1(m)) + (N - m) dt^2 W_w,  E_m = dt^4 W T1(m)  -- one 3 x 3 pair per STEP instead of one
 // matrix per step PAIR -- so the torque part of the entry of variables r (contact e1 of step j, axis x) and c (contact e2 of step m >= j, axis y),
 //     [J_e1' M(j, m) J_e2]_xy = J_e1[:, x] . (D_m J_e2)[:, y] - (C_j J_e1)[:, x] . (E_m J_e2)[:, y],
 // is the dot product of a 6-vector of r with a 6-vector of c, and the force part (x == y): fa_x (alpha_m + (m - j) beta_m) + fb_x (N - m) = f0_c - j f1_c.  One table

@@ -14,8 +14,8 @@
 //
 // Assembly: the condensed input matrix G = Q^1/2 s B_qp is never built.  Its blocks have the SRBD structure
 // theta: dt^2 (C_i - C_j) J_j, p: (i-j) dt^2/m I, omega: dt J_j, v: dt/m I (C = prefix sums of R_z'), so K = G'G + ...
-// is J_e' M(j,m) J_e' per contact pair with small per-step-pair tables, and G'v is a suffix sum per step (see phase A
-// in the kernel).  From K on it is v1's machinery with run-time tile counts: register-resident tiled Cholesky with
+// is J_e' M(j,m) J_e' per contact pair -- assembled since round 4 in the rank-6 form M(j,m) = D_m - C_j' E_m (one table row per presolved variable, every lane its own
+// C-layout entries: srbdqp_common.hpp, kasm_rows / kasm_tile) -- and G'v is a suffix sum per step (see phase A in the kernel).  From K on it is v1's machinery with run-time tile counts: register-resident tiled Cholesky with
 // the diagonal tiles inverted on the matrix cores, in-place W = L^-1, K^-1 = W'W.
 #pragma once
 #include "srbdqp_common.hpp"

@@ -94,7 +94,7 @@ struct WrenchSmem {
     static constexpr int o_eh = o_cp + up2(N * 9);        // 12N  Q^1/2 (A_qp x0 - x_ref)
     static constexpr int o_t1 = o_eh + n;                 // 9N
     static constexpr int o_t2 = o_t1 + up2(9 * N);        // 9N
-    static constexpr int o_mt = o_t2 + up2(9 * N);        // 9 NPAIR: M(j, m)
+    static constexpr int o_mt = o_t2 + up2(9 * N);        // 18N: D_m, E_m (de_tables); the region keeps the 9 NPAIR doubles the M(j, m) table had -- the T assembly's rows follow in it (o_ab)
     static constexpr int o_gv = o_mt + up2(9 * NPAIR);    // 9N   G'v tables
     // 12N  G x^0 (P x of the warm start, of the refinement).  fp32 tiles: both uses come behind the tile phases (WARM_LATE), so the array lives
     // in the dead tile region then (behind the parked V rows, in front of the G'v tables) and takes no room in phase A
@@ -554,7 +554,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     double* MT = sm + S::o_mt;
     double* GV = sm + S::o_gv;
     // Low-latency instantiation (XW = 2): the tables are the two set-up helpers' work -- wave NWS the error vector and the G'v
-    // tables behind it, wave NWS + 1 T1 / T2 and M(j, m) behind them, each chain inside ONE wave (its LDS operations complete in
+    // tables behind it, wave NWS + 1 T1 / T2 and D_m / E_m behind them, each chain inside ONE wave (its LDS operations complete in
     // order: no barrier between the two halves) -- while the step waves compute E, V, Bd, which need none of it; one barrier
     // joins the three.  Serially (every wave on every table, then E) the two phases took 6.4 k + 8.0 k cycles of a batch-1 solve.
     constexpr bool TSPLIT = (XW == 2);
