@@ -623,8 +623,14 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
                 int lane_j = lane;
                 SRBDQP_PHASE_LOCAL("+v"(lane_j));           // keeps the lane predicates of the inversion inside this block
                 bool ok;
-                const v4d winv = diag16_invert_mfma(d, lane_j, ok);
-                store_tile<true>(Djj, winv, lane_j);
+                if constexpr (TAIL1) {   // (batch 1, a workgroup's worth of registers: one column per lane, DPP multiply-adds -- 2.9 k against 3.3 k cycles a tile, srbdqp_mfma.hpp)
+                    store_tile<false>(Djj, d, lane_j);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: its LDS operations complete in order
+                    diag16_invert_dpp_tiles<double, double>(Djj, Djj, lane_j, ok);
+                } else {
+                    const v4d winv = diag16_invert_mfma(d, lane_j, ok);
+                    store_tile<true>(Djj, winv, lane_j);
+                }
                 if (!ok && lane == 0) sm[S::o_misc] = 1.0;
             }
         }

@@ -161,8 +161,9 @@ __device__ __forceinline__ v4d diag16_invert_mfma(v4d s, int lane, bool& ok) {
 // scheduler runs it beside the rest).  The blocked routine above is as many instructions but spends half its time waiting on dependent MFMAs and
 // on v_readlane hazards: 3309 cycles a tile alone on its SIMD against 2888 here, 3571 against 2961 with two waves per SIMD (tools/diag_probe.hip; a DPP
 // multiply-add of doubles issues every 8 cycles from one wave alone).  In and out through a 16 x 16 LDS tile of the caller's (C layout -> columns; W back
-// row-major, XOR-swizzled as the consumers read it); the four DPP rows work redundantly.  NOT USED by the kernels: its 64 live registers beside the ten
-// register tiles of the one-wave kernel end in scratch memory there (256 VGPRs + 88 bytes; configs[1] at 35 fixed iterations 1.775 -> 1.852 ms per 65,536 QPs).
+// row-major, XOR-swizzled as the consumers read it); the four DPP rows work redundantly.  Used by the general kernel and by the 4-wave kernel's batch-1
+// instantiation (N = 10 double support 14.75 -> 14.99 M QP/s, configs[4] 2.83 -> 2.88 M, the batch-1 call -0.8 us); NOT by the one-wave kernel: its 64 live
+// registers beside that kernel's ten register tiles end in scratch memory (256 VGPRs + 88 bytes; configs[1] at 35 fixed iterations 1.775 -> 1.852 ms per 65,536 QPs).
 // ---------------------------------------------------------------------------------------------------------
 template <int I>
 __device__ __forceinline__ void fmac_newbcast(double& acc, double nu, double m) {   // acc += nu[lane I of the row] * m
@@ -224,6 +225,22 @@ __device__ __forceinline__ v4d diag16_invert_dpp(v4d s, int lane, bool& ok, doub
     asm volatile("" ::: "memory");
     return w;
 }
-
+// ... from a row-major 16 x 16 tile `in` (float or double, not swizzled; this wave's own writes, complete) into the swizzled tile `out` (may be the same memory when
+// the types agree): the form the tile phases use -- the inverse of a diagonal tile is only ever read back from LDS.
+template <typename TI, typename TO>
+__device__ __forceinline__ void diag16_invert_dpp_tiles(const TI* in, TO* out, int lane, bool& ok) {
+    const int col = lane & 15, g = lane >> 4;
+    double S[16], R[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = (double)in[i * 16 + col]; R[i] = (i == col) ? 1.0 : 0.0; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the reads are done before `out` -- possibly the same tile -- is written)
+    ok = true;
+    diag16_pivot<0>(S, R, ok);
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i * 16 + (col ^ i)] = (TO)R[i];
+    }
+    asm volatile("" ::: "memory");
+}
 
 }  // namespace srbdqp

@@ -1079,25 +1079,21 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             if (mine) {
                 int lane_j = lane;
                 SRBDQP_PHASE_LOCAL("+v"(lane_j));
-                v4d dd;
-                if constexpr (sizeof(TT) == 8) {
-                    dd = d;
-                } else {   // fp32 accumulator layout -> the fp64 one, through the wave's scratch tile; the 16 x 16 inverse is fp64
+                bool ok = true;
+                if (XW > 0 && j == 0 && pre0) {                      // (inverted beside the assembly: the inverse waited in registers)
+                    const int cj = lane_j & 15, gj = lane_j >> 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int row = gj + 4 * q; Djj[row * 16 + (cj ^ row)] = (TT)winv0[q]; }
+                } else if constexpr (sizeof(TT) == 8) {
+                    // one column per lane, DPP multiply-adds (srbdqp_mfma.hpp): through the tile's own slot of the store, which receives the inverse
+                    store_tile_t<TT, false>(Djj, d, lane_j);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: its LDS operations complete in order
+                    diag16_invert_dpp_tiles<TT, TT>(Djj, Djj, lane_j, ok);
+                } else {   // fp32 tiles: the accumulator through the wave's scratch tile; the 16 x 16 inverse is formed in fp64 and stored in fp32
                     float* wsx = reinterpret_cast<float*>(sm + S::o_ws) + 256 * w;
                     store_tile_t<float, false>(wsx, d, lane_j);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: its LDS operations complete in order
-                    const int cj = lane_j & 15, gj = lane_j >> 4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) dd[q] = (double)wsx[(gj + 4 * q) * 16 + cj];
-                }
-                bool ok = true;
-                v4d winv;
-                if (XW > 0 && j == 0 && pre0) winv = winv0;          // (inverted beside the assembly)
-                else winv = diag16_invert_mfma(dd, lane_j, ok);
-                {
-                    const int cj = lane_j & 15, gj = lane_j >> 4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const int row = gj + 4 * q; Djj[row * 16 + (cj ^ row)] = (TT)winv[q]; }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    diag16_invert_dpp_tiles<float, TT>(wsx, Djj, lane_j, ok);
                 }
                 if (!ok && lane == 0) sm[S::o_misc] = 1.0;
             }
