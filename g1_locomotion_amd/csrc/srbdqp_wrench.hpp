@@ -151,7 +151,8 @@ struct WrenchSmem {
     static constexpr int o_vpc = o_zt;
     static constexpr bool VPARK = TB == 4 && SRBDQP_WRENCH_VPARK && (o_gv - o_vpr >= 6 * n) && (o_vpc + 6 * n <= o_e4);
     static_assert(!GX_LATE || o_gx == o_vpr + 6 * n, "fp32 tiles: G x^0 right behind the parked V rows");
-    static constexpr int o_end = cmax(endA, cmax(endB, endC2));
+    static constexpr int o_pre = cmax(endA, cmax(endB, endC2));   // low-latency instantiation: the scratch tile of the diagonal tile that is inverted beside the assembly (the tile store still holds tables then)
+    static constexpr int o_end = o_pre + (XW > 0 ? 256 : 0);
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr int lds_wgs = wgs_of(o_end);
 };
@@ -1030,7 +1031,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     if constexpr (XW > 0 && N <= 10 && sizeof(TT) == 8 && MODE == 0) {
         if (ta[0] == 0 && tb[0] == 0) {                              // (wave-uniform)
             bool ok0;
-            winv0 = diag16_invert_mfma(acc[0], lane, ok0);
+            winv0 = diag16_invert_dpp(acc[0], lane, ok0, sm + S::o_pre);
             if (!ok0 && lane == 0) sm[S::o_misc] = 1.0;
             pre0 = true;
         }
