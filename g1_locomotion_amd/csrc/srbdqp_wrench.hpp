@@ -103,6 +103,8 @@ struct WrenchSmem {
     static constexpr int o_tf = GX_LATE ? o_gv + up2(9 * N) : o_gx + n;   // 6N
     static constexpr int o_x0c = o_eh;                    // 12N  warm start in the scaled variables (the gradient is done with o_eh by then)
     static constexpr int o_ab = o_mt + 18 * N;            // (see below)
+    static constexpr int o_bb = o_ab + 8 * 16 * NT;       // ... and, where they fit in front of the 6-vectors without growing the layout (N >= 16), the columns' [D_m z_ang, E_m z_ang] rows
+    static constexpr bool BROWS = o_bb + 6 * 16 * NT <= o_tf + 6 * N;
     static constexpr int o_zt = cmax(o_tf + 6 * N, o_ab + 8 * 16 * NT);   // 6 NG: wrench-space 6-vector of every g coordinate (N = 4: behind the T assembly's rows)
     static constexpr int o_ei = o_zt + 6 * NG;            // 36N  E^-1 per step
     // rank-6 T assembly (round 4): D_m, E_m (18N doubles, srbdqp_common.hpp de_tables) at o_mt where the 9 NPAIR doubles of M(j, m) were, and behind them -- over
@@ -982,6 +984,14 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             row[1] = on ? (d2){z2, -(C[0] * z0 + C[1] * z1 + C[2] * z2)} : (d2){0.0, 0.0};
             row[2] = on ? (d2){-(C[3] * z0 + C[4] * z1 + C[5] * z2), -(C[6] * z0 + C[7] * z1 + C[8] * z2)} : (d2){0.0, 0.0};
             row[3] = (d2){on ? gl : 0.0, code};
+            if constexpr (S::BROWS) {   // the column side of the same coordinate, formed once here instead of once per tile slot by every lane of the column
+                const double* D = DE + 18 * j;
+                d2* brow = reinterpret_cast<d2*>(sm + S::o_bb + 6 * r);
+                double bv[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bv[i] = on ? s2 * (D[3 * i] * z0 + D[3 * i + 1] * z1 + D[3 * i + 2] * z2) : 0.0;
+                brow[0] = (d2){bv[0], bv[1]}; brow[1] = (d2){bv[2], bv[3]}; brow[2] = (d2){bv[4], bv[5]};
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -990,15 +1000,28 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             if (ta[s] >= 0) {
                 const int c = 16 * tb[s] + mcol;
                 const bool cin = c < n_g;
-                const int cc = cin ? c : 0, mm = gstep[cc], l2 = cc - igoff[mm];
-                const double* zc = ZT + 6 * cc;
-                const double* D = DE + 18 * mm;
-                const double c0 = zc[0], c1 = zc[1], c2 = zc[2];
-                double Bv[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) Bv[i] = s2 * (D[3 * i] * c0 + D[3 * i + 1] * c1 + D[3 * i + 2] * c2);      // D_m z_ang (3), E_m z_ang (3)
+                const int cc = cin ? c : 0;
+                int mm, l2;
+                double Bv[6], gc;
                 const int cm3 = cc - 3 * ((cc * 0xAAAB) >> 17);
-                const double gc = s2 * ((cm3 == 0) ? zc[3] : (cm3 == 1) ? zc[4] : zc[5]);
+                if constexpr (S::BROWS) {
+                    const d2 g67 = reinterpret_cast<const d2*>(AB + 8 * cc)[3];          // the coordinate's own row: z_lin and (step, offset) code
+                    const int cwc = (int)g67[1];
+                    mm = cwc >> 12;
+                    l2 = (((cwc & 4095) - 36 * mm) * 0xAAAB) >> 18;                         // (36 j + 6 l - 36 j) / 6
+                    gc = s2 * g67[0];
+                    const d2* brow = reinterpret_cast<const d2*>(sm + S::o_bb + 6 * cc);
+                    const d2 b01 = brow[0], b23 = brow[1], b45 = brow[2];
+                    Bv[0] = b01[0]; Bv[1] = b01[1]; Bv[2] = b23[0]; Bv[3] = b23[1]; Bv[4] = b45[0]; Bv[5] = b45[1];
+                } else {
+                    mm = gstep[cc]; l2 = cc - igoff[mm];
+                    const double* zc = ZT + 6 * cc;
+                    const double* D = DE + 18 * mm;
+                    const double c0 = zc[0], c1 = zc[1], c2 = zc[2];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) Bv[i] = s2 * (D[3 * i] * c0 + D[3 * i + 1] * c1 + D[3 * i + 2] * c2);      // D_m z_ang (3), E_m z_ang (3)
+                    gc = s2 * ((cm3 == 0) ? zc[3] : (cm3 == 1) ? zc[4] : zc[5]);
+                }
                 const int Ls = N - mm;
                 const double al = (double)(((Ls - 1) * Ls * (2 * Ls - 1)) / 6), be = (double)(((Ls - 1) * Ls) / 2);
                 const double fa = SQ[3 + cm3] * SQ[3 + cm3] * dt4m2, fb = SQ[9 + cm3] * SQ[9 + cm3] * dt2m2;
