@@ -80,6 +80,49 @@ def algorithmic_flops(N: int, K: float) -> float:
             + (2 * s * 13 + 2 * s * n) + n ** 3 / 3 + K * (2 * n * n + 10 * m))
 
 
+def useful_flops(N: int, K: float, stance, wrench: bool = False) -> float:
+    """W_eff: the minimal flop count of the algorithm the kernels really run on ONE QP -- the presolved (swing variables dropped)
+    closed-form path, or its wrench-reduced form (general kernel) -- as opposed to SURVEY 8(d)'s W(N, K) of the dense 12N-variable
+    path (`algorithmic_flops`) and to the flops the kernels ISSUE (PMC; masked lanes, padded 16x16 tiles, both triangles, redundant
+    per-lane 4x4 / 6x6 inversions included).  `stance` = stance contacts per horizon step (length N, or one int for every step).
+
+    dense presolved path (one-wave / 4-wave kernels), n = 3 sum(c), m = 5 sum(c):
+        500 N [linearise] + 54 n [one 6+6+2-vector table row per variable] + 18 n(n+1)/2 [rank-6 entry: 6 + 3 multiply-adds]
+        + (2 13 13 N + 12 n) [gradient: free response + one 6-vector product per variable] + n^3/3 [Cholesky] + n^3/3 [L^-1]
+        + n^3/3 [K^-1 = W'W, one triangle] + K (2 n^2 + 10 m) [ADMM: K^-1 rhs + rows] + (2 13 13 N + 26 n) [roll-out]
+    wrench-reduced path (general kernel): a step with c >= 3 stance contacts keeps g = 6 wrench coordinates, else g = 3c force
+        variables; n_g = sum(g); T = S + E^-1 is n_g x n_g.  Per step with c >= 3: E = Y D^-1 Y' (36 c, symmetric half), its 6x6
+        inverse (144), V = E^-1 Y D^-1 (216 c), Bd = D^-1 - D^-1 Y' V (108 c^2).  T: 16 n_g + 16 n_g(n_g+1)/2 [6 + 2 multiply-adds per
+        entry], n_g^3 [factor, inverse, product], x_q = -K^-1 q once (one linear solve), and per iteration
+        2 n_g^2 [T^-1 v] + per wrench step (36 c [V w] + 36 c [V' t] + 18 c^2 [Bd w]) + 10 m."""
+    c = [int(stance)] * N if np.isscalar(stance) else [int(v) for v in stance]
+    assert len(c) == N
+    n, m = 3 * sum(c), 5 * sum(c)
+    fixed = 500 * N + (2 * 13 * 13 * N + 12 * n) + (2 * 13 * 13 * N + 26 * n)
+    if not wrench:
+        return fixed + 54 * n + 18 * n * (n + 1) / 2 + n ** 3 + K * (2 * n * n + 10 * m)
+    g = [6 if ci >= 3 else 3 * ci for ci in c]
+    ng = sum(g)
+    step_setup = sum(36 * ci + 144 + 216 * ci + 108 * ci * ci for ci in c if ci >= 3)
+    solve = 2 * ng * ng + sum(72 * ci + 18 * ci * ci for ci in c if ci >= 3)
+    return fixed + step_setup + 16 * ng + 16 * ng * (ng + 1) / 2 + ng ** 3 + solve + K * (solve + 10 * m)
+
+
+def useful_flops_batch(N: int, contact, iters, wrench: bool) -> float:
+    """sum of useful_flops over a batch: contact (B, N, 4) flags, iters (B,) iteration counts (W_eff is affine in K: grouped by pattern)"""
+    c = np.asarray(contact).reshape(-1, N, 4).sum(axis=2).astype(np.int64)
+    it = np.asarray(iters, dtype=np.float64).reshape(-1)
+    pats, inv = np.unique(c, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    tot = 0.0
+    for k, pat in enumerate(pats):
+        sel = inv == k
+        a = useful_flops(N, 0.0, pat, wrench)
+        b = useful_flops(N, 1.0, pat, wrench) - a
+        tot += a * sel.sum() + b * it[sel].sum()
+    return tot
+
+
 def algorithmic_bytes(N: int, esz: int = 8) -> int:
     """HBM bytes per QP (inputs + outputs): esz bytes per scalar, contact flags counted at esz as
     the survey does (4,536 B at N = 10, fp64)."""
@@ -105,6 +148,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-sched-hint", action="store_true",
                     help="do not feed a batch's previous iteration counts back as the longest-first dispatch hint")
     ap.add_argument("--no-allgather", action="store_true", help="n_gpus > 1: leave the u_opt0 all-gather out of the headline value")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the per-step u_opt0 all-gather even at world size 1: the collective's code path "
+                         "on the one GPU at hand (rendezvous on 127.0.0.1 inside this process; no launcher, no re-exec)")
     ap.add_argument("--same-batch", action="store_true", help="every step solves the same batch (round-1 behaviour; A/B)")
     ap.add_argument("--max-iter", type=int, default=0, help="override srbdqp_config.max_iter (0 = library default)")
     ap.add_argument("--rho-restart", type=int, default=0, help="override srbdqp_config.rho_restart_iter (0 = library default)")
@@ -234,11 +280,17 @@ class Leg:
     def stats(self, solved_code):
         iters = self.torch.stack([t.cpu() for t in self.d_it[:self.nb]]).numpy()
         status = self.torch.stack([t.cpu() for t in self.d_st[:self.nb]]).numpy()
+        self._iters = iters
         return float(iters.mean()), float((status == solved_code).mean()), iters
 
     def flops_bytes(self, mean_iters):
         esz = 4 if self.f32 else 8
         return algorithmic_flops(self.N, mean_iters) * self.B, algorithmic_bytes(self.N, esz) * self.B
+
+    def useful_flops_launch(self):
+        """W_eff per launch: mean over the distinct batches, every QP with its own contact pattern and iteration count (after stats())"""
+        wrench = self.kname.startswith("wrench")
+        return float(np.mean([useful_flops_batch(self.N, self.host_batches[j][3], self._iters[j], wrench) for j in range(self.nb)]))
 
     def close(self):
         if self.eng is not None:
@@ -270,7 +322,7 @@ class RaggedLeg:
             # buffer set go (three calls later), so a call must not write where the call two before it may still be writing
             outs = [dict(u=torch.empty((rows, 12), dtype=torch.float64, device=dev), x=torch.empty((rows + B, 13), dtype=torch.float64, device=dev),
                          st=torch.zeros(B, dtype=torch.int32, device=dev), it=torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(2)]
-            self.sets.append(dict(Nq=Nq, rows=rows, d=dd, outs=outs, **outs[0]))
+            self.sets.append(dict(Nq=Nq, rows=rows, d=dd, outs=outs, off=off, ct=ct, **outs[0]))
         self.NO = nb
         from g1_locomotion_amd import _lib
         self.defer = not getattr(args, "in_place", False)
@@ -304,6 +356,17 @@ class RaggedLeg:
                 by += algorithmic_bytes(N, 8) * m.sum() / self.nb
         return fl, by
 
+    def useful_flops_launch(self):
+        tot = 0.0
+        for s in self.sets:
+            it = s["it"].cpu().numpy()
+            for N in RAGGED_HORIZONS:
+                idx = np.where(s["Nq"] == N)[0]
+                if len(idx):
+                    rows = (s["off"][idx][:, None] + np.arange(N)[None, :]).reshape(-1)
+                    tot += useful_flops_batch(N, s["ct"][rows].reshape(len(idx), N, 4), it[idx], True)
+        return tot / self.nb
+
     def close(self):
         self.eng.close()
 
@@ -334,7 +397,7 @@ def isolated_kernel_ms(leg, torch, n_iso, k0):
     return float(np.mean(iso)), len(iso)
 
 
-def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step, S, N, defer=False):
+def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step, S, N, defer=False, useful_launch=None):
     """`frac` = the flops the kernel really issues (PMC summary of the same kernel under profiles/) over the live kernel time
     and the dense peak; `frac_algorithmic` = SURVEY 8(d)'s W(N, K) over the same time."""
     alg_tf = flops_launch / (kernel_ms * 1e-3) / 1e12
@@ -360,6 +423,16 @@ def roofline(kname, flops_launch, abytes, B, kernel_ms, n_iso, peak, ms_per_step
                             "launch; a ragged solve = all its bucket launches.  The timed region overlaps consecutive steps on %d stream(s)" % (n_iso, S)),
          "algorithmic_flops_per_launch": flops_launch,
          "hbm_algorithmic_GBps": hbm_gbs, "hbm_frac_of_8TBps": hbm_gbs / 8000.0}
+    if useful_launch is not None:
+        # W_eff (useful_flops): the minimal flop count of the presolved / wrench-reduced algorithm the kernel runs, every QP with its own contact
+        # pattern and iteration count -- neither the dense path's W (frac_algorithmic) nor what the kernel issues (frac)
+        r["useful_flops_per_launch"] = useful_launch
+        r["achieved_useful"] = useful_launch / (kernel_ms * 1e-3) / 1e12
+        r["frac_useful"] = r["achieved_useful"] / peak
+        r["frac_useful_at_step_rate"] = useful_launch / (ms_per_step * 1e-3) / 1e12 / peak
+        r["frac_useful_note"] = ("W_eff = bench.useful_flops: linearise + closed-form assembly + Cholesky / L^-1 / W'W on the presolved (n_eff) or "
+                                 "wrench-reduced (n_g) matrix + K x (2 n^2 + 10 m) + roll-out, one triangle, no padding, no masked lanes; over the kernel time "
+                                 "(frac_useful) and over the driver-visible step time (frac_useful_at_step_rate)")
     try:
         best, scaled = None, False
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
@@ -417,7 +490,7 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, argv))
-    cid = args.config or (1 if args.gpus == 1 else 3)
+    cid = args.config or (1 if (args.gpus == 1 and not args.force_dist) else 3)
     cfg = CONFIGS[cid]
     B = args.batch or cfg["batch"]
     steps = args.steps or cfg["steps"]
@@ -435,9 +508,12 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
     dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:          # --force-dist without a launcher: a one-rank rendezvous inside this process
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist_mod.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -453,7 +529,7 @@ def main(argv=None):
         SOLVED = _lib.SOLVED
     # deferred tails (round 4): configs[1] on one GPU, on the one-wave kernel with its automatic rho restart.  Not with several ranks: the all-gather of
     # u_opt0 behind every step needs that step's forces complete, and at 65,536 QPs per launch the tail is a tenth of the launch anyway.
-    defer = (cid in (1, 2) and world == 1 and not stub and not args.in_place and args.rho_restart >= 0 and not args.same_batch
+    defer = (cid in (1, 2) and dist is None and not stub and not args.in_place and args.rho_restart >= 0 and not args.same_batch
              and (cid == 2 or (args.kernel in ("auto", "wave") and B >= 4096)))      # (configs[2]: the general kernel's restart pass on the library's tail stream)
     if cid == 4:
         leg = RaggedLeg(B, args, rank, local_rank, dev, torch, nb)
@@ -463,7 +539,7 @@ def main(argv=None):
     N, f32 = leg.N, leg.f32
     NO = leg.NO
     hint = "none" if (args.no_sched_hint or cid == 4 or (defer and cid == 1)) else "own"      # (deferred tails on the one-wave kernel: nothing left for a hint to do)
-    d_u0_all = [torch.empty((world * B, 12), dtype=torch.float32 if f32 else torch.float64, device=dev) for _ in range(NO)] if (world > 1 and cid != 4) else None
+    d_u0_all = [torch.empty((world * B, 12), dtype=torch.float32 if f32 else torch.float64, device=dev) for _ in range(NO)] if (dist is not None and cid != 4) else None
 
     def u0_of(o):
         return leg.d_u[o][:, 0, :].contiguous()
@@ -585,11 +661,15 @@ def main(argv=None):
             "ms_per_step": 1e3 * elapsed / max(steps, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
             "config": {"workload": cfg["workload"].format(B=B) + ("; u_opt0 all-gather over RCCL every step" if use_ag else "")
+                                   + ("; tails deferred (SRBDQP_FLAG_DEFER_TAIL: the ~4 % of a batch that reach a rho-restart mark finish in the next launch on their "
+                                      "stream; srbdqp_flush inside the timed region, every batch complete when the clock stops)" if defer else "")
                                    + (f"; steps rotate over {nb} distinct device batches" if nb > 1 else "; every step solves the same batch"),
                        "horizon": N if cid != 4 else list(RAGGED_HORIZONS), "batch_per_gpu": B, "kernel": kname, "streams": S,
                        "longest_first_hint": hint == "own", "deferred_tails": bool(defer), "world_size": world if dist is None else dist.get_world_size(),
                        "distinct_batches": nb, "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
-                       "allgather_in_value": bool(use_ag)},
+                       "allgather_in_value": bool(use_ag),
+                       "collective": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_at_world_size_1": bool(args.force_dist and world == 1),
+                                                                "what": "all_gather_into_tensor of u_opt0 (B x 12) on the step's own HIP stream, every step"}},
         }
         out.update(extra)
         if not stub:
@@ -606,10 +686,15 @@ def main(argv=None):
             out[key] = total_qp / elapsed_other
         if kernel_ms is not None:
             fl, by = leg.flops_bytes(mean_iters)
-            out["roofline"] = roofline(kname, fl, by, B, kernel_ms, n_iso, peak, 1e3 * elapsed / max(steps, 1), S, N, defer=leg.defer)
+            out["roofline"] = roofline(kname, fl, by, B, kernel_ms, n_iso, peak, 1e3 * elapsed / max(steps, 1), S, N, defer=leg.defer,
+                                       useful_launch=leg.useful_flops_launch())
         if world == 1 and not args.no_latency and not stub and cid == 1:
             from g1_locomotion_amd import synth
-            out["latency_batch1"] = latency_batch1(synth)
+            out["latency_batch1"] = lat = latency_batch1(synth)
+            # the p50 / p99 pairs again where the driver's record keeps them whole (north_star: single-QP p50 <= 50 us at batch 1)
+            out["config"]["latency_batch1_us"] = {k: {"p50": round(v["p50_us"], 2), "p99": round(v["p99_us"], 2)}
+                                                  for k, v in lat.items() if isinstance(v, dict) and "p50_us" in v}
+            out["config"]["latency_batch1_us"]["calls_per_variant"] = lat["calls_per_variant"]
         host_batch0 = leg.host_batches[0] if cid != 4 else None
         leg.close()
         leg = None
@@ -662,7 +747,8 @@ def also_legs(args, rank, local_rank, dev, torch, SOLVED):
                             + ("; restart passes on the library's tail stream beside the next solve, flushed inside the timed steps" if leg.defer else ""),
                 "value": B * steps / el, "unit": "QP/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "dtype": "f32" if leg.f32 else "f64",
                 "kernel": leg.kname, "admm_mean_iters": mean_iters, "solved_frac": solved_frac,
-                "roofline": roofline(leg.kname, fl, by, B, kernel_ms, n, peak, 1e3 * el / steps, S, leg.N, defer=leg.defer)}
+                "roofline": roofline(leg.kname, fl, by, B, kernel_ms, n, peak, 1e3 * el / steps, S, leg.N, defer=leg.defer,
+                                     useful_launch=leg.useful_flops_launch())}
             leg.close()
         except Exception as e:      # a failed side leg must not take the headline down with it; it is reported, not hidden
             res["configs[%d]" % cid] = {"error": repr(e)}
