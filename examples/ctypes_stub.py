@@ -39,23 +39,28 @@ def default_config(lib):
 
 
 class MPC:
-    """MPC(dt) + init_matrices() + update(): the three calls of run_simulation.py:169-170,106."""
+    """MPC(dt) + init_matrices() + update(): the three calls of run_simulation.py:169-170,106, with the attributes the caller fills
+    between them (x0 (13, 1), x_ref_hor (HORIZON_LENGTH, 13), g: run_simulation.py:73-82,96,103)."""
 
     def __init__(self, dt=0.04, lib=None):
         self.lib = lib or load()
         self.cfg = default_config(self.lib)
         self.cfg.dt = dt
         self.HORIZON_LENGTH = self.cfg.horizon
+        self.g = -9.80665
+        self.x0 = np.zeros((13, 1)); self.x0[12] = self.g
+        self.x_ref_hor = np.zeros((self.HORIZON_LENGTH, 13)); self.x_ref_hor[:, 12] = self.g
         self.h = C.c_void_p()
 
     def init_matrices(self):
         if self.lib.srbdqp_create(C.byref(self.cfg), C.byref(self.h)) != 0:      # no GPU: SRBDQP_E_NO_DEVICE, there is no CPU fallback
             raise RuntimeError(self.lib.srbdqp_last_error(None).decode())
 
-    def update(self, contact_horizon, c_horizon, p_com_horizon, x_current, x_ref_hor):
+    def update(self, contact_horizon, c_horizon, p_com_horizon, x_current=None, one_rollout=True):
+        """the reference's call, run_simulation.py:106: update(contact_horizon, c_horizon, p_com_horizon, x_current=MPC.x0, one_rollout=True)"""
         N = self.HORIZON_LENGTH
-        x0 = np.ascontiguousarray(x_current, np.float64).reshape(13)
-        xr = np.ascontiguousarray(x_ref_hor, np.float64).reshape(N, 13)
+        x0 = np.ascontiguousarray(self.x0 if x_current is None else x_current, np.float64).reshape(13)
+        xr = np.ascontiguousarray(self.x_ref_hor, np.float64).reshape(N, 13)
         ft = np.ascontiguousarray(c_horizon, np.float64).reshape(N, 12)
         ct = np.ascontiguousarray(np.asarray(contact_horizon) != 0, np.uint8).reshape(N, 4)
         pc = None if p_com_horizon is None else np.ascontiguousarray(p_com_horizon, np.float64).reshape(N, 3)
@@ -66,7 +71,7 @@ class MPC:
         if rc != 0:
             raise RuntimeError(self.lib.srbdqp_last_error(self.h).decode())
         self.status, self.iters = st.value, it.value                              # 1 solved, 2 iteration cap, < 0 failed (forces 0)
-        return u0.reshape(12, 1), x                                               # u_opt0, x_opt1 (row 1 = the next state)
+        return u0.reshape(12, 1), (x if one_rollout else x[:2])                   # u_opt0, x_opt1 (row 1 = the next state)
 
     def close(self):
         if self.h:

@@ -850,8 +850,13 @@ def test_documented_ctypes_stub_solves_a_qp(torch_first, built_lib):
     M = stub.MPC(dt=0.04)
     M.init_matrices()
     ref = orc.update(orc.SrbdParams(), x0, xr, ft, ct, pcom_hor=xr[:, 3:6])
+    MPC = M
     for pc in (xr[:, 3:6].copy(), None):
-        u0, x1 = M.update([np.array([1, 1, 1, 1])] * N, list(ft), pc, x0.reshape(13, 1), xr)
+        # the caller's statements as the reference writes them (run_simulation.py:73-82,94-106)
+        MPC.x0[:] = x0.reshape(13, 1)
+        MPC.x_ref_hor[:] = xr
+        contact_horizon, c_horizon, p_com_horizon = [np.array([1, 1, 1, 1])] * MPC.HORIZON_LENGTH, list(ft), pc
+        u0, x1 = MPC.update(contact_horizon, c_horizon, p_com_horizon, x_current=MPC.x0, one_rollout=True)
         assert M.status == ref["status"] == orc.STATUS_SOLVED and abs(M.iters - ref["iters"]) <= 5
         assert u0.shape == (12, 1) and x1.shape == (N + 1, 13)
         assert np.abs(u0.reshape(-1) - ref["u"][0]).max() <= TOL_TWIN_N and np.abs(x1 - ref["x"]).max() <= 1e-5
