@@ -768,9 +768,9 @@ def latency_batch1(synth, calls=10000):
         ts = np.array(ts[50:]) * 1e6
         return {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99))}
 
-    def mpc_update(sched, warm, n):
+    def mpc_update(sched, n):
         x0, xr, ft, ct = sets[sched]
-        mpc = MPC(dt=0.04, horizon=HORIZON, warm_start=warm)
+        mpc = MPC(dt=0.04, horizon=HORIZON)
         mpc.init_matrices()
         ts, its = [], []
         for i in range(n + 50):
@@ -813,21 +813,20 @@ def latency_batch1(synth, calls=10000):
         mpc.close()
         return pct(ts)
 
-    def closed_loop(warm, n):
+    def closed_loop(n):
         """a CORRELATED sequence: segments of 25 consecutive control steps, each starting from a synthetic state of the mixed gait (a large
-        disturbance) and then receding -- every state the previous plan's prediction, the contact schedule shifted by one step; cold = every solve
-        from zero, warm = from the previous plan and duals shifted by one step (the receding-horizon warm start; reset at a segment's start)"""
+        disturbance) and then receding -- every state the previous plan's prediction, the contact schedule shifted by one step; every solve from
+        zero (MPC(warm_start=True) was removed in round 5: profiles/r05_warm_start_sweep.txt)"""
         L = 25
         segs = (n + 50 + L - 1) // L
         X0, XR, FT, CT = synth.synthetic_batch(segs, HORIZON, seed=77, schedule="mixed")
-        mpc = MPC(dt=0.04, horizon=HORIZON, warm_start=warm, strict=False)
+        mpc = MPC(dt=0.04, horizon=HORIZON, strict=False)
         mpc.init_matrices()
         ts, its, capped = [], [], 0
         for s in range(segs):
             x = X0[s].copy()
             mpc.x_ref_hor[:] = XR[s]
             c_h = list(FT[s])
-            mpc.reset_warm_start()
             for j in range(L):
                 ct_h, x_cur = list(np.roll(CT[s], -j, axis=0)), x.reshape(13, 1)
                 t = time.perf_counter()
@@ -837,14 +836,13 @@ def latency_batch1(synth, calls=10000):
         mpc.close()
         return dict(pct(ts), mean_iters=float(np.mean(its[50:])), max_iter_rate=capped / len(ts))
 
-    out["cold"] = mpc_update("single", False, calls)
+    out["cold"] = mpc_update("single", calls)
     out["c_abi"] = c_abi("single", calls)
     out["c_abi_eps1e-3"] = c_abi("single", calls, eps_abs=1e-3, eps_rel=1e-3)
     out["c_abi_double_support"] = c_abi("double", calls)
-    out["mpc_update_double_support"] = mpc_update("double", False, calls)
+    out["mpc_update_double_support"] = mpc_update("double", calls)
     out["mpc_update_double_support_arrays"] = mpc_update_arrays("double", calls)
-    out["closed_loop_cold"] = closed_loop(False, calls // 2)
-    out["closed_loop_warm"] = closed_loop(True, calls // 2)
+    out["closed_loop_cold"] = closed_loop(calls // 2)
     # the two-phase call: the set-up (contact schedule, contact points, reference known beforehand) has run and finished;
     # timed = the second phase only, from "the measured state is in the staging array" to "the forces are there"
     x0, xr, ft, ct = sets["single"]
@@ -867,10 +865,10 @@ def latency_batch1(synth, calls=10000):
                    "in rotation, every solve from zero); c_abi: srbdqp_solve_staged_f64(B=1) alone on that gait (everything between the inputs and the forces); eps1e-3: OSQP's default "
                    "tolerance instead of 1e-6; c_abi_double_support / mpc_update_double_support: the same two calls on the REFERENCE'S OWN call "
                    "pattern, all four contact points active on every step, per-step lists as the reference passes them (run_simulation.py:94-101,106); "
-                   "..._arrays: (N, 12) / (N, 4) arrays instead of the lists; closed_loop_cold / closed_loop_warm: segments of 25 "
+                   "..._arrays: (N, 12) / (N, 4) arrays instead of the lists; closed_loop_cold: segments of 25 "
                    "consecutive control steps, each from a synthetic mixed-gait state and then receding (every state the previous plan's prediction, the contact schedule "
-                   "shifted by one step) -- cold from zero, warm from the previous plan and duals shifted by one step: the receding-horizon warm start on a correlated "
-                   "sequence; max_iter_rate = share of the solves that end at the iteration cap; c_abi_prepared_phase2: "
+                   "shifted by one step), every solve from zero (the shift-based warm start of rounds 1-4 cost 41 iterations against 30 and was removed: "
+                   "profiles/r05_warm_start_sweep.txt); max_iter_rate = share of the solves that end at the iteration cap; c_abi_prepared_phase2: "
                    "srbdqp_solve_prepared_f64 alone after a finished srbdqp_prepare_staged_f64 -- a different mode of operation (the "
                    "factorisation ran before the state arrived), listed beside c_abi, not instead of it")
     return out

@@ -351,7 +351,8 @@ int launch_wave_defer(srbdqp_handle* h, KArgs a, hipStream_t st, srbdqp_handle::
     const int rmax = a.restart_max > 0 ? a.restart_max : 1;
     for (int j = 0; j < rmax && j < srbdqp_handle::StreamSlot::kTailHist; ++j) T += slot->tail_hist[j];
     if (T < 64) T = 64;
-    if (const char* e = getenv("SRBDQP_TAIL_WGS_MIN")) { const long long m = atoll(e); if (a.B > 0 && T < m) T = m; }   // (experiments: the cost of empty tail workgroups)
+    static const long long tail_wgs_min = [] { const char* e = getenv("SRBDQP_TAIL_WGS_MIN"); return e ? atoll(e) : 0LL; }();   // (experiments: the cost of empty tail workgroups; read once)
+    if (a.B > 0 && T < tail_wgs_min) T = tail_wgs_min;
     if (T > (long long)slot->tail_cap) T = (long long)slot->tail_cap;
     for (int j = srbdqp_handle::StreamSlot::kTailHist - 1; j > 0; --j) slot->tail_hist[j] = slot->tail_hist[j - 1];
     slot->tail_hist[0] = a.B;
@@ -370,7 +371,10 @@ int launch_wave_defer(srbdqp_handle* h, KArgs a, hipStream_t st, srbdqp_handle::
 int launch_wave_defer_any(srbdqp_handle* h, const KArgs& a, hipStream_t st, srbdqp_handle::StreamSlot* slot, int maxs) {
     const bool s2 = maxs <= 2;
     switch (h->cfg.horizon) {
-        case 4: return s2 ? launch_wave_defer<4, 2>(h, a, st, slot) : launch_wave_defer<4, 4>(h, a, st, slot);
+        // N = 4: ONE instantiation for every launch and for the flush, whatever bound on the stance contacts the call came with -- a record written by a <4, 4>
+        // launch and continued by a <4, 2> one (the flush used to pick its MAXS from cfg.max_contacts_per_step, 0 -> 2, while the device API assumes 4 and the
+        // host API scans the flags per call) rebuilt the QP with the wrong bound and returned SRBDQP_CONTACT_BOUND with zero forces
+        case 4: return launch_wave_defer<4, 4>(h, a, st, slot);
         case 8: if (s2) return launch_wave_defer<8, 2>(h, a, st, slot); break;
         case 10: if (s2) return launch_wave_defer<10, 2>(h, a, st, slot); break;
         default: break;
@@ -379,8 +383,7 @@ int launch_wave_defer_any(srbdqp_handle* h, const KArgs& a, hipStream_t st, srbd
     return SRBDQP_E_INVALID;
 }
 
-// lists for launches of up to B QPs that may re-balance up to rmax times: (rmax + 1) records per QP of a launch can never overflow (a list holds what one
-// launch defers: at most its own QPs plus the unfinished records of the list before it)
+// lists for launches of up to B QPs that may re-balance up to rmax times (sized for the share that really continues; a full list is not an error)
 int ensure_tail_lists(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, int rmax);
 int flush_slot(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st);
 
@@ -673,7 +676,13 @@ int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hi
 }
 
 int ensure_tail_lists(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, int rmax) {
-    const size_t want = (size_t)(rmax + 1) * B + 4096 + 64;        // (+ the margin the kernel keeps free, srbdqp_setup1.hpp rs.more)
+    // Round 5: sized for the share of a launch that really continues, not for every QP of it (rmax + 1) times over (1.2 GB per stream at 65,536 QPs).  About 4 % of a
+    // configs[1] batch reach the first mark and 1 % the second; a list holds a QUARTER of the largest launch (at least 8192 records, never more than the
+    // (rmax + 1) B that can exist): 16,448 records x 3 lists x 1664 B = 82 MB at 65,536 QPs, 41 MB at 4096.  A QP that finds its list full runs its remaining
+    // passes in place (srbdqp_setup1.hpp, srbdqp_wave_defer_kernel): same results, it only holds its own launch up as the restart in place would.
+    size_t want = B / 4 > 8192 ? B / 4 : 8192;
+    if (want > (size_t)(rmax + 1) * B) want = (size_t)(rmax + 1) * B;
+    want += 64;
     if (slot->tail && slot->tail_cap >= want) return SRBDQP_OK;
     if (slot->tail) {                                               // growing: finish what the old lists hold, then let go of them
         int rc = flush_slot(h, slot, st);
@@ -684,7 +693,7 @@ int ensure_tail_lists(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStre
     if (!slot->tail_cnt) {
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&slot->tail_cnt), 64));
     }
-    const size_t cap = want + want / 4;
+    const size_t cap = want;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&slot->tail), 3 * cap * srbdqp::kTailRecDoubles * sizeof(double));
     if (e != hipSuccess) { h->err = std::string("hipMalloc tail lists: ") + hipGetErrorString(e); return SRBDQP_E_NOMEM; }
     slot->tail_cap = cap;
@@ -1069,6 +1078,7 @@ int srbdqp_flush(srbdqp_handle* h, void* stream) {
 
 int srbdqp_synchronize(srbdqp_handle* h) {
     if (!h) return SRBDQP_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));       // (the flush below launches a kernel: a thread that drives several devices may have another one current)
     for (auto& sl : h->slots) {                    // deferred tails of the handle's own stream are part of "everything enqueued"
         if (!sl.used || sl.st != h->stream) continue;
         if (sl.last_tail) { HIP_TRY(h, hipStreamWaitEvent(sl.st, sl.last_tail, 0)); sl.last_tail = nullptr; }
@@ -1205,6 +1215,10 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
     const size_t m = 20 * (size_t)h->cfg.horizon;
     int rc = ensure_restart_buffers(h, slot, lst, (size_t)B, m);
     if (rc != SRBDQP_OK) return rc;
+    // (a handle with SRBDQP_FLAG_DEFER_TAIL whose device-buffer solves ran their passes on the tail stream: slot->resid / ybuf / stbuf / rhobuf alias set 0 of the
+    //  rotation, and a staged or completion-word solve on the same stream comes through here -- it must not overwrite what a tail pass still reads)
+    if (slot->rs_nsets > 1)
+        for (auto& r : slot->rsets) if (r.ev_used) HIP_TRY(h, hipStreamWaitEvent(lst, r.ev_tail, 0));
     const bool lazy = h->lazy_restart;                      // staged path: the host looks at status[] before a second pass
     KArgs a1 = a;
     a1.max_iter = restart;
@@ -1802,8 +1816,10 @@ int srbdqp_ragged_flush(srbdqp_ragged* r, void* stream) {
     if (!r) return SRBDQP_E_INVALID;
     RAG_TRY(r, hipSetDevice(r->device));
     hipStream_t sin = stream ? reinterpret_cast<hipStream_t>(stream) : r->stream;
+    // (the events stay: they are re-recorded by every call, waiting for a completed one costs nothing, and a caller that issued calls on two streams
+    //  flushes each of them -- a flush of the other stream must still find the passes that write ITS outputs)
     for (auto& ev : r->last_tail)
-        if (ev) { RAG_TRY(r, hipStreamWaitEvent(sin, ev, 0)); ev = nullptr; }
+        if (ev) RAG_TRY(r, hipStreamWaitEvent(sin, ev, 0));
     return SRBDQP_OK;
 }
 

@@ -541,9 +541,6 @@ __device__ __forceinline__ bool setup1_pass(const KArgs& a, const QpIo& io, cons
             const int left = a.max_iter - rs_done;                                   // the cap is on the total
             rs.pass = rs_pass;
             rs.more = rs_pass < a.restart_max && a.restart_every < left;
-            // deferred tails: the continuation goes to a list of tail_cap records; with less room than every wave in flight could claim at once, this QP
-            // simply runs on at its rho (the host sizes the lists so that this cannot happen: (rho_restart_count + 1) records per QP of a launch)
-            if (a.tail_lists && a.B > 0) rs.more = rs.more && (a.tail_cnt[a.tail_iout] + 4096 < a.tail_cap);      // (a.B = 0: a flush launch continues in place)
             rs.kcap = rs.more ? a.restart_every : left;
             rs.park = park;
             int status = -1, iters = 0;
@@ -602,7 +599,9 @@ __device__ __forceinline__ unsigned long long unis_u64(unsigned long long v) {
 }
 template <typename T> __device__ __forceinline__ T* unis_ptr(T* p) { return reinterpret_cast<T*>(unis_u64(reinterpret_cast<unsigned long long>(p))); }
 
-__device__ __forceinline__ double* tail_claim(const KArgs& a) {   // a free record of the list this launch appends to (null: full -- cannot happen, see rs.more)
+// a free record of the list this launch appends to, or null: the list is full (round 5: the lists are sized for a quarter of a launch's QPs, not for all of them
+// three times over; the count may run past tail_cap -- the reader clamps it -- and a QP that finds no room runs its remaining passes in place)
+__device__ __forceinline__ double* tail_claim(const KArgs& a) {
     int slot = 0;
     if (threadIdx.x == 0) slot = atomicAdd(a.tail_cnt + a.tail_iout, 1);
     slot = __builtin_amdgcn_readfirstlane(slot);
@@ -610,16 +609,17 @@ __device__ __forceinline__ double* tail_claim(const KArgs& a) {   // a free reco
     return reinterpret_cast<double*>(a.tail_lists) + ((size_t)a.tail_iout * (size_t)a.tail_cap + (size_t)slot) * kTailRecDoubles;
 }
 
-__device__ __forceinline__ void tail_export(const KArgs& a, const QpIo& io, int b, double rho_b, int rs_pass, int rs_done, const double* park) {
+__device__ __forceinline__ bool tail_export(const KArgs& a, const QpIo& io, int b, double rho_b, int rs_pass, int rs_done, const double* park) {
     const int lane = threadIdx.x;
     double* rec = tail_claim(a);
-    if (!rec) return;
+    if (!rec) return false;
     if (lane == 0) {
         TailRecHead* hd = reinterpret_cast<TailRecHead*>(rec);
         hd->b = b; hd->pass = rs_pass; hd->done = rs_done; hd->pad = 0; hd->rho = rho_b; hd->io = io;
         if (io.status) io.status[b] = kStatusPending;
     }
     rec[16 + lane] = park[lane]; rec[80 + lane] = park[64 + lane]; rec[144 + lane] = park[128 + lane];
+    return true;
 }
 
 // FLUSH: the continuations alone (srbdqp_flush: a launch with no QPs of its own; a kernel of its own name, so that profiles keep the two apart).  Nothing comes
@@ -633,42 +633,46 @@ __global__ __launch_bounds__(64, 2) void srbdqp_wave_defer_kernel(KArgs a) {
     const int lane = threadIdx.x;
     const int T = a.tail_wgs;
     double* const park = sm + L1::o_end;
+    QpIo io;
+    int b, rs_pass, rs_done;
+    double rho_b;
+    bool again;
     if ((int)blockIdx.x < T) {
         // ---- a continuation of an earlier launch (first in the grid: these are the long ones)
         const int i = blockIdx.x;
         int cnt = a.tail_cnt[a.tail_iin];
-        cnt = cnt < a.tail_cap ? cnt : a.tail_cap;
+        cnt = cnt < a.tail_cap ? cnt : a.tail_cap;                                          // (claims past the end of a full list found no room: tail_claim)
         if (i == 0 && lane == 0) a.tail_cnt[a.tail_izero] = 0;                             // the list the NEXT launch appends to
         // (cnt <= T: the host launches one tail workgroup per record the list can hold -- a bound it knows, srbdqp.hip launch_wave_defer)
         const double* lin = reinterpret_cast<const double*>(a.tail_lists) + (size_t)a.tail_iin * (size_t)a.tail_cap * kTailRecDoubles;
         if (i >= cnt) return;
         const double* rec = lin + (size_t)i * kTailRecDoubles;
         const TailRecHead* hd = reinterpret_cast<const TailRecHead*>(rec);
-        QpIo io;
         io.x0 = unis_ptr(hd->io.x0); io.xref = unis_ptr(hd->io.xref); io.foot = unis_ptr(hd->io.foot); io.pcom = unis_ptr(hd->io.pcom);
         io.contact = unis_ptr(hd->io.contact); io.u_out = unis_ptr(hd->io.u_out); io.x_out = unis_ptr(hd->io.x_out); io.y_out = unis_ptr(hd->io.y_out);
         io.status = unis_ptr(hd->io.status); io.iters = unis_ptr(hd->io.iters);
-        const int b = __builtin_amdgcn_readfirstlane(hd->b);
-        int rs_pass = __builtin_amdgcn_readfirstlane(hd->pass), rs_done = __builtin_amdgcn_readfirstlane(hd->done);
-        double rho_b = unis(hd->rho);
+        b = __builtin_amdgcn_readfirstlane(hd->b);
+        rs_pass = __builtin_amdgcn_readfirstlane(hd->pass); rs_done = __builtin_amdgcn_readfirstlane(hd->done);
+        rho_b = unis(hd->rho);
         park[lane] = rec[16 + lane]; park[64 + lane] = rec[80 + lane]; park[128 + lane] = rec[144 + lane];
         __syncthreads();
-        bool again = setup1_pass<N, MAXS, true, false, false, 3>(a, io, b, sm, rho_b, rs_pass, rs_done);
-        if constexpr (FLUSH) {
-            while (again) again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
-        } else {
-            if (again) tail_export(a, io, b, rho_b, rs_pass, rs_done, park);
-        }
-    } else if constexpr (!FLUSH) {
+        again = setup1_pass<N, MAXS, true, false, false, 3>(a, io, b, sm, rho_b, rs_pass, rs_done);
+    } else {
+        if constexpr (FLUSH) return;
         // ---- a QP of this launch: its first pass
         const int wg = (int)blockIdx.x - T;
         if (wg >= a.B) return;
-        const int b = a.perm ? a.perm[wg] : wg;
-        double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
-        int rs_pass = 0, rs_done = 0;
-        const QpIo io = io_of(a);
-        if (setup1_pass<N, MAXS, true, false, false, 1>(a, io, b, sm, rho_b, rs_pass, rs_done)) tail_export(a, io, b, rho_b, rs_pass, rs_done, park);
+        b = a.perm ? a.perm[wg] : wg;
+        rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+        rs_pass = 0; rs_done = 0;
+        io = io_of(a);
+        again = setup1_pass<N, MAXS, true, false, false, 1>(a, io, b, sm, rho_b, rs_pass, rs_done);
     }
+    if (!again) return;
+    // at a mark, unconverged: hand the QP to the next launch on the stream -- or, when the list has no room left (or nothing comes behind a flush), run the
+    // passes it has left in place, as the restart kernel does (the strip is in place by now in both arms).  Same passes, same arithmetic either way.
+    if constexpr (!FLUSH) { if (tail_export(a, io, b, rho_b, rs_pass, rs_done, park)) return; }
+    while (again) again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
 }
 
 }  // namespace srbdqp

@@ -184,7 +184,9 @@ class BatchMPC:
 
     def flush(self, stream=0):
         """FLAG_DEFER_TAIL: enqueue the continuations no later solve has picked up (srbdqp_flush); stream = a hipStream_t address, 0 = every
-        stream this engine has launched on.  Does not synchronise."""
+        stream this engine has launched on.  Does not synchronise.  Until the flush has completed in stream order the device arrays of the earlier
+        solve_device() calls -- their OUTPUTS and their INPUTS (a continuation rebuilds its QP from the pointers of the launch it came from) -- must
+        stay untouched (include/srbdqp.h, SRBDQP_FLAG_DEFER_TAIL)."""
         _lib.check(self._lib.srbdqp_flush(self._h, C.c_void_p(int(stream)) if stream else None), self._h)
 
     # -- low-latency staged API (small batches; the single-robot control loop) --------------------------
@@ -370,7 +372,8 @@ class RaggedMPC:
 
     def flush(self, stream=0):
         """flags=FLAG_DEFER_TAIL: make `stream` (0 = the object's own) wait for the restart passes still running on the buckets' tail streams
-        (srbdqp_ragged_flush).  Does not synchronise."""
+        (srbdqp_ragged_flush).  Does not synchronise.  The input and output arrays of the earlier solve_device() calls must stay untouched until the
+        flush has completed in stream order (the passes read the former and write the latter)."""
         self._check(self._lib.srbdqp_ragged_flush(self._h, C.c_void_p(int(stream)) if stream else None))
 
     def solve(self, problems):
@@ -403,11 +406,11 @@ class RaggedMPC:
 class MPC:
     """Drop-in for ``srbd_mpc.mpc.MPC`` on the hot path (run_simulation.py:169-170,73-82,96,103,106)."""
 
-    def __init__(self, dt: float = 0.04, horizon: int = 10, device: int = 0, warm_start: bool = False, strict: bool = True,
-                 **overrides):
-        """warm_start=True starts every solve from the previous plan and duals shifted by one step.  Off by default: on
-        this problem it does not shorten the solve (the dual residual, not the starting point, sets the iteration
-        count -- DESIGN.md section 2) and the extra staging traffic costs ~13 us per call.
+    def __init__(self, dt: float = 0.04, horizon: int = 10, device: int = 0, strict: bool = True, **overrides):
+        """Every solve starts from zero.  (Rounds 1-4 had `warm_start=True`: the previous plan and duals shifted by one step.  Removed in round 5 -- on this
+        ADMM (sigma -> 0, alpha = 1.6) an error of the starting point decays by |1 - alpha| = 0.6 per iteration whatever else happens, and the dual residual
+        sees it through P: the shifted plan is 0.2 |x*| from the new optimum but ~400 |q| from it through P (zero: 1 |q|), i.e. log(400) / log(1 / 0.6) = 12
+        iterations WORSE than zero: 41 against 30 on closed loops, profiles/r05_warm_start_sweep.txt, DESIGN.md section 2.  The C-ABI keeps warm_u / warm_y.)
         strict=True (default): a solve that ends with a negative status (SRBDQP_NUMERICAL, SRBDQP_CONTACT_BOUND: the kernel
         returned all-zero forces) raises SrbdqpError instead of handing zeros to the WBID step; a solve that stops at the
         iteration cap (SRBDQP_MAX_ITER) returns its best iterate with a RuntimeWarning.  strict=False returns whatever came
@@ -419,13 +422,14 @@ class MPC:
         self.x0[12] = self.g
         self.x_ref_hor = np.zeros((self.HORIZON_LENGTH, NX))
         self.x_ref_hor[:, 12] = self.g
-        self.warm_start = bool(warm_start)
+        if "warm_start" in overrides:
+            raise TypeError("MPC(warm_start=...) was removed in round 5: a shift-based start costs this ADMM 10 iterations instead of saving any "
+                            "(profiles/r05_warm_start_sweep.txt); BatchMPC.solve(warm_u=, warm_y=) remains for callers with a better start")
         self.strict = bool(strict)
         self.solve_time = 0.0                   # seconds spent in the last solve (the node's solve-time statistic)
         self._device = device
         self._overrides = overrides
         self._engine: Optional[BatchMPC] = None
-        self._warm = False
         self._u_opt = None
         self._x_opt = None
         self._status = 0
@@ -503,9 +507,8 @@ class MPC:
         use_pcom = p_com_horizon is not None
         if use_pcom:
             st["pcom"][0] = np.asarray(p_com_horizon, dtype=np.float64).reshape(N, 3)
-        use_warm = self.warm_start and self._warm
         t0 = time.perf_counter()
-        eng.solve_staged(1, use_pcom=use_pcom, use_warm=use_warm, want_x=True, want_y=self.warm_start)
+        eng.solve_staged(1, use_pcom=use_pcom, use_warm=False, want_x=True, want_y=False)
         self.solve_time = time.perf_counter() - t0
         self._status = int(st["status"][0])
         self._iters = int(st["iters"][0])
@@ -513,16 +516,6 @@ class MPC:
             self._not_solved(self._status, self._iters, 4)
         self._u_opt = st["u"][0].copy()
         self._x_opt = st["x"][0].copy()
-        if self.warm_start and self._status in (_lib.SOLVED, _lib.MAX_ITER):
-            # shift the plan one step: next call's u_k starts from this call's u_{k+1}; written in place for the next call
-            wu = st["warm_u"][0].reshape(N, NU)
-            wu[:-1] = self._u_opt[1:]; wu[-1] = self._u_opt[-1]
-            y = st["y"][0].reshape(N, _lib.ROWS_PER_STEP)
-            wy = st["warm_y"][0].reshape(N, _lib.ROWS_PER_STEP)
-            wy[:-1] = y[1:]; wy[-1] = y[-1]
-            self._warm = True
-        else:
-            self._warm = False
         return self._u_opt, self._x_opt
 
     def _not_solved(self, status, iters, stacklevel):
@@ -531,7 +524,6 @@ class MPC:
         if not self.strict:
             return
         if status < 0:
-            self._warm = False
             raise SrbdqpError(f"MPC solve failed with status {status} "
                               f"({'non-finite inputs or a singular contact geometry' if status == _lib.NUMERICAL else 'more stance contacts in a step than max_contacts_per_step'}); "
                               "the kernel returned zero forces")
@@ -568,7 +560,6 @@ class MPC:
         if self._status != _lib.SOLVED:
             self._not_solved(self._status, self._iters, 3)
         self._u_opt, self._x_opt = st["u"][0].copy(), st["x"][0].copy()
-        self._warm = False
         return self._u_opt[0].reshape(NU, 1).copy(), (self._x_opt.copy() if one_rollout else self._x_opt[:2].copy())
 
     def update(self, contact_horizon: Sequence, c_horizon: Sequence, p_com_horizon, x_current=None,
@@ -581,9 +572,7 @@ class MPC:
         lists (two np.concatenate of N small arrays: ~2.4 us of ~4.5 us in total); (N, 12) / (N, 4) arrays instead of lists cost
         ~2 us less."""
         upd = self._upd
-        if upd is None or self.warm_start:
-            if self.warm_start:
-                return self._update_general(contact_horizon, c_horizon, p_com_horizon, x_current, one_rollout)
+        if upd is None:
             upd = self._bind()
         try:
             x_cur = self.x0 if x_current is None else x_current
@@ -623,9 +612,6 @@ class MPC:
         u_opt0 = u[0].reshape(NU, 1).copy()
         x_opt1 = x.copy() if one_rollout else x[:2].copy()
         return u_opt0, x_opt1
-
-    def reset_warm_start(self):
-        self._warm = False
 
     def close(self):
         self._upd = None

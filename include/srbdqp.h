@@ -62,7 +62,12 @@ extern "C" {
                                      same results; the outputs of such a QP (about 4 % of a configs[1] batch) arrive later: its status[] reads
                                      SRBDQP_PENDING (one-wave kernel) or SRBDQP_MAX_ITER (the others: the pass it ended) until then, and
                                      srbdqp_flush() completes / waits for what is left.  A caller must not read a solve's outputs, nor hand its
-                                     output arrays to another solve, before the flush.  For pipelines of independent batches; see srbdqp_flush */
+                                     output arrays to another solve, before the flush.  The same holds for the solve's INPUT arrays (x0, x_ref, foot,
+                                     contact, pcom, warm_u, warm_y): a continuation rebuilds its QP from the pointers of the launch it came from, one or
+                                     two launches later, and the restart passes on the tail stream re-read them -- every input array of a deferred
+                                     solve must stay unmodified until srbdqp_flush / srbdqp_ragged_flush has completed in stream order (a receding-horizon
+                                     caller that overwrites its inputs for the next step first gets continuations of a QP that is half old, half new,
+                                     with no error).  For pipelines of independent batches in their own buffers; see srbdqp_flush */
 #define SRBDQP_FLAG_NO_SPIN 2     /* srbdqp_solve_staged_f64: wait with hipStreamSynchronize instead of spinning on the
                                      completion word the kernel writes to host memory */
 
@@ -241,7 +246,7 @@ int srbdqp_solve_ragged_f64(srbdqp_ragged* r, int32_t B, const int32_t* N_per_qp
                             double* u_out, double* x_out, int32_t* status, int32_t* iters);
 /* cfg.flags & SRBDQP_FLAG_DEFER_TAIL at srbdqp_ragged_create: the restart passes of a bucket run on the bucket's own tail stream behind its first pass -- the
  * caller's stream waits for the first passes only, the passes run beside what it enqueues next (e.g. the next call: every shared array exists three times, in
- * rotation).  srbdqp_ragged_flush makes `stream` (NULL = the object's own) wait for the passes still running; before it the outputs of the QPs a first pass left
+ * rotation).  The call's input AND output arrays must stay untouched until the flush has completed in stream order (the passes read the former, write the latter).  srbdqp_ragged_flush makes `stream` (NULL = the object's own) wait for the passes still running; before it the outputs of the QPs a first pass left
  * at its cap (status SRBDQP_MAX_ITER at that point) are not final.  A no-op without the flag.  The host-buffer entry points flush by themselves. */
 int srbdqp_ragged_flush(srbdqp_ragged* r, void* stream);
 /* The same two calls with fp32 buffers and fp32 ADMM iterations (as srbdqp_solve_batch_device_f32 / _f32; every bucket factors
@@ -277,8 +282,8 @@ int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev,
  * launched on) left for later -- the one-wave kernel's continuations that no later solve has picked up (one launch of the
  * continuations alone, enqueued on that stream, in which every such QP runs all the passes it has left), and the restart passes running on the library's own tail stream (the
  * stream is made to wait for them through an event).  Returns without synchronising; after it every output of every earlier solve on
- * that stream is complete in stream order.  A no-op without the flag or with nothing pending.  srbdqp_synchronize() flushes the
- * handle's own stream first. */
+ * that stream is complete in stream order -- and only then may the INPUT arrays of those solves be overwritten (SRBDQP_FLAG_DEFER_TAIL above).
+ * A no-op without the flag or with nothing pending.  srbdqp_synchronize() flushes the handle's own stream first. */
 int srbdqp_flush(srbdqp_handle* h, void* stream);
 
 /* Low-latency path for small batches (the single-robot control loop, B = 1): the library owns pinned, GPU-mapped host

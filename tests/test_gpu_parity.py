@@ -135,11 +135,13 @@ def test_contact_bound_and_empty_contact_set(torch_first, built_lib):
 
 def test_mpc_update_drop_in_path(torch_first, built_lib):
     """The reference caller's sequence (g1_mujoco_sim/src/run_simulation.py:73-111) through MPC.update(): shapes of
-    what comes back, parity with the oracle, and warm starting across consecutive control steps."""
+    what comes back, parity with the oracle, and a second control step from the predicted state."""
     from g1_locomotion_amd import mpc
     N = 10
     x0, xr, ft, ct = (a[0] for a in orc.synthetic_batch(1, N, seed=55, schedule="double"))
-    MPC = mpc.MPC(dt=0.04, warm_start=True)
+    with pytest.raises(TypeError):
+        mpc.MPC(dt=0.04, warm_start=True)               # removed in round 5 (profiles/r05_warm_start_sweep.txt)
+    MPC = mpc.MPC(dt=0.04)
     MPC.init_matrices()
     MPC.x0[:] = x0.reshape(13, 1)
     MPC.x_ref_hor[:] = xr
@@ -152,7 +154,7 @@ def test_mpc_update_drop_in_path(torch_first, built_lib):
     assert MPC.status == ref["status"] == orc.STATUS_SOLVED
     assert np.abs(u_opt0.flatten() - ref["u"][0]).max() <= TOL_TWIN_N
     assert np.abs(x_opt1 - ref["x"]).max() <= 1e-5
-    # next control step: same scene, state moved to the predicted one, plan and duals shifted by one step (warm start)
+    # next control step: same scene, state moved to the predicted one
     MPC.x0[:] = x_opt1[1].reshape(13, 1)
     u2, _ = MPC.update(contact_horizon, c_horizon, p_com_horizon, x_current=MPC.x0, one_rollout=False)
     assert MPC.status == orc.STATUS_SOLVED
@@ -472,7 +474,7 @@ def test_rho_restart_on_the_staged_batch1_path(torch_first, built_lib):
     hard = [b for b in range(400) if refs[b]["iters"] > 100][:4]
     easy = [b for b in range(400) if refs[b]["iters"] <= 40][:2]
     assert len(hard) >= 2
-    MPC = mpc.MPC(dt=0.04, warm_start=False, rho_restart_iter=100)
+    MPC = mpc.MPC(dt=0.04, rho_restart_iter=100)
     MPC.init_matrices()
     for b in hard + easy + hard:
         MPC.x_ref_hor[:] = xr[b]
@@ -950,7 +952,10 @@ def test_assembly_of_a_flight_phase_qp(torch_first, built_lib, kernel):
     assert np.all(got["P"][1] == 0.0) and np.all(got["q"][1] == 0.0)
 
 
-@pytest.mark.parametrize("N,every,count,schedule,B", [(10, 0, 0, "single", 4096), (10, 25, 3, "single", 1024), (8, 30, 2, "single", 1024), (4, 25, 3, "double", 512)])
+# (the last case: restart marks every 5 iterations, so nearly every QP of a 32,768-QP launch continues -- far more records than a list holds (a quarter of the
+#  largest launch, round 5): the QPs that find their list full run their remaining passes in place, with the same results)
+@pytest.mark.parametrize("N,every,count,schedule,B", [(10, 0, 0, "single", 4096), (10, 25, 3, "single", 1024), (8, 30, 2, "single", 1024), (4, 25, 3, "double", 512),
+                                                      (4, 5, 3, "single", 32768)])
 def test_deferred_tails_equal_the_restart_in_place(torch_first, built_lib, N, every, count, schedule, B):
     """SRBDQP_FLAG_DEFER_TAIL: a QP that reaches a restart mark unconverged rides in the next solve on the stream instead of holding its own launch up.  Same
     passes, same arithmetic: after srbdqp_flush() every status, iteration count, force and state equals the restart in place, batch by batch -- over a
@@ -1005,6 +1010,39 @@ def test_deferred_tails_equal_the_restart_in_place(torch_first, built_lib, N, ev
         for j, (o, r) in enumerate(zip(outs, ref_outs)):
             assert torch.equal(o["st"], r["st"]) and torch.equal(o["it"], r["it"]), (j, streams, hint)
             assert float((o["u"] - r["u"]).abs().max()) <= 1e-9 and float((o["x"] - r["x"]).abs().max()) <= 1e-11, (j, float((o["u"] - r["u"]).abs().max()))
+
+
+def test_deferred_tails_at_n4_without_a_contact_bound(torch_first, built_lib):
+    """Advisor, round 4: with max_contacts_per_step = 0 (the default) the device API runs N = 4 on <4, 4>, and srbdqp_flush / srbdqp_synchronize / the
+    host-buffer auto-flush used to continue its records on <4, 2> -- a QP with more than two stance contacts in a step then came back
+    SRBDQP_CONTACT_BOUND with zero forces.  One instantiation for every defer launch and flush at N = 4 now: double-support QPs left pending by the LAST
+    launch (only the flush can finish them) equal the restart in place, through the device API and through host-buffer calls whose contact scans
+    alternate between 2 and 4."""
+    torch = torch_first
+    from g1_locomotion_amd import BatchMPC, _lib
+    dev = torch.device("cuda", 0)
+    N, B = 4, 512
+    kw = dict(kernel=_lib.KERNEL_WAVE, rho_restart_iter=25, rho_restart_count=3)          # max_contacts_per_step left at 0
+    dbl = orc.synthetic_batch(B, N, seed=4401, schedule="double")
+    sgl = orc.synthetic_batch(B, N, seed=4402, schedule="single")
+    with BatchMPC(horizon=N, **kw) as eng:
+        ref_d, ref_s = eng.solve(*dbl), eng.solve(*sgl)
+    assert (ref_d["iters"] > 25).sum() >= 4 and (ref_d["status"] > 0).all()
+    with BatchMPC(horizon=N, flags=_lib.FLAG_DEFER_TAIL, **kw) as eng:
+        d = [torch.from_numpy(v).to(dev) for v in dbl]
+        u = torch.zeros((B, N, 12), dtype=torch.float64, device=dev)
+        st = torch.full((B,), -77, dtype=torch.int32, device=dev); it = torch.zeros(B, dtype=torch.int32, device=dev)
+        eng.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), u.data_ptr(), status=st.data_ptr(), iters=it.data_ptr())
+        assert eng.kernel_name() == "wave_defer_f64_n4_s4", eng.kernel_name()
+        eng.synchronize()                                   # flushes the handle's own stream
+        np.testing.assert_array_equal(st.cpu().numpy(), ref_d["status"])
+        np.testing.assert_array_equal(it.cpu().numpy(), ref_d["iters"])
+        assert np.abs(u.cpu().numpy() - ref_d["u"]).max() <= 1e-9
+        for batch, ref in ((sgl, ref_s), (dbl, ref_d), (sgl, ref_s), (dbl, ref_d)):      # host-buffer calls: the scan says 2, 4, 2, 4
+            out = eng.solve(*batch)
+            np.testing.assert_array_equal(out["status"], ref["status"])
+            np.testing.assert_array_equal(out["iters"], ref["iters"])
+            assert np.abs(out["u"] - ref["u"]).max() <= 1e-9
 
 
 def test_status_does_not_depend_on_the_batch_size(torch_first, built_lib):

@@ -86,8 +86,8 @@ def main():
         ks.append(eng.last_kernel_ms() * 1e-3)
     out["kernel_events"] = pct(ks[50:])
     eng.close()
-    for warm in (False, True):
-        mpc = MPC(dt=0.04, horizon=10, warm_start=warm)
+    for warm in (False,):       # (MPC(warm_start=True) was removed in round 5: profiles/r05_warm_start_sweep.txt)
+        mpc = MPC(dt=0.04, horizon=10)
         mpc.init_matrices()
         ts = []
         for i in range(calls + 100):
@@ -103,9 +103,9 @@ def main():
     from g1_locomotion_amd import msgs
     FEET = np.array([[0.0, 0.0645, 0.0], [0.17, 0.0645, 0.0], [0.0, -0.0645, 0.0], [0.17, -0.0645, 0.0]])
     COM = np.array([0.085, 0.0, 0.598])
-    for warm in (False, True):
+    for warm in (False,):
         for standing in (True, False):
-            mpc = MPC(dt=0.04, horizon=10, warm_start=warm)
+            mpc = MPC(dt=0.04, horizon=10)
             mpc.init_matrices()
             real_update = mpc.update
             ts, its = [], []
