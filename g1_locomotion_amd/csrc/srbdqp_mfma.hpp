@@ -185,7 +185,8 @@ struct Diag16Rows {
         }
     }
 };
-template <int K>
+// pivots K .. KEND - 1 (KEND = 16: the whole tile; the low-latency general kernel runs the tile in two halves around a workgroup barrier)
+template <int K, int KEND = 16>
 __device__ __forceinline__ void diag16_pivot(double (&S)[16], double (&R)[16], bool& ok) {
     const double d = mov_newbcast<K>(S[K]);
     ok = ok && (d > 0.0);                         // (a NaN pivot fails the comparison too)
@@ -197,8 +198,8 @@ __device__ __forceinline__ void diag16_pivot(double (&S)[16], double (&R)[16], b
         double nu;
         asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(nu) : "v"(S[K]), "v"(-r));       // -u, two wait states before its first DPP read
         Diag16Rows<K, K + 1>::run(S, R, nu, u, wk);
-        diag16_pivot<K + 1>(S, R, ok);
     }
+    if constexpr (K + 1 < KEND) diag16_pivot<K + 1, KEND>(S, R, ok);
 }
 // tile: 256 doubles of LDS owned by this wave; on return it holds W = L^-1 row-major with the column XOR-swizzled (tile[row * 16 + (col ^ row)]), exact zeros
 // above the diagonal; the return value is the same W in C layout.

@@ -154,7 +154,8 @@ struct WrenchSmem {
     static constexpr bool VPARK = TB == 4 && SRBDQP_WRENCH_VPARK && (o_gv - o_vpr >= 6 * n) && (o_vpc + 6 * n <= o_e4);
     static_assert(!GX_LATE || o_gx == o_vpr + 6 * n, "fp32 tiles: G x^0 right behind the parked V rows");
     static constexpr int o_pre = cmax(endA, cmax(endB, endC2));   // low-latency instantiation: the scratch tile of the diagonal tile that is inverted beside the assembly (the tile store still holds tables then)
-    static constexpr int o_end = o_pre + (XW > 0 ? 256 : 0);
+    static constexpr int o_hand = o_pre + (XW > 0 ? 256 : 0);   // ... and, with the tile phases pipelined (XW = 2, below), the two tiles assembled for wave 0 by waves 1 and 3
+    static constexpr int o_end = o_hand + (XW == 2 ? 512 : 0);
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr int lds_wgs = wgs_of(o_end);
 };
@@ -403,6 +404,213 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
     }
     asm volatile("" ::: "memory");
     return xt;
+}
+
+// ---- the tile phases of the low-latency instantiation as ONE static pipeline on four waves (round 5) -------------------------------------------------------
+// A batch-1 solve has the CU to itself: what counts is the CHAIN of the factorisation -- invert diagonal tile j, form the one panel tile (j, j + 1), take its
+// square off diagonal tile j + 1, invert that -- not the work.  Phases F, W, I one after the other were 29 k cycles of a 119 k solve (F 18.8 k: per block
+// column an inversion, a barrier, the panels, a barrier and the owner's share of the trailing updates; then W 5.0 k and I 5.2 k, block row by block row with two
+// barriers each).  Here wave j inverts diagonal tile (j, j) and owns the tile above it, (j - 1, j), so a block column costs the chain
+//     t1(J)    the panel U_J,J+1 = L_JJ^-1 T_J,J+1 and D_J+1 -= U'U straight from the owner's registers (an accumulator register is at once the A and the
+//              B operand of that product), beside the other waves' panels                                                              -> barrier B
+//     t2(J)    the inversion of diagonal tile J + 1, in two halves around barrier M                                                     -> barrier A
+// and everything else rides under the inversions, on the three waves that are not inverting: the trailing updates of column J and the closing product of
+// block row J of W = L^-1 in front of M (res = -W_JJ o, o formed one column earlier); o of block row J + 1 and term J of T^-1 = W'W behind it.  A 16 x 16 x 16
+// product is four v_mfma_f64_16x16x4 of 64 cycles each on the wave's SIMD, so the schedule is STATIC -- one straight-line block per (wave, column), no loop, no
+// runtime tile tables: the loads of a block's products are in flight together and the MFMAs run back to back -- and balanced: at most four products per wave
+// behind an M, against the ~1.6 k cycles the second half of an inversion lasts.  (A first version with a loop over the columns and run-time ownership tables
+// spent 500 - 800 cycles per product and left 1 - 1.3 k cycles per column exposed: F + W + I 23.5 k; tools/latp_stamps.py.)
+//   F tiles (accumulators):   wave 0: (0,0) (0,2) (1,3)    wave 1: (1,1) (0,1)    wave 2: (2,2) (1,2) (0,3)    wave 3: (3,3) (2,3)
+//   W tiles (o -> res):       row 1: (0,1) wave 0;   row 2: (0,2) wave 0, (1,2) wave 1;   row 3: (2,3) wave 0, (1,3) wave 1, (0,3) wave 2
+//   T^-1 tiles (accumulators): wave 0: (0,0) (0,2) (1,2)    wave 1: (0,1) (1,1)    wave 2: (2,2) (3,3)    wave 3: (0,3) (1,3) (2,3)
+// NTC = number of 16 x 16 block columns (the schedule of fewer columns is the same one without the tiles that do not exist).  Same products, same operand order
+// as the phases of the batch instantiations: the tiles of T^-1 agree to rounding.  The slots of the tile store hold, in turn, U_ab, W_b<-a and T^-1_ab.
+#ifndef SRBDQP_LATP_SPLIT
+#define SRBDQP_LATP_SPLIT 5
+#endif
+#ifdef SRBDQP_LATP_STAMPS   // (diagnostic builds: when wave w arrives at a join of the set-up -- rows 1 + w of the stamp buffer of a B = 1 solve)
+#define WAVE_ARRIVE(a, w, lane, i) do { if ((a).stamps && (a).B == 1 && (lane) == 0 && (w) < 4) (a).stamps[16 * (1 + (w)) + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WAVE_ARRIVE(a, w, lane, i) do { } while (0)
+#endif
+#ifdef SRBDQP_LATP_STAMPS   // diagnostic builds: when each wave ARRIVES at the barriers of the pipeline (rows 1 + wave of the stamp buffer of a B = 1 solve; tools/latp_stamps.py)
+#define LBAR(i) do { if (stamps && lane == 0) stamps[16 * (1 + W) + (i)] = (long long)__builtin_amdgcn_s_memtime(); __syncthreads(); } while (0)
+#else
+#define LBAR(i) __syncthreads()
+#endif
+template <int W, int NTC>
+__device__ __forceinline__ void latp_run(double* T, v4d& acc0, v4d& acc1, v4d& acc2, double* misc, const int lane, long long* stamps) {
+    (void)stamps;
+    constexpr int KSPLIT = SRBDQP_LATP_SPLIT;
+    const int mcol = lane & 15, kq = lane >> 4;
+    const v4d zero4 = (v4d){0.0, 0.0, 0.0, 0.0};
+    auto TL = [&](int a_, int b_) __attribute__((always_inline)) -> double* { return T + tile_id(a_, b_) * 256; };
+    // o = sign * Wjj * reg   (Wjj = L_jj^-1 from its swizzled slot; reg = a C-layout register tile: register r is the B operand of K-step r)      panel, closing product of a W tile
+    auto p_dinv_reg = [&](const double* D, const v4d& reg, const double sign) __attribute__((always_inline)) -> v4d {
+        v4d o = zero4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kq + 4 * r;
+            double av = D[mcol * 16 + (k ^ mcol)];
+            av = (k <= mcol) ? sign * av : 0.0;
+            o = mma16(av, reg[r], o);
+        }
+        return o;
+    };
+    // acc += sign * A' B, both row-major tiles of the store                                                                                    trailing update, W'W term, U W term
+    auto p_at_b = [&](v4d& acc, const double* A, const double* B, const double sign) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int k = 4 * r + kq; acc = mma16(sign * A[k * 16 + mcol], B[k * 16 + mcol], acc); }
+    };
+    // acc += A' Wjj (A row-major tile, or null: Wjj' Wjj)                                                                                      first product of a W tile, last-row term of T^-1
+    auto p_at_d = [&](v4d& acc, const double* A, const double* D) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * r + kq;
+            double dv = D[k * 16 + (mcol ^ k)];
+            dv = (mcol <= k) ? dv : 0.0;
+            const double av = A ? A[k * 16 + mcol] : dv;
+            acc = mma16(av, dv, acc);
+        }
+    };
+    auto p_reg_sq = [&](v4d& acc, const v4d& reg) __attribute__((always_inline)) {      // acc -= reg' reg from registers
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mma16(-reg[r], reg[r], acc);
+    };
+    double dS[16], dR[16];
+    bool dok = true;
+    auto inv_first = [&](double* slot) __attribute__((always_inline)) {     // the raw diagonal tile is in its slot (this wave's own store, complete behind barrier B)
+        const int col = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dS[i] = slot[i * 16 + col]; dR[i] = (i == col) ? 1.0 : 0.0; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        diag16_pivot<0, KSPLIT>(dS, dR, dok);
+    };
+    auto inv_second = [&](double* slot) __attribute__((always_inline)) {
+        diag16_pivot<KSPLIT, 16>(dS, dR, dok);
+        const int col = lane & 15;
+        if ((lane >> 4) == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) slot[i * 16 + (col ^ i)] = dR[i];
+        }
+        if (!dok && lane == 0) misc[0] = 1.0;
+    };
+    // panel of this wave's super-diagonal tile, its square off the wave's diagonal tile, the diagonal tile into its slot for the inversion
+    auto chain_t1 = [&](int j) __attribute__((always_inline)) {
+        acc1 = p_dinv_reg(TL(j, j), acc1, 1.0);
+        store_tile_t<double, false>(TL(j, j + 1), acc1, lane);
+        p_reg_sq(acc0, acc1);
+        store_tile_t<double, false>(TL(j + 1, j + 1), acc0, lane);
+    };
+    v4d i0 = zero4, i1 = zero4, i2 = zero4, wo = zero4;
+    LBAR(0);                                                     // A0: the inverse of tile (0, 0) is in the store
+    // ================================ column 0
+    if constexpr (NTC > 1) {
+        if constexpr (W == 0 && NTC > 2) { acc1 = p_dinv_reg(TL(0, 0), acc1, 1.0); store_tile_t<double, false>(TL(0, 2), acc1, lane); }
+        if constexpr (W == 1) chain_t1(0);
+        if constexpr (W == 2 && NTC > 3) { acc2 = p_dinv_reg(TL(0, 0), acc2, 1.0); store_tile_t<double, false>(TL(0, 3), acc2, lane); }
+        LBAR(1);                                                 // B0
+    }
+    if constexpr (NTC > 1 && W == 1) inv_first(TL(1, 1));
+    else {
+        if constexpr (W == 0 && NTC > 3) p_at_b(acc2, TL(0, 1), TL(0, 3), -1.0);
+        if constexpr (W == 2 && NTC > 2) { p_at_b(acc1, TL(0, 1), TL(0, 2), -1.0); p_at_b(acc0, TL(0, 2), TL(0, 2), -1.0); }
+        if constexpr (W == 3 && NTC > 3) { p_at_b(acc1, TL(0, 2), TL(0, 3), -1.0); p_at_b(acc0, TL(0, 3), TL(0, 3), -1.0); }
+    }
+    LBAR(2);                                                     // M0
+    if constexpr (NTC > 1 && W == 1) inv_second(TL(1, 1));
+    else if constexpr (W == 0) {
+        if constexpr (NTC > 1) p_at_d(wo, TL(0, 1), TL(0, 0));
+        p_at_d(i0, nullptr, TL(0, 0));
+    }
+    LBAR(3);                                                     // A1
+    // ================================ column 1
+    if constexpr (NTC > 1) {
+        if constexpr (NTC > 2) {
+            if constexpr (W == 0 && NTC > 3) { acc2 = p_dinv_reg(TL(1, 1), acc2, 1.0); store_tile_t<double, false>(TL(1, 3), acc2, lane); }
+            if constexpr (W == 2) chain_t1(1);
+            LBAR(4);                                             // B1
+        }
+        if constexpr (NTC > 2 && W == 2) inv_first(TL(2, 2));
+        else {
+            if constexpr (W == 0) { const v4d res = p_dinv_reg(TL(1, 1), wo, -1.0); store_tile_t<double, false>(TL(0, 1), res, lane); }
+            if constexpr (W == 3 && NTC > 3) { p_at_b(acc1, TL(1, 2), TL(1, 3), -1.0); p_at_b(acc0, TL(1, 3), TL(1, 3), -1.0); }
+        }
+        LBAR(5);                                                 // M1
+        if constexpr (NTC > 2 && W == 2) inv_second(TL(2, 2));
+        else {
+            if constexpr (W == 0) {
+                if constexpr (NTC > 2) { wo = zero4; p_at_d(wo, TL(0, 2), TL(0, 0)); p_at_b(wo, TL(1, 2), TL(0, 1), 1.0); }
+                p_at_b(i0, TL(0, 1), TL(0, 1), 1.0);
+            }
+            if constexpr (W == 1) {
+                if constexpr (NTC > 2) p_at_d(wo, TL(1, 2), TL(1, 1));
+                p_at_d(i0, TL(0, 1), TL(1, 1));
+                p_at_d(i1, nullptr, TL(1, 1));
+            }
+        }
+        LBAR(6);                                                 // A2
+    }
+    // ================================ column 2
+    if constexpr (NTC > 2) {
+        if constexpr (NTC > 3) {
+            if constexpr (W == 3) chain_t1(2);
+            LBAR(7);                                             // B2
+        }
+        if constexpr (NTC > 3 && W == 3) inv_first(TL(3, 3));
+        else {
+            if constexpr (W == 0) { const v4d res = p_dinv_reg(TL(2, 2), wo, -1.0); store_tile_t<double, false>(TL(0, 2), res, lane); }
+            if constexpr (W == 1) { const v4d res = p_dinv_reg(TL(2, 2), wo, -1.0); store_tile_t<double, false>(TL(1, 2), res, lane); }
+        }
+        LBAR(8);                                                 // M2
+        if constexpr (NTC > 3 && W == 3) inv_second(TL(3, 3));
+        else {
+            if constexpr (W == 0) {
+                if constexpr (NTC > 3) { wo = zero4; p_at_d(wo, TL(2, 3), TL(2, 2)); }
+                p_at_b(i0, TL(0, 2), TL(0, 2), 1.0);
+                p_at_d(i1, TL(0, 2), TL(2, 2));
+                p_at_d(i2, TL(1, 2), TL(2, 2));
+            }
+            if constexpr (W == 1) {
+                if constexpr (NTC > 3) { wo = zero4; p_at_d(wo, TL(1, 3), TL(1, 1)); p_at_b(wo, TL(2, 3), TL(1, 2), 1.0); }
+                p_at_b(i0, TL(0, 2), TL(1, 2), 1.0);
+                p_at_b(i1, TL(1, 2), TL(1, 2), 1.0);
+            }
+            if constexpr (W == 2) {
+                if constexpr (NTC > 3) { p_at_d(wo, TL(0, 3), TL(0, 0)); p_at_b(wo, TL(1, 3), TL(0, 1), 1.0); p_at_b(wo, TL(2, 3), TL(0, 2), 1.0); }
+                p_at_d(i0, nullptr, TL(2, 2));
+            }
+        }
+        LBAR(9);                                                 // A3
+    }
+    // ================================ column 3
+    if constexpr (NTC > 3) {
+        if constexpr (W == 0) { const v4d res = p_dinv_reg(TL(3, 3), wo, -1.0); store_tile_t<double, false>(TL(2, 3), res, lane); }
+        if constexpr (W == 1) { const v4d res = p_dinv_reg(TL(3, 3), wo, -1.0); store_tile_t<double, false>(TL(1, 3), res, lane); }
+        if constexpr (W == 2) { const v4d res = p_dinv_reg(TL(3, 3), wo, -1.0); store_tile_t<double, false>(TL(0, 3), res, lane); }
+        LBAR(10);                                                 // M3
+        if constexpr (W == 0) { p_at_b(i0, TL(0, 3), TL(0, 3), 1.0); p_at_b(i1, TL(0, 3), TL(2, 3), 1.0); p_at_b(i2, TL(1, 3), TL(2, 3), 1.0); }
+        if constexpr (W == 1) { p_at_b(i0, TL(0, 3), TL(1, 3), 1.0); p_at_b(i1, TL(1, 3), TL(1, 3), 1.0); }
+        if constexpr (W == 2) { p_at_b(i0, TL(2, 3), TL(2, 3), 1.0); p_at_d(i1, nullptr, TL(3, 3)); }
+        if constexpr (W == 3) { p_at_d(i0, TL(0, 3), TL(3, 3)); p_at_d(i1, TL(1, 3), TL(3, 3)); p_at_d(i2, TL(2, 3), TL(3, 3)); }
+        LBAR(11);                                                 // A4: every read of W is done
+    }
+    // ================================ T^-1 into the store (swizzled, as the half rows are read)
+    if constexpr (W == 0) {
+        store_tile_t<double, true>(TL(0, 0), i0, lane);
+        if constexpr (NTC > 2) { store_tile_t<double, true>(TL(0, 2), i1, lane); store_tile_t<double, true>(TL(1, 2), i2, lane); }
+    }
+    if constexpr (W == 1 && NTC > 1) { store_tile_t<double, true>(TL(0, 1), i0, lane); store_tile_t<double, true>(TL(1, 1), i1, lane); }
+    if constexpr (W == 2 && NTC > 2) { store_tile_t<double, true>(TL(2, 2), i0, lane); if constexpr (NTC > 3) store_tile_t<double, true>(TL(3, 3), i1, lane); }
+    if constexpr (W == 3 && NTC > 3) { store_tile_t<double, true>(TL(0, 3), i0, lane); store_tile_t<double, true>(TL(1, 3), i1, lane); store_tile_t<double, true>(TL(2, 3), i2, lane); }
+    LBAR(12);
+}
+template <int NTC>
+__device__ __forceinline__ void latp_dispatch(const int w, double* T, v4d& acc0, v4d& acc1, v4d& acc2, double* misc, const int lane, long long* stamps) {
+    if (w == 0) latp_run<0, NTC>(T, acc0, acc1, acc2, misc, lane, stamps);
+    else if (w == 1) latp_run<1, NTC>(T, acc0, acc1, acc2, misc, lane, stamps);
+    else if (w == 2) latp_run<2, NTC>(T, acc0, acc1, acc2, misc, lane, stamps);
+    else latp_run<3, NTC>(T, acc0, acc1, acc2, misc, lane, stamps);
 }
 
 // One QP (index b) on one workgroup of NW waves.  TIO = element type of the caller's buffers, R = iteration type.
@@ -932,6 +1140,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             }
         }
     }
+    WAVE_ARRIVE(a, w, lane, 13);
     __syncthreads();
     if constexpr (TSPLIT) gradient_and_warm_start();
     if constexpr (MODE == 1) { if (sm[S::o_misc] != 0.0) { if (t == 0) a.ub_out[(size_t)b * (N + 1) + N] = -1.0; return; } }
@@ -946,9 +1155,24 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // ================= phase H: T = S + E^-1 entry by entry into the C-layout register tiles =================
     const int NT = (n_g + 15) >> 4;
     const int NTT = (NT * (NT + 1)) >> 1;
-    int ta[TS], tb[TS];
+    // Low-latency instantiation on four waves (N = 8, 10: two step waves + two set-up helpers), round 5: the tile phases F / W / I as ONE pipeline around the
+    // chain of diagonal-tile inversions (below).  Wave j owns diagonal tile (j, j) AND the tile above it, (j - 1, j) -- so the next diagonal tile is updated from
+    // its owner's registers and inverted without waiting for anybody -- ; wave 0 also owns (0, 2) and (1, 3), wave 2 (0, 3).  In the assembly wave 0 holds (0, 0)
+    // only (it inverts it beside the other waves' assembly): its two other tiles are assembled by waves 1 and 3 in their free slot and handed over through LDS.
+    constexpr bool LATP = XW == 2 && NW == 4 && sizeof(TT) == 8 && MODE == 0;
+    static_assert(!LATP || (TS <= 3 && S::NT <= 4), "pipelined tile phases: at most 4 x 4 tiles, three slots per wave");
+    constexpr int TSL = LATP ? 3 : TS;                                  // tile slots per wave in these phases
+    int ta[TSL], tb[TSL];
 #pragma unroll
-    for (int s = 0; s < TS; ++s) {
+    for (int s = 0; s < TSL; ++s) {
+        if constexpr (LATP) {
+            int a_ = -1, b_ = -1;
+            if (s == 0) { a_ = w; b_ = w; }
+            else if (s == 1) { if (w >= 1) { a_ = w - 1; b_ = w; } }
+            else { if (w == 1) { a_ = 0; b_ = 2; } else if (w == 2) { a_ = 0; b_ = 3; } else if (w == 3) { a_ = 1; b_ = 3; } }
+            const bool on = b_ >= 0 && b_ < NT;
+            ta[s] = on ? a_ : -1; tb[s] = on ? b_ : -1;
+        } else {
         // (low-latency instantiation: wave 0 owns tile (0, 0) ONLY -- it inverts it beside the other waves' assembly, below -- and the other NW - 1 waves
         // share the rest; with 10 tiles on 4 waves nobody holds more than before)
         constexpr bool LATK = XW > 0 && N <= 10;                       // (N = 24 has set-up helper waves too, in its batch instantiation)
@@ -958,8 +1182,9 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         while (((bb + 1) * (bb + 2)) / 2 <= id) ++bb;
         tb[s] = (id < NTT) ? bb : -1;
         ta[s] = (id < NTT) ? id - (bb * (bb + 1)) / 2 : -1;
+        }
     }
-    v4t acc[TS];
+    v4t acc[TSL];
     {
         // The rank-6 form of srbdqp_common.hpp in the g coordinates: S(r, c) = z_r' [M(j, m), same(j, m)] z_c with M(j, m) = D_m - C_j' E_m, so with a row
         // [z_ang, -C_j z_ang, z_lin] per g coordinate (built once, below) and [D_m z_ang, E_m z_ang, f0, f1] of the lane's column (formed per tile slot) an entry
@@ -995,7 +1220,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < TS; ++s) {
+        for (int s = 0; s < TSL; ++s) {
             acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
             if (ta[s] >= 0) {
                 const int c = 16 * tb[s] + mcol;
@@ -1059,12 +1284,17 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             pre0 = true;
         }
     }
+    if constexpr (LATP) {   // the two tiles assembled for wave 0
+        if (w == 1 && ta[2] >= 0) store_tile_t<TT, false>(sm + S::o_hand, acc[2], lane);
+        if (w == 3 && ta[2] >= 0) store_tile_t<TT, false>(sm + S::o_hand + 256, acc[2], lane);
+    }
     SRBDQP_STAMP(a, b, 3);
+    WAVE_ARRIVE(a, w, lane, 14);
     __syncthreads();
     if constexpr (MODE == 1) {   // assembly dump (tests): T dense [NG][NG], then q[12N], V rows / Bd rows per lane, goff
         double* out = a.P_out + (size_t)b * (S::NG * S::NG);
 #pragma unroll
-        for (int s = 0; s < TS; ++s) {
+        for (int s = 0; s < TSL; ++s) {
             if (ta[s] >= 0) {
                 const int c = 16 * tb[s] + mcol;
 #pragma unroll
@@ -1090,6 +1320,33 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         return;
     } else {
 
+    if constexpr (LATP) {
+    // ================= phases F / W / I as one static pipeline around the chain of diagonal-tile inversions (latp_run, above) =================
+    SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
+    if (w == 0) {   // wave 0 takes over the two tiles waves 1 and 3 assembled for it; its own tile (0, 0) is inverted already
+        const bool on1 = NT > 2, on2 = NT > 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = kq + 4 * q;
+            acc[1][q] = on1 ? sm[S::o_hand + row * 16 + mcol] : 0.0;
+            acc[2][q] = on2 ? sm[S::o_hand + 256 + row * 16 + mcol] : 0.0;
+        }
+        TT* D00 = T;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = kq + 4 * q; D00[row * 16 + (mcol ^ row)] = (TT)winv0[q]; }
+    }
+    {
+        double* misc = sm + S::o_misc;
+        long long* stp = a.stamps;
+        if (S::NT >= 4 && NT >= 4) latp_dispatch<(S::NT >= 4 ? 4 : 3)>(w, T, acc[0], acc[1], acc[2], misc, lane, stp);       // (wave-uniform: every wave of the workgroup takes the same arm, with its barriers)
+        else if (NT == 3) latp_dispatch<3>(w, T, acc[0], acc[1], acc[2], misc, lane, stp);
+        else if (NT == 2) latp_dispatch<2>(w, T, acc[0], acc[1], acc[2], misc, lane, stp);
+        else latp_dispatch<1>(w, T, acc[0], acc[1], acc[2], misc, lane, stp);
+    }
+    SRBDQP_STAMP(a, b, 4);
+    SRBDQP_STAMP(a, b, 5);
+    SRBDQP_STAMP(a, b, 6);
+    } else {
     // ================= phase F: tiled right-looking Cholesky T = U'U, trailing tiles in registers =================
     SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
     for (int j = 0; j < NT; ++j) {
@@ -1098,7 +1355,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             bool mine = false;
             v4t d = acc[0];
 #pragma unroll
-            for (int s = 0; s < TS; ++s)
+            for (int s = 0; s < TSL; ++s)
                 if (ta[s] == j && tb[s] == j) { mine = true; d = acc[s]; }
             if (mine) {
                 int lane_j = lane;
@@ -1124,7 +1381,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < TS; ++s) {
+        for (int s = 0; s < TSL; ++s) {
             if (ta[s] == j && tb[s] > j) {
                 v4t o = (v4t){TT(0), TT(0), TT(0), TT(0)};
 #pragma unroll
@@ -1140,7 +1397,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < TS; ++s) {
+        for (int s = 0; s < TSL; ++s) {
             if (ta[s] > j) {
                 const TT* Ua = T + tile_id(j, ta[s]) * 256;
                 const TT* Ub = T + tile_id(j, tb[s]) * 256;
@@ -1210,7 +1467,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // ================= phase I: T^-1 = W'W =================
     SRBDQP_PHASE_LOCAL("+v"(mcol), "+v"(kq));
 #pragma unroll
-    for (int s = 0; s < TS; ++s) {
+    for (int s = 0; s < TSL; ++s) {
         acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
         if (ta[s] >= 0) {
             const int ia = ta[s], ib = tb[s];
@@ -1239,10 +1496,11 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < TS; ++s)
+    for (int s = 0; s < TSL; ++s)
         if (ta[s] >= 0) store_tile_t<TT, true>(T + tile_id(ta[s], tb[s]) * 256, acc[s], lane);
     __syncthreads();
     SRBDQP_STAMP(a, b, 6);
+    }   // !LATP
 
 #ifndef SRBDQP_WRENCH_REROLE
 #define SRBDQP_WRENCH_REROLE 1

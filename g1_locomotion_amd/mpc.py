@@ -21,6 +21,10 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
+try:                                    # CPython binding of the two batch-1 calls (csrc/fastcall.c, built by __graft_entry__.build()); optional: ctypes otherwise
+    from . import _fastcall
+except ImportError:                     # pragma: no cover
+    _fastcall = None
 from ._lib import NX, NU, NC, SrbdqpError
 
 
@@ -207,10 +211,22 @@ class BatchMPC:
                 pcom=view(st.pcom, d, (cap, N, 3)), warm_u=view(st.warm_u, d, (cap, n)), warm_y=view(st.warm_y, d, (cap, m)),
                 u=view(st.u, d, (cap, N, NU)), x=view(st.x, d, (cap, N + 1, NX)), y=view(st.y, d, (cap, m)),
                 status=view(st.status, i32, (cap,)), iters=view(st.iters, i32, (cap,)))
+            self._fcb = None
+            if _fastcall is not None:       # the same two C entry points through their function pointers (no ctypes trampoline per call)
+                raw = _lib.load_raw()
+                addr = lambda f: C.cast(f, C.c_void_p).value
+                self._fcb = _fastcall.bind(addr(raw.srbdqp_update_f64), addr(raw.srbdqp_solve_staged_f64), self._h.value, N, st.x0, st.x_ref, st.foot,
+                                           st.contact, st.pcom, st.u, st.x, st.status, st.iters)
         return self._stage
 
     def solve_staged(self, B=1, use_pcom=False, use_warm=False, want_x=True, want_y=False):
         """One kernel launch over the first B staged QPs; inputs are read and outputs written in the staging arrays."""
+        fcb = getattr(self, "_fcb", None)
+        if fcb is not None:
+            rc = _fastcall.solve_staged(fcb, int(B), int(use_pcom), int(use_warm), int(want_x), int(want_y))
+            if rc:
+                _lib.check(rc, self._h)
+            return
         _lib.check(self._lib.srbdqp_solve_staged_f64(self._h, int(B), int(use_pcom), int(use_warm), int(want_x), int(want_y)), self._h)
 
     def prepare_staged(self, B=1, use_pcom=False):
@@ -426,7 +442,8 @@ class MPC:
             raise TypeError("MPC(warm_start=...) was removed in round 5: a shift-based start costs this ADMM 10 iterations instead of saving any "
                             "(profiles/r05_warm_start_sweep.txt); BatchMPC.solve(warm_u=, warm_y=) remains for callers with a better start")
         self.strict = bool(strict)
-        self.solve_time = 0.0                   # seconds spent in the last solve (the node's solve-time statistic)
+        self._solve_time = 0.0                  # seconds spent in the last solve (the node's solve-time statistic)
+        self._fcb = None                        # the CPython binding of srbdqp_update_f64 (csrc/fastcall.c), once bound
         self._device = device
         self._overrides = overrides
         self._engine: Optional[BatchMPC] = None
@@ -434,10 +451,16 @@ class MPC:
         self._x_opt = None
         self._status = 0
         self._iters = 0
+        self._last_fc = False                   # ... through the CPython binding (solve_time is read from it)
         self._last_fast = False                 # the last call went through update()'s bound fast path: results are read from the staging arrays
         self._upd = None                        # srbdqp_update_f64 with every argument bound (see _bind)
 
     # outcome of the last call.  The fast path of update() leaves everything in the library's staging arrays and these read it there on demand.
+    @property
+    def solve_time(self) -> float:
+        """seconds inside the library during the last call"""
+        return _fastcall.solve_time(self._fcb) if (self._last_fc and self._fcb is not None) else self._solve_time
+
     @property
     def status(self) -> int:
         return int(self._s_status[0]) if self._last_fast else self._status
@@ -484,6 +507,7 @@ class MPC:
         self._args_pcom = ins + (P(self._s_pcom),) + outs
         self._args_nopcom = ins + (None,) + outs
         self._upd = _lib.load_raw().srbdqp_update_f64
+        self._fcb = getattr(eng, "_fcb", None)
         return self._upd
 
     def solve(self, x_current, x_ref_hor, c_horizon, contact_horizon, p_com_horizon=None):
@@ -491,7 +515,7 @@ class MPC:
         Inputs are written straight into the library's pinned staging arrays (no hipMemcpy on this path)."""
         if self._engine is None:
             self.init_matrices()
-        self._last_fast = False
+        self._last_fast = self._last_fc = False
         eng, N = self._engine, self.HORIZON_LENGTH
         st = eng.stage()
         st["x0"][0] = np.asarray(x_current, dtype=np.float64).reshape(NX)
@@ -509,7 +533,7 @@ class MPC:
             st["pcom"][0] = np.asarray(p_com_horizon, dtype=np.float64).reshape(N, 3)
         t0 = time.perf_counter()
         eng.solve_staged(1, use_pcom=use_pcom, use_warm=False, want_x=True, want_y=False)
-        self.solve_time = time.perf_counter() - t0
+        self._solve_time = time.perf_counter() - t0
         self._status = int(st["status"][0])
         self._iters = int(st["iters"][0])
         if self._status != _lib.SOLVED:
@@ -551,11 +575,11 @@ class MPC:
         """Second phase of prepare(): returns what update() returns, for the measured state x_current (default: self.x0)."""
         eng = self._engine
         st = eng.stage()
-        self._last_fast = False
+        self._last_fast = self._last_fc = False
         st["x0"][0] = np.asarray(self.x0 if x_current is None else x_current, dtype=np.float64).reshape(NX)
         t0 = time.perf_counter()
         eng.solve_prepared(1, want_x=True)
-        self.solve_time = time.perf_counter() - t0
+        self._solve_time = time.perf_counter() - t0
         self._status, self._iters = int(st["status"][0]), int(st["iters"][0])
         if self._status != _lib.SOLVED:
             self._not_solved(self._status, self._iters, 3)
@@ -574,6 +598,18 @@ class MPC:
         upd = self._upd
         if upd is None:
             upd = self._bind()
+        fcb = self._fcb
+        if fcb is not None:                        # csrc/fastcall.c: the lists walked with the C API, straight into the staging arrays, results as fresh arrays
+            r = _fastcall.update(fcb, contact_horizon, c_horizon, p_com_horizon, self.x0 if x_current is None else x_current, self.x_ref_hor, one_rollout)
+            if r is not NotImplemented:            # (anything it does not recognise -- other dtypes, shapes, nested lists -- takes the NumPy path below)
+                u0, x1, st, rc = r
+                self._last_fast = self._last_fc = True
+                if rc:
+                    _lib.check(rc, self._engine._h)
+                if st != 1:                        # (_lib.SOLVED)
+                    self._not_solved(st, int(self._s_iters[0]), 3)
+                return u0, x1
+        self._last_fc = False
         try:
             x_cur = self.x0 if x_current is None else x_current
             try:
@@ -598,7 +634,7 @@ class MPC:
             return self._update_general(contact_horizon, c_horizon, p_com_horizon, x_current, one_rollout)
         t0 = time.perf_counter()
         rc = upd(*args)
-        self.solve_time = time.perf_counter() - t0
+        self._solve_time = time.perf_counter() - t0
         self._last_fast = True
         if rc:
             _lib.check(rc, self._engine._h)
@@ -615,7 +651,7 @@ class MPC:
 
     def close(self):
         self._upd = None
-        self._last_fast = False
+        self._last_fast = self._last_fc = False
         if self._engine is not None:
             self._engine.close()
             self._engine = None
