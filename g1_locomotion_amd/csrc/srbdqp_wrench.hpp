@@ -155,7 +155,9 @@ struct WrenchSmem {
     static_assert(!GX_LATE || o_gx == o_vpr + 6 * n, "fp32 tiles: G x^0 right behind the parked V rows");
     static constexpr int o_pre = cmax(endA, cmax(endB, endC2));   // low-latency instantiation: the scratch tile of the diagonal tile that is inverted beside the assembly (the tile store still holds tables then)
     static constexpr int o_hand = o_pre + (XW > 0 ? 256 : 0);   // ... and, with the tile phases pipelined (XW = 2, below), the two tiles assembled for wave 0 by waves 1 and 3
-    static constexpr int o_end = o_hand + (XW == 2 ? 512 : 0);
+    static constexpr int o_abx = o_hand + (XW == 2 ? 512 : 0);  // ... and the T assembly's row / column tables, built by a set-up helper beside phase E (they overlay live tables in their batch-kernel place)
+    static constexpr int o_bbx = o_abx + (XW == 2 ? 8 * 16 * NT : 0);
+    static constexpr int o_end = o_bbx + (XW == 2 ? 6 * 16 * NT : 0);
     static constexpr size_t bytes = (size_t)o_end * sizeof(double);
     static constexpr int lds_wgs = wgs_of(o_end);
 };
@@ -439,7 +441,7 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
 #define LBAR(i) __syncthreads()
 #endif
 template <int W, int NTC>
-__device__ __forceinline__ void latp_run(double* T, v4d& acc0, v4d& acc1, v4d& acc2, double* misc, const int lane, long long* stamps) {
+__device__ __forceinline__ void latp_run(double* T, const double* D0, v4d& acc0, v4d& acc1, v4d& acc2, double* misc, const int lane, long long* stamps) {
     (void)stamps;
     constexpr int KSPLIT = SRBDQP_LATP_SPLIT;
     const int mcol = lane & 15, kq = lane >> 4;
@@ -497,18 +499,18 @@ __device__ __forceinline__ void latp_run(double* T, v4d& acc0, v4d& acc1, v4d& a
     };
     // panel of this wave's super-diagonal tile, its square off the wave's diagonal tile, the diagonal tile into its slot for the inversion
     auto chain_t1 = [&](int j) __attribute__((always_inline)) {
-        acc1 = p_dinv_reg(TL(j, j), acc1, 1.0);
+        acc1 = p_dinv_reg(j == 0 ? D0 : TL(j, j), acc1, 1.0);
         store_tile_t<double, false>(TL(j, j + 1), acc1, lane);
         p_reg_sq(acc0, acc1);
         store_tile_t<double, false>(TL(j + 1, j + 1), acc0, lane);
     };
     v4d i0 = zero4, i1 = zero4, i2 = zero4, wo = zero4;
-    LBAR(0);                                                     // A0: the inverse of tile (0, 0) is in the store
+    // (no barrier here: the inverse of tile (0, 0) -- D0 -- sits in wave 0's scratch tile since before the barrier that ended the assembly, and is read there)
     // ================================ column 0
     if constexpr (NTC > 1) {
-        if constexpr (W == 0 && NTC > 2) { acc1 = p_dinv_reg(TL(0, 0), acc1, 1.0); store_tile_t<double, false>(TL(0, 2), acc1, lane); }
+        if constexpr (W == 0 && NTC > 2) { acc1 = p_dinv_reg(D0, acc1, 1.0); store_tile_t<double, false>(TL(0, 2), acc1, lane); }
         if constexpr (W == 1) chain_t1(0);
-        if constexpr (W == 2 && NTC > 3) { acc2 = p_dinv_reg(TL(0, 0), acc2, 1.0); store_tile_t<double, false>(TL(0, 3), acc2, lane); }
+        if constexpr (W == 2 && NTC > 3) { acc2 = p_dinv_reg(D0, acc2, 1.0); store_tile_t<double, false>(TL(0, 3), acc2, lane); }
         LBAR(1);                                                 // B0
     }
     if constexpr (NTC > 1 && W == 1) inv_first(TL(1, 1));
@@ -520,8 +522,8 @@ __device__ __forceinline__ void latp_run(double* T, v4d& acc0, v4d& acc1, v4d& a
     LBAR(2);                                                     // M0
     if constexpr (NTC > 1 && W == 1) inv_second(TL(1, 1));
     else if constexpr (W == 0) {
-        if constexpr (NTC > 1) p_at_d(wo, TL(0, 1), TL(0, 0));
-        p_at_d(i0, nullptr, TL(0, 0));
+        if constexpr (NTC > 1) p_at_d(wo, TL(0, 1), D0);
+        p_at_d(i0, nullptr, D0);
     }
     LBAR(3);                                                     // A1
     // ================================ column 1
@@ -540,7 +542,7 @@ __device__ __forceinline__ void latp_run(double* T, v4d& acc0, v4d& acc1, v4d& a
         if constexpr (NTC > 2 && W == 2) inv_second(TL(2, 2));
         else {
             if constexpr (W == 0) {
-                if constexpr (NTC > 2) { wo = zero4; p_at_d(wo, TL(0, 2), TL(0, 0)); p_at_b(wo, TL(1, 2), TL(0, 1), 1.0); }
+                if constexpr (NTC > 2) { wo = zero4; p_at_d(wo, TL(0, 2), D0); p_at_b(wo, TL(1, 2), TL(0, 1), 1.0); }
                 p_at_b(i0, TL(0, 1), TL(0, 1), 1.0);
             }
             if constexpr (W == 1) {
@@ -577,7 +579,7 @@ __device__ __forceinline__ void latp_run(double* T, v4d& acc0, v4d& acc1, v4d& a
                 p_at_b(i1, TL(1, 2), TL(1, 2), 1.0);
             }
             if constexpr (W == 2) {
-                if constexpr (NTC > 3) { p_at_d(wo, TL(0, 3), TL(0, 0)); p_at_b(wo, TL(1, 3), TL(0, 1), 1.0); p_at_b(wo, TL(2, 3), TL(0, 2), 1.0); }
+                if constexpr (NTC > 3) { p_at_d(wo, TL(0, 3), D0); p_at_b(wo, TL(1, 3), TL(0, 1), 1.0); p_at_b(wo, TL(2, 3), TL(0, 2), 1.0); }
                 p_at_d(i0, nullptr, TL(2, 2));
             }
         }
@@ -597,7 +599,7 @@ __device__ __forceinline__ void latp_run(double* T, v4d& acc0, v4d& acc1, v4d& a
     }
     // ================================ T^-1 into the store (swizzled, as the half rows are read)
     if constexpr (W == 0) {
-        store_tile_t<double, true>(TL(0, 0), i0, lane);
+        store_tile_t<double, true>(T, i0, lane);
         if constexpr (NTC > 2) { store_tile_t<double, true>(TL(0, 2), i1, lane); store_tile_t<double, true>(TL(1, 2), i2, lane); }
     }
     if constexpr (W == 1 && NTC > 1) { store_tile_t<double, true>(TL(0, 1), i0, lane); store_tile_t<double, true>(TL(1, 1), i1, lane); }
@@ -606,11 +608,11 @@ __device__ __forceinline__ void latp_run(double* T, v4d& acc0, v4d& acc1, v4d& a
     LBAR(12);
 }
 template <int NTC>
-__device__ __forceinline__ void latp_dispatch(const int w, double* T, v4d& acc0, v4d& acc1, v4d& acc2, double* misc, const int lane, long long* stamps) {
-    if (w == 0) latp_run<0, NTC>(T, acc0, acc1, acc2, misc, lane, stamps);
-    else if (w == 1) latp_run<1, NTC>(T, acc0, acc1, acc2, misc, lane, stamps);
-    else if (w == 2) latp_run<2, NTC>(T, acc0, acc1, acc2, misc, lane, stamps);
-    else latp_run<3, NTC>(T, acc0, acc1, acc2, misc, lane, stamps);
+__device__ __forceinline__ void latp_dispatch(const int w, double* T, const double* D0, v4d& acc0, v4d& acc1, v4d& acc2, double* misc, const int lane, long long* stamps) {
+    if (w == 0) latp_run<0, NTC>(T, D0, acc0, acc1, acc2, misc, lane, stamps);
+    else if (w == 1) latp_run<1, NTC>(T, D0, acc0, acc1, acc2, misc, lane, stamps);
+    else if (w == 2) latp_run<2, NTC>(T, D0, acc0, acc1, acc2, misc, lane, stamps);
+    else latp_run<3, NTC>(T, D0, acc0, acc1, acc2, misc, lane, stamps);
 }
 
 // One QP (index b) on one workgroup of NW waves.  TIO = element type of the caller's buffers, R = iteration type.
@@ -867,8 +869,49 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         return a.s * (J[0] * g[0] + J[12] * g[1] + J[24] * g[2] + SQ[3 + axl] * dt2m * g[3 + axl] + SQ[9 + axl] * dtm * g[6 + axl]);
     };
     if constexpr (TSPLIT) {
+        // ... and, behind its tables, each helper builds one of the two tables of the T assembly (phase H), one g coordinate per lane, HERE: the wrench-space 6-vector
+        // z of a coordinate follows from the contact flags and J alone (phase E writes the same values to ZT for the other users), and D_m / E_m are wave NWS + 1's
+        // own (complete behind its wait) -- so phase H starts with its tiles instead of a table pass and a barrier, and takes a column's [D_m z, E_m z] from the
+        // table instead of forming it per tile slot (round 5: T assembly 7.4 k -> 6.0 k cycles; both helpers still reach the join before the step waves)
+        static_assert(16 * S::NT <= 64, "one g coordinate per lane of a helper wave");
         if (tab_a) gt_tables_wave(sm + S::o_eh);
         if (tab_b) de_tables<N>(CP, T1, T2, SQ, dt2, MT, lane, 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((tab_a || tab_b) && lane < 16 * S::NT) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const int r = lane;
+            const bool on = r < n_g;
+            const int rr = on ? r : 0, j = gstep[rr], l = rr - igoff[j];
+            const int g0 = sct[4 * j], g1 = sct[4 * j + 1], g2 = sct[4 * j + 2], g3 = sct[4 * j + 3];
+            const bool wr = (g0 + g1 + g2 + g3) >= 3;
+            const int want = l / 3, lm = l - 3 * want;
+            int cc = -1, seen = 0;
+            if (g0) { if (seen == want && cc < 0) cc = 0; ++seen; }
+            if (g1) { if (seen == want && cc < 0) cc = 1; ++seen; }
+            if (g2) { if (seen == want && cc < 0) cc = 2; ++seen; }
+            if (g3) { if (seen == want && cc < 0) cc = 3; ++seen; }
+            const int ug = (cc >= 0 ? 3 * cc : 0) + lm;
+            const double* Jj = sm + S::o_J + j * 36;
+            const double z0 = wr ? ((l == 0) ? 1.0 : 0.0) : Jj[ug], z1 = wr ? ((l == 1) ? 1.0 : 0.0) : Jj[12 + ug], z2 = wr ? ((l == 2) ? 1.0 : 0.0) : Jj[24 + ug];
+            if (tab_a) {        // rows: [z_ang, -C_j z_ang, z_lin[(row index) mod 3], (step, offset of the row in the step's E^-1) as one exact integer]
+                const double gl = wr ? ((l >= 3) ? 1.0 : 0.0) : 1.0;
+                const double* C = CP + 9 * j;
+                const double code = on ? (double)(4096 * j + 36 * j + 6 * l) : -4096.0;
+                d2* row = reinterpret_cast<d2*>(sm + S::o_abx + 8 * r);
+                row[0] = on ? (d2){z0, z1} : (d2){0.0, 0.0};
+                row[1] = on ? (d2){z2, -(C[0] * z0 + C[1] * z1 + C[2] * z2)} : (d2){0.0, 0.0};
+                row[2] = on ? (d2){-(C[3] * z0 + C[4] * z1 + C[5] * z2), -(C[6] * z0 + C[7] * z1 + C[8] * z2)} : (d2){0.0, 0.0};
+                row[3] = (d2){on ? gl : 0.0, code};
+            } else {            // columns: s^2 [D_m z_ang, E_m z_ang]
+                const double s2e = a.s * a.s;
+                const double* D = MT + 18 * j;
+                d2* brow = reinterpret_cast<d2*>(sm + S::o_bbx + 6 * r);
+                double bv[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bv[i] = on ? s2e * (D[3 * i] * z0 + D[3 * i + 1] * z1 + D[3 * i + 2] * z2) : 0.0;
+                brow[0] = (d2){bv[0], bv[1]}; brow[1] = (d2){bv[2], bv[3]}; brow[2] = (d2){bv[4], bv[5]};
+            }
+        }
     } else {
         gt_tables(sm + S::o_eh);
         de_tables<N>(CP, T1, T2, SQ, dt2, MT, t, BT);
@@ -1054,49 +1097,72 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 for (int q = 0; q < 3; ++q) Em[3 + q][p] = Em[p][3 + q];
             // (the J entries are read again below rather than kept: 36 doubles per lane across this phase were spilled)
             asm volatile("" ::: "memory");
-            // Cholesky E = L L', Li = L^-1, E^-1 = Li' Li
-            double Lm[6][6], Li[6][6];
-            bool okE = true;
-#pragma unroll
-            for (int p = 0; p < 6; ++p) {
-                double d = Em[p][p];
-#pragma unroll
-                for (int k2 = 0; k2 < p; ++k2) d = fma(-Lm[p][k2], Lm[p][k2], d);
-                okE = okE && (d > 0.0);
-                // (okE reports a non-positive pivot.  rsq + two Newton steps only in the low-latency instantiation, where it shortens the chain; in the batch
-                // instantiations -- 168 registers, three workgroups interleaved -- the library 1 / sqrt was the faster one: N = 10 double support 15.2 against 14.5 M QP/s)
-                double inv;
-                if constexpr (XW > 0) inv = (d > 0.0) ? fast_rsqrt2(d) : 0.0;
-                else inv = 1.0 / sqrt(d);
-                Lm[p][p] = d * inv;
-                Li[p][p] = inv;
-#pragma unroll
-                for (int q = p + 1; q < 6; ++q) {
-                    double v = Em[q][p];
-#pragma unroll
-                    for (int k2 = 0; k2 < p; ++k2) v = fma(-Lm[q][k2], Lm[p][k2], v);
-                    Lm[q][p] = v * inv;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-#pragma unroll
-                for (int r = c + 1; r < 6; ++r) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int k2 = c; k2 < r; ++k2) v = fma(Lm[r][k2], Li[k2][c], v);
-                    Li[r][c] = -v * Li[r][r];
-                }
+            // E^-1 through its structure (round 5): E = [A B; B' G] with G = S D^-1 S' DIAGONAL (S = [I I I I]: the force rows of W), so
+            //     E^-1 = [ Sc^-1, -Sc^-1 B G^-1 ; sym, G^-1 + G^-1 B' Sc^-1 B G^-1 ],   Sc = A - B G^-1 B'   (3 x 3, SPD)
+            // -- a 3 x 3 Cholesky and three reciprocals instead of the 6 x 6 Cholesky + triangular inverse + L^-T L^-1 every lane of the step ran redundantly
+            // (three dependent rsqrt chains instead of six, ~120 instead of ~270 fp64 instructions: 7.8 k -> cycles of the batch-1 set-up were this block).
             double Ei[6][6];
+            bool okE = true;
+            {
+                // G = n_c diag(1 / d_xy, 1 / d_xy, 1 / d_z) with n_c = 3 or 4 stance contacts (a wrench step): its inverse without a division
+                const double inc = ((f0 + f1 + f2 + f3) == 4) ? 0.25 : (1.0 / 3.0);
+                const double ig[3] = {dxy * inc, dxy * inc, dz * inc};
+                double BG[3][3];                                         // B G^-1
 #pragma unroll
-            for (int p = 0; p < 6; ++p)
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int q = p; q < 6; ++q) {
-                    double v = 0.0;
+                    for (int q = 0; q < 3; ++q) BG[p][q] = Em[p][3 + q] * ig[q];
+                double Sc[3][3];
 #pragma unroll
-                    for (int k2 = q; k2 < 6; ++k2) v = fma(Li[k2][p], Li[k2][q], v);
-                    Ei[p][q] = v; Ei[q][p] = v;
-                }
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int q = p; q < 3; ++q) {
+                        double v = Em[p][q];
+#pragma unroll
+                        for (int k2 = 0; k2 < 3; ++k2) v = fma(-BG[p][k2], Em[q][3 + k2], v);
+                        Sc[p][q] = v;
+                    }
+                // Sc = L L' (lower), Li = L^-1
+                auto rs = [&](double d) -> double {
+                    if constexpr (XW > 0) return (d > 0.0) ? fast_rsqrt2(d) : 0.0;
+                    else return 1.0 / sqrt(d);
+                };
+                okE = okE && (Sc[0][0] > 0.0);
+                const double r0 = rs(Sc[0][0]);
+                const double l10 = Sc[0][1] * r0, l20 = Sc[0][2] * r0;
+                const double d1 = fma(-l10, l10, Sc[1][1]);
+                okE = okE && (d1 > 0.0);
+                const double r1 = rs(d1);
+                const double l21 = fma(-l20, l10, Sc[1][2]) * r1;
+                const double d2 = fma(-l21, l21, fma(-l20, l20, Sc[2][2]));
+                okE = okE && (d2 > 0.0);
+                const double r2 = rs(d2);
+                const double m10 = -l10 * r0 * r1;                       // Li[1][0]
+                const double m21 = -l21 * r1 * r2;                       // Li[2][1]
+                const double m20 = -(l20 * r0 + l21 * m10) * r2;         // Li[2][0]
+                double Si[3][3];                                         // Sc^-1 = Li' Li
+                Si[0][0] = fma(r0, r0, fma(m10, m10, m20 * m20)); Si[0][1] = fma(m10, r1, m20 * m21); Si[0][2] = m20 * r2;
+                Si[1][1] = fma(r1, r1, m21 * m21); Si[1][2] = m21 * r2; Si[2][2] = r2 * r2;
+                Si[1][0] = Si[0][1]; Si[2][0] = Si[0][2]; Si[2][1] = Si[1][2];
+                double C12[3][3];                                        // -Sc^-1 B G^-1
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) C12[p][q] = -(Si[p][0] * BG[0][q] + Si[p][1] * BG[1][q] + Si[p][2] * BG[2][q]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { Ei[p][q] = Si[p][q]; Ei[p][3 + q] = C12[p][q]; Ei[3 + q][p] = C12[p][q]; }
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int q = p; q < 3; ++q) {
+                        double v = (p == q) ? ig[p] : 0.0;                 // G^-1 - (B G^-1)' C12
+#pragma unroll
+                        for (int k2 = 0; k2 < 3; ++k2) v = fma(-BG[k2][p], C12[k2][q], v);
+                        Ei[3 + p][3 + q] = v; Ei[3 + q][3 + p] = v;
+                    }
+            }
             if (!okE && stepok && ul == 0) sm[S::o_misc] = 1.0;   // 4 collinear contact points: E singular
             // row rl of E^-1 (select chain: no runtime-indexed register array)
             double er[6];
@@ -1193,8 +1259,12 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const double s2 = a.s * a.s, dt4m2 = dt2m * dt2m, dt2m2 = dtm * dtm;
         const double* ZT = sm + S::o_zt;
         const double* DE = MT;
-        double* AB = sm + S::o_ab;
+        constexpr bool ROWS_EARLY = TSPLIT;                              // (built by the helper wave beside phase E, above)
+        constexpr bool BROWS_ = S::BROWS || ROWS_EARLY;
+        double* AB = sm + (ROWS_EARLY ? S::o_abx : S::o_ab);
+        [[maybe_unused]] const double* BB = sm + (ROWS_EARLY ? S::o_bbx : S::o_bb);
         typedef double d2 __attribute__((ext_vector_type(2)));
+        if constexpr (!ROWS_EARLY) {
         for (int r = t; r < 16 * S::NT; r += BT) {
             const bool on = r < n_g;
             const int rr = on ? r : 0, j = gstep[rr], l = rr - igoff[j];
@@ -1219,6 +1289,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             }
         }
         __syncthreads();
+        }
 #pragma unroll
         for (int s = 0; s < TSL; ++s) {
             acc[s] = (v4t){TT(0), TT(0), TT(0), TT(0)};
@@ -1229,13 +1300,13 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 int mm, l2;
                 double Bv[6], gc;
                 const int cm3 = cc - 3 * ((cc * 0xAAAB) >> 17);
-                if constexpr (S::BROWS) {
+                if constexpr (BROWS_) {
                     const d2 g67 = reinterpret_cast<const d2*>(AB + 8 * cc)[3];          // the coordinate's own row: z_lin and (step, offset) code
                     const int cwc = (int)g67[1];
                     mm = cwc >> 12;
                     l2 = (((cwc & 4095) - 36 * mm) * 0xAAAB) >> 18;                         // (36 j + 6 l - 36 j) / 6
                     gc = s2 * g67[0];
-                    const d2* brow = reinterpret_cast<const d2*>(sm + S::o_bb + 6 * cc);
+                    const d2* brow = reinterpret_cast<const d2*>(BB + 6 * cc);
                     const d2 b01 = brow[0], b23 = brow[1], b45 = brow[2];
                     Bv[0] = b01[0]; Bv[1] = b01[1]; Bv[2] = b23[0]; Bv[3] = b23[1]; Bv[4] = b45[0]; Bv[5] = b45[1];
                 } else {
@@ -1331,17 +1402,15 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             acc[1][q] = on1 ? sm[S::o_hand + row * 16 + mcol] : 0.0;
             acc[2][q] = on2 ? sm[S::o_hand + 256 + row * 16 + mcol] : 0.0;
         }
-        TT* D00 = T;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int row = kq + 4 * q; D00[row * 16 + (mcol ^ row)] = (TT)winv0[q]; }
     }
     {
         double* misc = sm + S::o_misc;
         long long* stp = a.stamps;
-        if (S::NT >= 4 && NT >= 4) latp_dispatch<(S::NT >= 4 ? 4 : 3)>(w, T, acc[0], acc[1], acc[2], misc, lane, stp);       // (wave-uniform: every wave of the workgroup takes the same arm, with its barriers)
-        else if (NT == 3) latp_dispatch<3>(w, T, acc[0], acc[1], acc[2], misc, lane, stp);
-        else if (NT == 2) latp_dispatch<2>(w, T, acc[0], acc[1], acc[2], misc, lane, stp);
-        else latp_dispatch<1>(w, T, acc[0], acc[1], acc[2], misc, lane, stp);
+        const double* D0 = sm + S::o_pre;           // L_00^-1, swizzled, where diag16_invert_dpp left it (the scratch tile lies outside the tile store and the tables)
+        if (S::NT >= 4 && NT >= 4) latp_dispatch<(S::NT >= 4 ? 4 : 3)>(w, T, D0, acc[0], acc[1], acc[2], misc, lane, stp);       // (wave-uniform: every wave of the workgroup takes the same arm, with its barriers)
+        else if (NT == 3) latp_dispatch<3>(w, T, D0, acc[0], acc[1], acc[2], misc, lane, stp);
+        else if (NT == 2) latp_dispatch<2>(w, T, D0, acc[0], acc[1], acc[2], misc, lane, stp);
+        else latp_dispatch<1>(w, T, D0, acc[0], acc[1], acc[2], misc, lane, stp);
     }
     SRBDQP_STAMP(a, b, 4);
     SRBDQP_STAMP(a, b, 5);
