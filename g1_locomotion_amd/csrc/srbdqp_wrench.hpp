@@ -115,19 +115,9 @@ struct WrenchSmem {
     // ---- phase B (tiles)
     static constexpr int o_T = o_R;
     static constexpr int o_ws = o_T + NTT * 256 * TB / 8;   // fp32 tiles: one 16 x 16 scratch tile per wave (operand re-layout)
-    // fp32 tiles: the lower triangle of E^-1 per step (21 N doubles: the very values that went into T -- V and Bd formed from a
-    // rounded copy break the Woodbury identity 100 times worse than rounding V and Bd themselves), written in phase E and kept
-    // through phases F / W / I behind the tiles AND behind the phase-A arrays; the rows of V and Bd are formed from it afterwards
-    static constexpr int o_e4 = cmax(o_ws + (TB == 4 ? NW * 128 : 0), TB == 4 ? endA : 0);
-    // ... and the gradient of every variable (fp32 tiles: 168 registers per lane -- it waited in scratch memory from the tables to x_q)
-    // (only where it costs no occupancy: the fp32-tile kernels are compiled for 3 waves per SIMD = 12 waves per CU)
-    static constexpr int o_qv = o_e4 + (TB == 4 ? 21 * N : 0);
-    static constexpr int wgs_of(int doubles) { return 163840 / (((doubles * 8 + 1279) / 1280) * 1280); }   // (LDS is handed out in blocks of 320 dwords on gfx950)
-    static constexpr bool QV_PARK = TB == 4 && (wgs_of(cmax(endA, o_qv + n / 2)) * NW >= 12 || wgs_of(cmax(endA, o_qv + n / 2)) == wgs_of(cmax(endA, o_qv)));
-    static constexpr int endB = o_qv + (QV_PARK ? n / 2 : 0);   // (n floats: the leading fp32 part; the remainder -- one register -- stays with the lane)
     // fp64 iterations with a half row longer than 60 (N = 24): its last KTAIL entries per lane, entry-major [KTAIL][BT] (the tiles
     // are dead by then and their region is far larger)
-    #ifndef SRBDQP_WRENCH_KTAIL36
+#ifndef SRBDQP_WRENCH_KTAIL36
 #define SRBDQP_WRENCH_KTAIL36 12
 #endif
 #ifndef SRBDQP_WRENCH_VLDS
@@ -143,6 +133,20 @@ struct WrenchSmem {
     static constexpr int o_kt = up2(endC);
     static constexpr int o_vl = o_kt + KTAIL * BT;        // VL: row and column of V per lane, entry-major [12][BT]
     static constexpr int endC2 = o_vl + ((TB == 8 && SRBDQP_WRENCH_VLDS && CHMAX <= 36) ? 12 * BT : 0);
+    static constexpr int wgs_of(int doubles) { return 163840 / (((doubles * 8 + 1279) / 1280) * 1280); }   // (LDS is handed out in blocks of 320 dwords on gfx950)
+    // fp32 tiles: the lower triangle of E^-1 per step (21 N doubles: the very values that went into T -- V and Bd formed from a
+    // rounded copy break the Woodbury identity 100 times worse than rounding V and Bd themselves), written in phase E and kept
+    // through phases F / W / I behind the tiles AND behind the phase-A arrays; the rows of V and Bd are formed from it afterwards
+    // (round 5: the same late formation for the fp64-tile instantiations wherever the triangle fits WITHOUT costing a workgroup per CU -- their V / Bd rows were
+    //  the 116 - 312 bytes per lane these kernels kept in scratch memory across the tile phases: 5 x the algorithmic HBM traffic on the N = 12 bucket of configs[4])
+    static constexpr int o_e4x = cmax(o_ws, endA);
+    static constexpr bool E4_FITS = TB == 8 && XW == 0 && wgs_of(cmax(cmax(endA, endC2), o_e4x + 21 * N)) == wgs_of(cmax(cmax(endA, endC2), o_ws));
+    static constexpr int o_e4 = TB == 4 ? cmax(o_ws + NW * 128, endA) : (E4_FITS ? o_e4x : o_ws);
+    // ... and the gradient of every variable (fp32 tiles: 168 registers per lane -- it waited in scratch memory from the tables to x_q)
+    // (only where it costs no occupancy: the fp32-tile kernels are compiled for 3 waves per SIMD = 12 waves per CU)
+    static constexpr int o_qv = o_e4 + ((TB == 4 || E4_FITS) ? 21 * N : 0);
+    static constexpr bool QV_PARK = TB == 4 && (wgs_of(cmax(endA, o_qv + n / 2)) * NW >= 12 || wgs_of(cmax(endA, o_qv + n / 2)) == wgs_of(cmax(endA, o_qv)));
+    static constexpr int endB = o_qv + (QV_PARK ? n / 2 : 0);   // (n floats: the leading fp32 part; the remainder -- one register -- stays with the lane)
     // fp32 tiles, long horizons: the lane's fp64 row and column of V wait in the dead tile region while x_q and its refinement run
     // (entry-major [6][n] each, indexed by the lane's variable; two free regions: behind the ADMM vectors up to the G'v tables the
     // refinement still needs, and the 6-vectors + E^-1 blocks of the assembly) -- they were the larger half of the kernel's spills
@@ -982,7 +986,9 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // the triangle of E^-1 kept in LDS behind the tiles, and held in fp32 from then on.  Formed here they waited in scratch
     // memory across phases F / W / I: 10 GB of HBM traffic per 65,536-QP launch against 0.29 GB of inputs and outputs
     // (rocprofv3 FETCH_SIZE / WRITE_SIZE, round 2).
-    constexpr bool VBD_LATE = sizeof(TT) == 4;
+    // (round 5: fp64 tiles too, for the instantiations compiled at 3 waves per SIMD -- N <= 12 in fp64, every fp32 instantiation on fp64 tiles -- where the
+    //  triangle fits the LDS the workgroup has anyway, WrenchSmem::E4_FITS)
+    constexpr bool VBD_LATE = sizeof(TT) == 4 || (S::E4_FITS && MODE == 0 && (CHMAX <= 36 || sizeof(R) == 4));
     typedef double VS;   // (x_q and its refinement need V and Bd in fp64: rounded to fp32 the refinement contracts 10 x slower)
     VS vrow[6], vcol[6];
     double bjv[4];                                                   // bjv: J[:, u] of the lane's variable and 1 / D_u (apply_kinv)
@@ -993,7 +999,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     constexpr bool BD_LAST = SRBDQP_WRENCH_BD_LAST && VBD_LATE && BD_EXPLICIT;   // ... formed after x_q and its refinement (form_bd)
     // explicit Bd rows: fp32 from the start in the fp32-tile kernel (only the iterations use them there; x_q and its refinement
     // run in fp64, where the implicit form is exact enough) -- 12 registers instead of 24 next to the T^-1 row
-    typedef typename std::conditional<sizeof(TT) == 4, float, double>::type BS;
+    typedef typename std::conditional<(sizeof(TT) == 4 || (VBD_LATE && sizeof(R) == 4)), float, double>::type BS;
     [[maybe_unused]] BS bdrow[12];
     int bsel = 0;                                                    // g row (within the step) of the unit part of Y'[:, u]
     int before_ci = 0;                                               // stance contacts of the step before ci
