@@ -201,7 +201,7 @@ def _resolved_restart(N, B, it, cnt, max_iter, kname):
         it = 55 if N <= 10 else {12: 70, 16: 80, 24: 100}.get(N, 125)
     if it <= 0 or it >= max_iter:
         return {"every": 0, "count": 0, "how": "off"}
-    cnt = cnt if cnt > 0 else ((2 if N <= 12 else {16: 3, 24: 2}.get(N, 1)) if auto else 1)
+    cnt = min(cnt if cnt > 0 else ((2 if N <= 12 else {16: 3, 24: 2}.get(N, 1)) if auto else 1), 3)     # (values above 3 mean 3: srbdqp.h)
     how = "one more launch over the same grid per pass (only the workgroups of the capped QPs do anything)"
     if wave:
         how = ("deferred: a QP at a mark hands itself to the next launch on its stream (srbdqp_flush completes the last ones)" if "defer" in kname

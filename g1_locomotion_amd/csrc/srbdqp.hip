@@ -644,6 +644,9 @@ inline int restart_iter_of(const srbdqp_handle* h, int maxs, int B, bool wave = 
     const int N = c.horizon;
     if (automatic) r = (N <= 10) ? 55 : (N == 12 ? 70 : (N == 16 ? 80 : (N == 24 ? 100 : 125)));
     if (count) *count = c.rho_restart_count > 0 ? c.rho_restart_count : (!automatic ? 1 : ((N <= 12) ? 2 : (N == 16 ? 3 : (N == 24 ? 2 : 1))));
+    // at most three re-balancings, on every kernel (round 5): the one-wave kernel runs its continued passes as three straight copies of the body -- a loop around it
+    // costs the whole kernel 30 registers and puts 52 - 72 bytes per lane in scratch memory -- and the rule is the same for every kernel and batch size
+    if (count && *count > 3) *count = 3;
     return (r > 0 && r < c.max_iter) ? r : 0;
 }
 

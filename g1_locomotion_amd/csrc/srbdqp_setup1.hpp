@@ -579,8 +579,18 @@ __global__ __launch_bounds__(64, 2) void srbdqp_setup1_kernel(KArgs a) {
     if constexpr (!RST) {
         setup1_pass<N, MAXS, FUSED, DUMP, PHI, 0>(a, io, b, sm, rho_b, rs_pass, rs_done);
     } else {
+        // (round 5: the continued passes as three straight copies instead of a loop -- a loop around the body has the compiler hoist the body's index arithmetic and
+        //  constants in front of it and keep them live through it: 256 VGPRs + 52 bytes of scratch at N = 10.  Exact for rho_restart_count <= 3; with more
+        //  re-balancings allowed the third continued pass runs on to the iteration cap)
         bool again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 1>(a, io, b, sm, rho_b, rs_pass, rs_done);
-        while (again) again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        again = setup1_pass<N, MAXS, FUSED, DUMP, PHI, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        KArgs al = a;
+        al.restart_max = 0;
+        setup1_pass<N, MAXS, FUSED, DUMP, PHI, 2>(al, io, b, sm, rho_b, rs_pass, rs_done);
     }
 }
 
@@ -671,8 +681,29 @@ __global__ __launch_bounds__(64, 2) void srbdqp_wave_defer_kernel(KArgs a) {
     if (!again) return;
     // at a mark, unconverged: hand the QP to the next launch on the stream -- or, when the list has no room left (or nothing comes behind a flush), run the
     // passes it has left in place, as the restart kernel does (the strip is in place by now in both arms).  Same passes, same arithmetic either way.
-    if constexpr (!FLUSH) { if (tail_export(a, io, b, rho_b, rs_pass, rs_done, park)) return; }
-    while (again) again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+    if constexpr (!FLUSH) {
+        if (tail_export(a, io, b, rho_b, rs_pass, rs_done, park)) return;
+        // The list is full (rare: the lists hold a quarter of a launch).  In place, but NOT as a loop: a loop around the body has the compiler hoist the body's index
+        // arithmetic and constants in front of it and keep them live through it (256 VGPRs + 72 bytes of scratch for the whole kernel, against 225 + 0) -- three
+        // straight copies instead, which cover rho_restart_count <= 3 exactly; with more re-balancings allowed the third copy runs on to the iteration cap.
+#ifndef SRBDQP_DEFER_NO_INPLACE     // (experiment: what the three copies cost the hot path)
+        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        KArgs al = a;
+        al.restart_max = 0;
+        setup1_pass<N, MAXS, true, false, false, 2>(al, io, b, sm, rho_b, rs_pass, rs_done);
+#endif
+    } else {   // a flush: every pass the QP has left, in place (the same three straight copies)
+        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        KArgs al = a;
+        al.restart_max = 0;
+        setup1_pass<N, MAXS, true, false, false, 2>(al, io, b, sm, rho_b, rs_pass, rs_done);
+    }
 }
 
 }  // namespace srbdqp

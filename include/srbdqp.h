@@ -110,7 +110,8 @@ typedef struct srbdqp_config {
                                    * the staged batch-1 call launches a further pass only when a status[] asks for it. */
     int32_t rho_restart_count;    /* at most this many re-balancings, one every rho_restart_iter iterations, each from the rho of the
                                    * pass before it.  0 (default) = automatic: with the automatic rho_restart_iter 2 (N <= 12), 3 (N = 16),
-                                   * 1 (N = 20), 2 (N = 24); with an explicit rho_restart_iter 1 */
+                                   * 1 (N = 20), 2 (N = 24); with an explicit rho_restart_iter 1.  Values above 3 mean 3 (every kernel: the
+                                   * one-wave kernel holds its continued passes as three straight copies of its body) */
     double dt;                    /* run_simulation.py:169 */
     double mass;                  /* wbid.py:291 model.getMass() */
     double inertia[3];            /* wbid.py:261-266 torso inertia diagonal */

@@ -406,7 +406,7 @@ def test_one_wave_kernel_restarts_in_place(torch_first, built_lib, N, every, cou
     from g1_locomotion_amd import BatchMPC
     B = 4096
     x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=1000, schedule=schedule)
-    p = orc.params_for(N, rho_restart_iter=every or 55, rho_restart_count=count or 2)
+    p = orc.params_for(N, rho_restart_iter=every or 55, rho_restart_count=min(count or 2, 3))      # (srbdqp_config.rho_restart_count: values above 3 mean 3)
     ref = c_oracle.solve_batch(p, x0, xr, ft, ct, nthreads=8)
     plain = c_oracle.solve_batch(orc.params_for(N), x0, xr, ft, ct, nthreads=8)
     kw = {} if every == 0 else dict(rho_restart_iter=every, rho_restart_count=count)
