@@ -50,6 +50,7 @@ struct srbdqp_handle {
         // the caller passes none (the second pass warm-starts from the first pass's outputs)
         char* rs = nullptr; size_t rs_items = 0, rs_rows = 0;
         float* resid = nullptr; double* ybuf = nullptr;
+        double* ubuf = nullptr;                   // staged first pass: device copy of u for the pass behind it (KArgs::u_dev)
         int32_t* stbuf = nullptr;
         double* rhobuf[2] = {nullptr, nullptr};   // rho a restart pass ran its QPs with, for the pass behind it (alternating)
         // SRBDQP_FLAG_DEFER_TAIL on the kernels that restart by further LAUNCHES: three sets of the buffers above in rotation (a solve's restart passes run on
@@ -391,7 +392,7 @@ int flush_slot(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st
 template <int N>
 bool staged_inline_inputs(const srbdqp_handle* h, const KArgs& a, srbdqp::StagedIn<N>& in) {
     if (!(h->staged_call && a.B == 1 && a.x0 == h->stage_d.x0 && a.xref == h->stage_d.x_ref && a.foot == h->stage_d.foot && a.contact == h->stage_d.contact) ||
-        a.perm || a.row_off || a.resid_in || (a.pcom && a.pcom != h->stage_d.pcom)) return false;
+        a.perm || a.row_off || (a.pcom && a.pcom != h->stage_d.pcom)) return false;     // (a restart pass of the staged call too: the host starts it only for a QP at the cap)
     std::memcpy(in.x0, h->stage_h.x0, sizeof(in.x0));
     std::memcpy(in.xref, h->stage_h.x_ref, sizeof(in.xref));
     std::memcpy(in.foot, h->stage_h.foot, sizeof(in.foot));
@@ -666,6 +667,7 @@ int ensure_restart_buffers(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hi
         }
         const auto& r0 = slot->rsets[0];
         slot->resid = r0.resid; slot->ybuf = r0.ybuf; slot->stbuf = r0.stbuf; slot->rhobuf[0] = r0.rhobuf[0]; slot->rhobuf[1] = r0.rhobuf[1];
+        slot->ubuf = (B <= 64) ? c.take<double>(B * (m * 12 / 20)) : nullptr;       // (only the staged path uses it: small batches)
     };
     slot->rs_nsets = nsets; slot->last_tail = nullptr;
     Carver sz(nullptr);
@@ -738,7 +740,8 @@ int srbdqp_restart_pass(srbdqp_handle* h, const KArgs& a1, hipStream_t st, int m
     if (last_out) *last_out = last;
     KArgs a2 = a1;
     a2.resid_in = a1.resid_out;
-    a2.warm_u = a1.u_out;                                   // newtons, as a caller's warm start would be
+    a2.warm_u = a1.u_dev ? a1.u_dev : a1.u_out;             // newtons, as a caller's warm start would be (the device copy of a staged first pass)
+    a2.u_dev = (a1.u_dev && !last) ? a1.u_dev : nullptr;    // ... refreshed by every pass another one may follow
     a2.warm_y = a1.y_out;
     a2.max_iter = last ? left : every;
     a2.iters_base = done;
@@ -1229,6 +1232,7 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
     if (!a1.y_out) { a1.y_out = slot->ybuf; a1.y_capped_only = 1; }
     if (!a1.status) a1.status = slot->stbuf;
     if (!lazy) { a1.done_flag = nullptr; a1.done_count = nullptr; }
+    if (lazy && slot->ubuf && !h->io_f32) a1.u_dev = slot->ubuf;   // (the staged arrays are host memory: the pass behind this one reads its warm start on the device)
     rc = launch(h, a1, lst, maxs, lazy ? 0 : 1);
     if (lazy) { h->last_args = a1; h->lazy_pending = (rc == SRBDQP_OK); h->lazy_rcount = rcount; h->lazy_slot = slot; }
     if (rc != SRBDQP_OK || lazy) return rc;

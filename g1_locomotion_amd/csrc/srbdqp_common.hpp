@@ -61,6 +61,8 @@ struct KArgs {
     int32_t y_capped_only;   // first pass, y_out = the engine's own buffer (the caller asked for no duals): only a QP that ends at the cap stores them
                              //   (20 N values per QP for every QP was a quarter of the HBM traffic of a configs[2] solve)
     int32_t qp_span;         // host only: number of QP slots the per-QP workspaces must hold (second pass: original B)
+    double* u_dev;           // staged first pass that a restart pass may follow: a second copy of u [B][N][12] in DEVICE memory -- the pass behind it warm-starts from
+                             //   there instead of reading the staging array back over PCIe (2.4 us of the two-launch calls that make the p99), or null
     // deferred tails (SRBDQP_FLAG_DEFER_TAIL, srbdqp_wave_defer_kernel): a QP that reaches a restart mark unconverged is not continued by its own
     // workgroup but appended -- (x, y), its re-balanced rho, its own input / output pointers -- to a list in HBM, and one of the first tail_wgs workgroups
     // of the NEXT launch on the same stream runs its next pass.  Three lists per launch stream in rotation: this launch reads tail_cnt[tail_iin] records
@@ -429,6 +431,7 @@ __device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_ou
     constexpr int n = Dims<N>::n;
     const int t = threadIdx.x;
     for (int c = t; c < n; c += BT) u_out[(size_t)b * n + c] = a.s * uh[c];
+    if (a.u_dev) for (int c = t; c < n; c += BT) a.u_dev[(size_t)b * n + c] = a.s * uh[c];
     if (!x_out) return;
     const double* x0 = sm + S::o_x0;
     // phase A1: per-step angular / linear acceleration sums  s_j = J_j u_j (3), sum_contacts u_j / m (3)  -- one step

@@ -1933,6 +1933,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const size_t row0 = a.row_off ? (size_t)a.row_off[b] : (size_t)b * N;
         TIO* uo = reinterpret_cast<TIO*>(a.u_out) + row0 * 12;
         for (int c = t; c < n; c += LT) uo[c] = (TIO)(a.s * uh[c]);
+        if constexpr (sizeof(TIO) == 8) { if (a.u_dev) for (int c = t; c < n; c += LT) a.u_dev[row0 * 12 + c] = a.s * uh[c]; }
         if (a.x_out) {
             const double* x0 = sm + S::o_x0;
             double* sj = scratch + 6 * N;

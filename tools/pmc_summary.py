@@ -100,7 +100,7 @@ def main():
         git_rev = None
     d = {"round": rnd, "bench_kernel_name": kname, "batch_per_launch": B, "horizon": N, "library_sha256": lib_sha, "git_rev": git_rev,
          "dominant_kernel": d0["rocprof_kernel_trace"]["name"],
-         "workload": "bench.py --streams 1 ...: one solve at a time; see `command`",
+         "workload": os.environ.get("PMC_WORKLOAD", "bench.py --streams 1 ...: one solve at a time; see `command`"),
          "command": "tools/pmc_collect.sh (one rocprofv3 --pmc <group> --kernel-trace pass per counter group) + rocprofv3 --kernel-trace --stats on the same bench command",
          "kernel_avg_us_rocprof_kernel_trace": tot_us,
          "hbm": {"fetch_bytes_corrected_x2": tot_fetch, "write_bytes": tot_write, "traffic_bytes_per_launch": tot_fetch + tot_write,
