@@ -434,6 +434,11 @@ __device__ __forceinline__ R apply_kinv(R wv, R* wbw, R* tbw, R* vb, int lane, i
 #ifndef SRBDQP_LATP_SPLIT
 #define SRBDQP_LATP_SPLIT 5
 #endif
+#ifdef SRBDQP_LATP_STAMPS
+#define ESTAMP(a, i) do { if ((a).stamps && (a).B == 1 && threadIdx.x == 0) (a).stamps[16 * 5 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ESTAMP(a, i) do { } while (0)
+#endif
 #ifdef SRBDQP_LATP_STAMPS   // (diagnostic builds: when wave w arrives at a join of the set-up -- rows 1 + w of the stamp buffer of a B = 1 solve)
 #define WAVE_ARRIVE(a, w, lane, i) do { if ((a).stamps && (a).B == 1 && (lane) == 0 && (w) < 4) (a).stamps[16 * (1 + (w)) + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -775,6 +780,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     // order: no barrier between the two halves) -- while the step waves compute E, V, Bd, which need none of it; one barrier
     // joins the three.  Serially (every wave on every table, then E) the two phases took 6.4 k + 8.0 k cycles of a batch-1 solve.
     constexpr bool TSPLIT = (XW == 2);
+    constexpr int TUNR = (XW > 0 && N <= 10) ? N : 4;                   // table loops over the steps: fully unrolled in the low-latency instantiation (every LDS read of a chain in flight at once)
     const bool tab_a = !TSPLIT || w == NWS, tab_b = !TSPLIT || w == NWS + 1;
     const int tt = TSPLIT ? lane : t;
     constexpr int TSTR = TSPLIT ? 64 : BT;
@@ -790,7 +796,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const double w0 = SQ[0] * SQ[0], w1 = SQ[1] * SQ[1], w2 = SQ[2] * SQ[2];
         const double m0p = Cm[p], m1p = Cm[3 + p], m2p = Cm[6 + p], m0q = Cm[q], m1q = Cm[3 + q], m2q = Cm[6 + q], mpq = Cm[pq];
         double s1 = 0.0, s2 = 0.0;
-#pragma unroll 4
+#pragma unroll TUNR
         for (int i = 0; i < N; ++i) {
             const double* Ci = CP + i * 9;
             const double on = (i >= mm) ? 1.0 : 0.0;
@@ -816,7 +822,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 double acc = 0.0;
                 const double c0 = Cj[comp], c1 = Cj[3 + comp], c2 = Cj[6 + comp];
                 const double q0 = SQ[0] * dt2, q1 = SQ[1] * dt2, q2 = SQ[2] * dt2, qw = SQ[6 + comp] * dt;
-#pragma unroll 4
+#pragma unroll TUNR
                 for (int i = 0; i < N; ++i) {
                     const double* Ci = CP + i * 9;
                     const double* v = vec + 12 * i;
@@ -828,7 +834,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const int e = e0 - 3 * N, j = e / 6, comp = 3 + (e - 6 * j);
                 const int kk = (comp < 6) ? comp : 3 + comp;
                 double acc = 0.0;
-#pragma unroll 4
+#pragma unroll TUNR
                 for (int i = 0; i < N; ++i) {
                     const double wgt = (i >= j) ? ((comp < 6) ? (double)(i - j) : 1.0) : 0.0;
                     acc = fma(wgt, vec[12 * i + kk], acc);
@@ -1074,6 +1080,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const int fl[4] = {f0, f1, f2, f3};
         double* ZT = sm + S::o_zt;
         double* EI = sm + S::o_ei + 36 * js;
+        ESTAMP(a, 0);
         if (wrench) {
             // E = W D^-1 W' (6 x 6, SPD): every lane of the step forms and inverts it redundantly in registers
             double Em[6][6];
@@ -1103,6 +1110,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 for (int q = 0; q < 3; ++q) Em[3 + q][p] = Em[p][3 + q];
             // (the J entries are read again below rather than kept: 36 doubles per lane across this phase were spilled)
             asm volatile("" ::: "memory");
+            ESTAMP(a, 1);
             // E^-1 through its structure (round 5): E = [A B; B' G] with G = S D^-1 S' DIAGONAL (S = [I I I I]: the force rows of W), so
             //     E^-1 = [ Sc^-1, -Sc^-1 B G^-1 ; sym, G^-1 + G^-1 B' Sc^-1 B G^-1 ],   Sc = A - B G^-1 B'   (3 x 3, SPD)
             // -- a 3 x 3 Cholesky and three reciprocals instead of the 6 x 6 Cholesky + triangular inverse + L^-T L^-1 every lane of the step ran redundantly
@@ -1169,35 +1177,42 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                         Ei[3 + p][3 + q] = v; Ei[3 + q][3 + p] = v;
                     }
             }
+            ESTAMP(a, 2);
             if (!okE && stepok && ul == 0) sm[S::o_misc] = 1.0;   // 4 collinear contact points: E singular
-            // row rl of E^-1 (select chain: no runtime-indexed register array)
-            double er[6];
+            // E^-1 goes to LDS WHOLE, from the first lane of the step, and every lane reads what it needs back (its row; one column entry per row) behind a
+            // wave-local wait -- the 12 lanes of a step sit in one wave.  Until round 5 each lane picked row rl and column 3 + ax out of its register copy with
+            // select chains: hipcc turned them into divergent branches around the entries' own arithmetic (37 exec-masked blocks, each run by every wave for every
+            // case): 5.0 k of the 7.8 k cycles of this phase at batch 1.
+            if (stepok && ul == 0) {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                d2* EI2 = reinterpret_cast<d2*>(EI);                   // (36 js doubles: 16-byte aligned)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) er[c] = (rl == 0) ? Ei[0][c] : (rl == 1) ? Ei[1][c] : (rl == 2) ? Ei[2][c] : (rl == 3) ? Ei[3][c] : (rl == 4) ? Ei[4][c] : Ei[5][c];
-            if (stepok) {
+                for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    EI[6 * rl + 3 * h + i] = h ? er[3 + i] : er[i];
-                    ZT[6 * Rrow + 3 * h + i] = (3 * h + i == rl) ? 1.0 : 0.0;
-                }
-            }
-            if constexpr (VBD_LATE) {
-                if (stepok) {
+                    for (int c2 = 0; c2 < 3; ++c2) EI2[3 * r + c2] = (d2){Ei[r][2 * c2], Ei[r][2 * c2 + 1]};
+                if constexpr (VBD_LATE) {
                     double* E4 = sm + S::o_e4 + 21 * js;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        if (3 * h + i <= rl) E4[(rl * (rl + 1)) / 2 + 3 * h + i] = h ? er[3 + i] : er[i];
-                }
-            } else {
-                const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
-                double yv[6];
+                    for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const double ea = (ax == 0) ? Ei[r][3] : (ax == 1) ? Ei[r][4] : Ei[r][5];
-                    yv[r] = Ei[r][0] * j0 + Ei[r][1] * j1 + Ei[r][2] * j2 + ea;
+                        for (int c = 0; c <= r; ++c) E4[(r * (r + 1)) / 2 + c] = Ei[r][c];
                 }
+            }
+            if (stepok) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ZT[6 * Rrow + 3 * h + i] = (3 * h + i == rl) ? 1.0 : 0.0;
+            }
+            if constexpr (!VBD_LATE) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (one wave: its LDS operations complete in order)
+                const double j0 = Jj[ul], j1 = Jj[12 + ul], j2 = Jj[24 + ul];
+                double er[6], yv[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) er[c] = EI[6 * rl + c];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) yv[r] = Ei[r][0] * j0 + Ei[r][1] * j1 + Ei[r][2] * j2 + EI[6 * r + 3 + ax];
                 form_vbd(er, yv);
             }
+            ESTAMP(a, 3);
         } else {
             // identity coordinates: g row r <-> the r-th stance force variable of the step
             const int ug = ug_id;
