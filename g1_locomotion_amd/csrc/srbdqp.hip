@@ -466,7 +466,10 @@ struct WrenchTraits {
 #ifndef SRBDQP_F64_SMALL_WPS
 #define SRBDQP_F64_SMALL_WPS 3
 #endif
-    static constexpr int want = (sizeof(R) == 4) ? 3 : (S::CHMAX <= 36 ? SRBDQP_F64_SMALL_WPS : (S::CHMAX <= 60 ? 2 : 1));   // register budget
+#ifndef SRBDQP_F32_ON_F64_WPS
+#define SRBDQP_F32_ON_F64_WPS 3
+#endif
+    static constexpr int want = (sizeof(R) == 4) ? ((TB == 8 && S::CHMAX > 30) ? SRBDQP_F32_ON_F64_WPS : 3) : (S::CHMAX <= 36 ? SRBDQP_F64_SMALL_WPS : (S::CHMAX <= 60 ? 2 : 1));   // register budget
 #endif
     static constexpr int wps = by_lds < want ? by_lds : want;
 };

@@ -25,7 +25,6 @@ KNOWN = {
     "srbdqp_wrench_kernel<24, float, float, 0, 3, float, 5, 0>": 64,
     "srbdqp_wrench_kernel<24, float, float, 0, 2, double, 5, 3>": 84,
     "srbdqp_wrench_kernel<24, double, double, 0, 1, double, 5, 3>": 20,
-    "srbdqp_wrench_kernel<20, double, double, 0, 2, double, 5, 0>": 12,
 }
 
 
