@@ -643,10 +643,17 @@ __global__ __launch_bounds__(64, 2) void srbdqp_wave_defer_kernel(KArgs a) {
     const int lane = threadIdx.x;
     const int T = a.tail_wgs;
     double* const park = sm + L1::o_end;
-    QpIo io;
-    int b, rs_pass, rs_done;
-    double rho_b;
-    bool again;
+    // the passes a QP has left, in place: three straight copies of the body (see below), in each arm on its own -- the arms share nothing, so that the first passes
+    // (96 % of the workgroups) run the code they ran before there was an overflow path
+    auto in_place = [&](const QpIo& io, const int b, double rho_b, int rs_pass, int rs_done) __attribute__((always_inline)) {
+        bool again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
+        if (!again) return;
+        KArgs al = a;
+        al.restart_max = 0;
+        setup1_pass<N, MAXS, true, false, false, 2>(al, io, b, sm, rho_b, rs_pass, rs_done);
+    };
     if ((int)blockIdx.x < T) {
         // ---- a continuation of an earlier launch (first in the grid: these are the long ones)
         const int i = blockIdx.x;
@@ -658,51 +665,34 @@ __global__ __launch_bounds__(64, 2) void srbdqp_wave_defer_kernel(KArgs a) {
         if (i >= cnt) return;
         const double* rec = lin + (size_t)i * kTailRecDoubles;
         const TailRecHead* hd = reinterpret_cast<const TailRecHead*>(rec);
+        QpIo io;
         io.x0 = unis_ptr(hd->io.x0); io.xref = unis_ptr(hd->io.xref); io.foot = unis_ptr(hd->io.foot); io.pcom = unis_ptr(hd->io.pcom);
         io.contact = unis_ptr(hd->io.contact); io.u_out = unis_ptr(hd->io.u_out); io.x_out = unis_ptr(hd->io.x_out); io.y_out = unis_ptr(hd->io.y_out);
         io.status = unis_ptr(hd->io.status); io.iters = unis_ptr(hd->io.iters);
-        b = __builtin_amdgcn_readfirstlane(hd->b);
-        rs_pass = __builtin_amdgcn_readfirstlane(hd->pass); rs_done = __builtin_amdgcn_readfirstlane(hd->done);
-        rho_b = unis(hd->rho);
+        const int b = __builtin_amdgcn_readfirstlane(hd->b);
+        int rs_pass = __builtin_amdgcn_readfirstlane(hd->pass), rs_done = __builtin_amdgcn_readfirstlane(hd->done);
+        double rho_b = unis(hd->rho);
         park[lane] = rec[16 + lane]; park[64 + lane] = rec[80 + lane]; park[128 + lane] = rec[144 + lane];
         __syncthreads();
-        again = setup1_pass<N, MAXS, true, false, false, 3>(a, io, b, sm, rho_b, rs_pass, rs_done);
-    } else {
-        if constexpr (FLUSH) return;
+        if (!setup1_pass<N, MAXS, true, false, false, 3>(a, io, b, sm, rho_b, rs_pass, rs_done)) return;
+        // at a mark, unconverged: on to the next launch on the stream -- or, when the list has no room left (or nothing comes behind a flush), the passes it has left
+        // in place, as the restart kernel runs them (the strip is in place by now).  Same passes, same arithmetic either way.
+        if constexpr (!FLUSH) { if (tail_export(a, io, b, rho_b, rs_pass, rs_done, park)) return; }
+        in_place(io, b, rho_b, rs_pass, rs_done);
+    } else if constexpr (!FLUSH) {
         // ---- a QP of this launch: its first pass
         const int wg = (int)blockIdx.x - T;
         if (wg >= a.B) return;
-        b = a.perm ? a.perm[wg] : wg;
-        rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
-        rs_pass = 0; rs_done = 0;
-        io = io_of(a);
-        again = setup1_pass<N, MAXS, true, false, false, 1>(a, io, b, sm, rho_b, rs_pass, rs_done);
-    }
-    if (!again) return;
-    // at a mark, unconverged: hand the QP to the next launch on the stream -- or, when the list has no room left (or nothing comes behind a flush), run the
-    // passes it has left in place, as the restart kernel does (the strip is in place by now in both arms).  Same passes, same arithmetic either way.
-    if constexpr (!FLUSH) {
+        const int b = a.perm ? a.perm[wg] : wg;
+        double rho_b = a.rho_qp ? a.rho_qp[b] : a.rho;
+        int rs_pass = 0, rs_done = 0;
+        const QpIo io = io_of(a);
+        if (!setup1_pass<N, MAXS, true, false, false, 1>(a, io, b, sm, rho_b, rs_pass, rs_done)) return;
         if (tail_export(a, io, b, rho_b, rs_pass, rs_done, park)) return;
         // The list is full (rare: the lists hold a quarter of a launch).  In place, but NOT as a loop: a loop around the body has the compiler hoist the body's index
-        // arithmetic and constants in front of it and keep them live through it (256 VGPRs + 72 bytes of scratch for the whole kernel, against 225 + 0) -- three
-        // straight copies instead, which cover rho_restart_count <= 3 exactly; with more re-balancings allowed the third copy runs on to the iteration cap.
-#ifndef SRBDQP_DEFER_NO_INPLACE     // (experiment: what the three copies cost the hot path)
-        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
-        if (!again) return;
-        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
-        if (!again) return;
-        KArgs al = a;
-        al.restart_max = 0;
-        setup1_pass<N, MAXS, true, false, false, 2>(al, io, b, sm, rho_b, rs_pass, rs_done);
-#endif
-    } else {   // a flush: every pass the QP has left, in place (the same three straight copies)
-        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
-        if (!again) return;
-        again = setup1_pass<N, MAXS, true, false, false, 2>(a, io, b, sm, rho_b, rs_pass, rs_done);
-        if (!again) return;
-        KArgs al = a;
-        al.restart_max = 0;
-        setup1_pass<N, MAXS, true, false, false, 2>(al, io, b, sm, rho_b, rs_pass, rs_done);
+        // arithmetic and constants in front of it and keep them live through it (256 VGPRs + 72 bytes of scratch for the whole kernel) -- three straight copies
+        // instead, which cover rho_restart_count <= 3 exactly (values above 3 mean 3: srbdqp.h).
+        in_place(io, b, rho_b, rs_pass, rs_done);
     }
 }
 
