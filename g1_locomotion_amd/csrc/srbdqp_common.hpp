@@ -471,38 +471,49 @@ __device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_ou
         scratch[idx] = v;
     }
     __syncthreads();
+    // phase A3 (round 5): Euler angles and CoM positions of the steps 1 .. N as one more prefix stage (6 N entries, a lane each, the reads of every trip in flight; the
+    // two kinds of entries on different waves where there are several), then the rows of x as a plain gather.  Until round 5 the store loop formed them entry by
+    // entry inside a five-way branch over (k, component): two or three trips of divergent arms with up to 60 dependent LDS reads each -- 4.1 k of the roll-out's 6.5 k
+    // cycles in the batch-1 kernels.
+    double* pa = sj;                                                     // (the per-step sums are dead behind phase A2)
+    constexpr int PA_OFF = (64 * ((3 * N + 63) / 64) + 3 * N <= BT) ? 64 * ((3 * N + 63) / 64) : 3 * N;
+    for (int tt = t; tt < PA_OFF + 3 * N; tt += BT) {
+        if (tt < 3 * N || tt >= PA_OFF) {
+            const bool posn = tt >= PA_OFF;
+            const int e = posn ? tt - PA_OFF : tt;
+            const int k = e / 3 + 1, comp = e % 3 + (posn ? 3 : 0);
+            double acc;
+            if (posn) {             // p_k = p_0 + dt sum_{l<k} v_l
+                acc = x0[6 + comp];
+                if constexpr (N <= 12) {
+#pragma unroll
+                    for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc += (l < k) ? sv : 0.0; }
+                } else {
+                    for (int l = 1; l < k; ++l) acc += scratch[(l - 1) * 6 + comp];
+                }
+            } else {                // theta_k = theta_0 + dt sum_{l<k} T_l omega_l
+                acc = 0.0;
+                auto term_of = [&](int l) {
+                    const double* T = sm + S::o_tm + l * 9 + comp * 3;
+                    const double* w = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
+                    return T[0] * w[0] + T[1] * w[1] + T[2] * w[2];
+                };
+                if constexpr (N <= 12) {
+#pragma unroll
+                    for (int l = 0; l < N; ++l) { const double term = term_of(l); acc += (l < k) ? term : 0.0; }
+                } else {
+                    for (int l = 0; l < k; ++l) acc += term_of(l);
+                }
+            }
+            pa[6 * (k - 1) + comp] = x0[comp] + a.dt * acc;
+        }
+    }
+    __syncthreads();
     double* xo = x_out + (size_t)b * (N + 1) * 13;
     for (int idx = t; idx < 13 * (N + 1); idx += BT) {
         const int k = idx / 13, comp = idx % 13;
-        double v;
-        if (k == 0) v = x0[comp];
-        else if (comp == 12) v = x0[12];
-        else if (comp >= 6) v = scratch[(k - 1) * 6 + comp - 6];
-        else if (comp >= 3) {   // p_k = p_0 + dt sum_{l<k} v_l
-            double acc = x0[6 + comp];
-            if constexpr (N <= 12) {
-#pragma unroll
-                for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc += (l < k) ? sv : 0.0; }
-            } else {
-                for (int l = 1; l < k; ++l) acc += scratch[(l - 1) * 6 + comp];
-            }
-            v = x0[comp] + a.dt * acc;
-        } else {                // theta_k = theta_0 + dt sum_{l<k} T_l omega_l
-            double acc = 0.0;
-            auto term_of = [&](int l) {
-                const double* T = sm + S::o_tm + l * 9 + comp * 3;
-                const double* w = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
-                return T[0] * w[0] + T[1] * w[1] + T[2] * w[2];
-            };
-            if constexpr (N <= 12) {
-#pragma unroll
-                for (int l = 0; l < N; ++l) { const double term = term_of(l); acc += (l < k) ? term : 0.0; }
-            } else {
-                for (int l = 0; l < k; ++l) acc += term_of(l);
-            }
-            v = x0[comp] + a.dt * acc;
-        }
-        xo[idx] = v;
+        const double* src = (k == 0 || comp == 12) ? (x0 + comp) : ((comp >= 6) ? (scratch + (k - 1) * 6 + comp - 6) : (pa + (k - 1) * 6 + comp));
+        xo[idx] = *src;
     }
 }
 template <int N, class L, int BT = kThreads>

@@ -1947,7 +1947,9 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         double* scratch = sm + S::o_scr;
         const size_t row0 = a.row_off ? (size_t)a.row_off[b] : (size_t)b * N;
         TIO* uo = reinterpret_cast<TIO*>(a.u_out) + row0 * 12;
+        ESTAMP(a, 4);
         for (int c = t; c < n; c += LT) uo[c] = (TIO)(a.s * uh[c]);
+        ESTAMP(a, 5);
         if constexpr (sizeof(TIO) == 8) { if (a.u_dev) for (int c = t; c < n; c += LT) a.u_dev[row0 * 12 + c] = a.s * uh[c]; }
         if (a.x_out) {
             const double* x0 = sm + S::o_x0;
@@ -1967,6 +1969,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 sj[idx] = s;
             }
             __syncthreads();
+            ESTAMP(a, 6);
             for (int idx = t; idx < 6 * N; idx += LT) {
                 const int k = idx / 6 + 1, comp = idx % 6;
                 double acc2 = 0.0;   // (all N steps, the later ones adding exact zeros: the reads of all trips in flight together, srbdqp_common.hpp rollout_and_store_to)
@@ -1981,24 +1984,29 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 scratch[idx] = v;
             }
             __syncthreads();
-            TIO* xo = reinterpret_cast<TIO*>(a.x_out) + (row0 + (size_t)b) * 13;      // N + 1 rows per QP
-            for (int idx = t; idx < 13 * (N + 1); idx += LT) {
-                const int k = idx / 13, comp = idx % 13;
-                double v;
-                if (k == 0) v = x0[comp];
-                else if (comp == 12) v = x0[12];
-                else if (comp >= 6) v = scratch[(k - 1) * 6 + comp - 6];
-                else if (comp >= 3) {
-                    double acc2 = x0[6 + comp];
+            ESTAMP(a, 7);
+            // Euler angles and CoM positions of the steps 1 .. N as ONE more prefix stage (6 N entries, a lane each, the reads of every trip in flight) and the rows
+            // of x as a plain gather behind it.  Until round 5 the store loop formed them entry by entry inside a five-way branch over (k, component) -- two trips
+            // of divergent arms with up to 60 dependent LDS reads each: 4.1 k of the roll-out's 6.5 k cycles at batch 1.
+            double* pa = sj;                                             // (the per-step sums are dead behind the stage above)
+            // (the two kinds of entries on different waves where the workgroup has more than one: no divergent arms)
+            constexpr int PA_OFF = (64 * ((3 * N + 63) / 64) + 3 * N <= LT) ? 64 * ((3 * N + 63) / 64) : 3 * N;
+            static_assert(PA_OFF + 3 * N <= LT, "one pass over the angle and position entries");
+            if (t < 3 * N || (t >= PA_OFF && t < PA_OFF + 3 * N)) {
+                const bool posn = t >= PA_OFF;
+                const int e = posn ? t - PA_OFF : t;
+                const int k = e / 3 + 1, comp = e % 3 + (posn ? 3 : 0), idx = 6 * (k - 1) + comp;
+                double acc2;
+                if (posn) {                                              // position: x0 + dt (v_0 + ... + v_{k-1})
+                    acc2 = x0[6 + comp];
                     if constexpr (N <= 12) {
 #pragma unroll
                         for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc2 += (l < k) ? sv : 0.0; }
                     } else {
                         for (int l = 1; l < k; ++l) acc2 += scratch[(l - 1) * 6 + comp];
                     }
-                    v = x0[comp] + a.dt * acc2;
-                } else {
-                    double acc2 = 0.0;
+                } else {                                                 // Euler angles: x0 + dt sum_{l < k} Rz(psi_l)' omega_l
+                    acc2 = 0.0;
                     auto term_of = [&](int l) {
                         const double* Tm = sm + S::o_tm + l * 9 + comp * 3;
                         const double* wv2 = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
@@ -2010,9 +2018,15 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                     } else {
                         for (int l = 0; l < k; ++l) acc2 += term_of(l);
                     }
-                    v = x0[comp] + a.dt * acc2;
                 }
-                xo[idx] = (TIO)v;
+                pa[idx] = x0[comp] + a.dt * acc2;
+            }
+            __syncthreads();
+            TIO* xo = reinterpret_cast<TIO*>(a.x_out) + (row0 + (size_t)b) * 13;      // N + 1 rows per QP
+            for (int idx = t; idx < 13 * (N + 1); idx += LT) {
+                const int k = idx / 13, comp = idx % 13;
+                const double* src = (k == 0 || comp == 12) ? (x0 + comp) : ((comp >= 6) ? (scratch + (k - 1) * 6 + comp - 6) : (pa + (k - 1) * 6 + comp));
+                xo[idx] = (TIO)(*src);
             }
         }
     }

@@ -18,12 +18,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # kernel (as tools/resource_table.py prints it) -> scratch bytes per lane it may use
 KNOWN = {
     "srbdqp_compact_kernel<12, 2, false, false, false>": 20,
-    "srbdqp_wrench_kernel<8, float, float, 0, 3, double, 5, 0>": 12,
+    "srbdqp_wrench_kernel<8, float, float, 0, 3, double, 5, 0>": 20,
     "srbdqp_wrench_kernel<12, float, float, 0, 3, double, 5, 0>": 116,
-    "srbdqp_wrench_kernel<16, float, float, 0, 3, double, 5, 0>": 216,
+    "srbdqp_wrench_kernel<16, float, float, 0, 3, double, 5, 0>": 228,
     "srbdqp_wrench_kernel<10, float, float, 0, 3, float, 5, 0>": 28,
-    "srbdqp_wrench_kernel<24, float, float, 0, 3, float, 5, 0>": 64,
-    "srbdqp_wrench_kernel<24, float, float, 0, 2, double, 5, 3>": 84,
+    "srbdqp_wrench_kernel<24, float, float, 0, 3, float, 5, 0>": 48,
+    "srbdqp_wrench_kernel<24, float, float, 0, 2, double, 5, 3>": 92,
     "srbdqp_wrench_kernel<24, double, double, 0, 1, double, 5, 3>": 20,
 }
 

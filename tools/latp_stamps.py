@@ -33,6 +33,9 @@ print("last    " + " ".join(f"{v:6.0f}" for v in acc.max(axis=0)))
 print("segment " + " ".join(f"{v:6.0f}" for v in np.diff(np.concatenate([[0], acc.max(axis=0)]))))
 e = st_buf.cpu().numpy().astype(np.float64)[5][:4]
 print("phase E on wave 0 (last solve), cycles: E build", int(e[1] - e[0]), " inverse", int(e[2] - e[1]), " er / yv / V / Bd + stores", int(e[3] - e[2]), " from stamp 1 to the start of E", int(e[0] - st_buf.cpu().numpy().astype(np.float64)[0][1]))
+r5 = st_buf.cpu().numpy().astype(np.float64)[5]; r0 = st_buf.cpu().numpy().astype(np.float64)[0]
+if r5[4] > 0:
+    print("roll-out (last solve), cycles: stamp 8 -> start", int(r5[4] - r0[8]), " u store", int(r5[5] - r5[4]), " s_j + barrier", int(r5[6] - r5[5]), " prefix + barrier", int(r5[7] - r5[6]), " x rows + store -> stamp 9", int(r0[9] - r5[7]))
 joins /= cnt
 print("arrival at the join behind the tables / E (cycles since stamp 1 = wave 0 past load + linearise):", np.round(joins[:, 0]).astype(int).tolist(), "  at the barrier behind the T assembly (since stamp 2):", np.round(joins[:, 1]).astype(int).tolist())
 eng.close()
