@@ -34,7 +34,7 @@ EXPORTS = (
     "srbdqp_assemble_f64", "srbdqp_assemble_wrench_f64",
     "srbdqp_ragged_create", "srbdqp_ragged_destroy", "srbdqp_ragged_last_error", "srbdqp_ragged_flush", "srbdqp_solve_ragged_device_f64", "srbdqp_solve_ragged_f64",
     "srbdqp_solve_ragged_device_f32", "srbdqp_solve_ragged_f32", "srbdqp_solve_ragged_warm_device_f64", "srbdqp_solve_ragged_warm_device_f32",
-    "srbdqp_set_schedule_hint", "srbdqp_flush", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_update_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_version",
+    "srbdqp_set_schedule_hint", "srbdqp_flush", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_update_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_batch1_launch_path", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
     "srbdqp_mpc_inputs_f64", "srbdqp_mpc_inputs_device_f64",
@@ -174,6 +174,8 @@ def load():
     lib.srbdqp_last_kernel_parts_ms.restype = C.c_int
     lib.srbdqp_kernel_name.argtypes = [H]
     lib.srbdqp_kernel_name.restype = C.c_char_p
+    lib.srbdqp_batch1_launch_path.argtypes = [H]
+    lib.srbdqp_batch1_launch_path.restype = C.c_char_p
     lib.srbdqp_swing_f64.argtypes = [H, C.c_int64, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp]
     lib.srbdqp_swing_f64.restype = C.c_int
     lib.srbdqp_swing_device_f64.argtypes = [H, C.c_int64, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, C.c_void_p]

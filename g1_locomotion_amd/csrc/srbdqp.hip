@@ -22,6 +22,7 @@
 #include "srbdqp_wrench.hpp"
 #include "srbdqp_cascade.hpp"
 #include "srbdqp_cascade.h"
+#include "srbdqp_aql.hpp"
 
 using srbdqp::KArgs;
 
@@ -94,6 +95,10 @@ struct srbdqp_handle {
     // kernels whose dynamic-LDS limit has been raised on this handle's device (function attributes are per device, and a
     // process may hold handles on several)
     std::unordered_set<const void*> lds_attr_done;
+    // the staged one-QP call's own AQL queue (srbdqp_aql.hpp); null: hipLaunchKernelGGL (set-up failed -- aql_why says how -- or SRBDQP_NO_AQL=1)
+    srbdqp::AqlQueue* aql = nullptr;
+    bool aql_tried = false;
+    std::string aql_why;
 };
 
 // slot of a launch stream (at most kMaxSlots distinct streams per handle; null when exhausted)
@@ -388,6 +393,40 @@ int launch_wave_defer_any(srbdqp_handle* h, const KArgs& a, hipStream_t st, srbd
 int ensure_tail_lists(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st, size_t B, int rmax);
 int flush_slot(srbdqp_handle* h, srbdqp_handle::StreamSlot* slot, hipStream_t st);
 
+// the handle's AQL queue, made at the first staged one-QP call (a 5 MB code object goes through the HSA loader once per process and device)
+srbdqp::AqlQueue* aql_queue(srbdqp_handle* h) {
+    if (h->aql_tried) return h->aql;
+    h->aql_tried = true;
+    const char* off = std::getenv("SRBDQP_NO_AQL");
+    if (off && off[0] && off[0] != '0') { h->aql_why = "SRBDQP_NO_AQL is set"; return nullptr; }
+    int bus = 0, dev = 0, dom = 0;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, h->cfg.device) != hipSuccess || hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, h->cfg.device) != hipSuccess ||
+        hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, h->cfg.device) != hipSuccess) { (void)hipGetLastError(); h->aql_why = "no PCI address for the HIP device"; return nullptr; }
+    h->aql = srbdqp::AqlQueue::create(srbdqp::aql_device(dom, bus, dev), &h->aql_why);
+    return h->aql;
+}
+
+// every kernel this handle started through its own queue has ended: before anything that must follow it is handed to a HIP stream
+int aql_quiesce(srbdqp_handle* h) {
+    if (!h->aql || !h->aql->in_flight()) return SRBDQP_OK;
+    if (h->aql->wait_end(5000000000ull)) return SRBDQP_OK;
+    h->err = "a kernel on the handle's AQL queue did not end within 5 s";
+    return SRBDQP_E_HIP;
+}
+
+// one workgroup of a *_kernel_in instantiation (arguments: KArgs, then StagedIn<N>) through the handle's own queue; false: the caller launches through HIP
+template <class In>
+bool aql_launch_in(srbdqp_handle* h, hipStream_t st, const char* kd_format, int n, int x, const KArgs& a, const In& in, unsigned block, size_t lds) {
+    // (events and tail passes live on HIP streams; a call that does not spin on the completion word waits on its stream)
+    if (!h->staged_call || st != h->stream || !a.done_flag || (h->cfg.flags & (SRBDQP_FLAG_DEFER_TAIL | SRBDQP_FLAG_TIMING | SRBDQP_FLAG_NO_SPIN))) return false;
+    srbdqp::AqlQueue* q = aql_queue(h);
+    if (!q) return false;
+    char name[160];
+    std::snprintf(name, sizeof(name), kd_format, n, x);
+    const srbdqp::AqlKernel& k = srbdqp::aql_kernel(q->device(), name, sizeof(KArgs) + sizeof(In));
+    return q->launch(k, &a, sizeof(KArgs), &in, sizeof(In), block, (uint32_t)lds);
+}
+
 // one staged QP whose inputs still sit in the library's own staging arrays: they ride in the kernel-argument segment (srbdqp_common.hpp StagedIn)
 template <int N>
 bool staged_inline_inputs(const srbdqp_handle* h, const KArgs& a, srbdqp::StagedIn<N>& in) {
@@ -434,6 +473,9 @@ int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
                 if (rc1 != SRBDQP_OK) return rc1;
                 KArgs ai = a;
                 ai.inline_in = 1;
+                if (aql_launch_in(h, st, "_ZN6srbdqp24srbdqp_compact_kernel_inILi%dELi%dEEEvNS_5KArgsENS_8StagedInIXT_EEE.kd", N, MAXS, ai, in, srbdqp::kThreads, lds1)) return SRBDQP_OK;
+                rc1 = aql_quiesce(h);
+                if (rc1 != SRBDQP_OK) return rc1;
                 hipLaunchKernelGGL((srbdqp::srbdqp_compact_kernel_in<N, MAXS>), dim3(1), dim3(srbdqp::kThreads), lds1, st, ai, in);
                 return SRBDQP_OK;
             }
@@ -514,6 +556,9 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
                         if (rcl != SRBDQP_OK) return rcl;
                         KArgs ai = a;
                         ai.inline_in = 1;
+                        if (aql_launch_in(h, st, "_ZN6srbdqp23srbdqp_wrench_kernel_inILi%dELi%dEEEvNS_5KArgsENS_8StagedInIXT_EEE.kd", N, XW, ai, in, SL::BT, ldsl)) return SRBDQP_OK;
+                        rcl = aql_quiesce(h);
+                        if (rcl != SRBDQP_OK) return rcl;
                         hipLaunchKernelGGL((srbdqp::srbdqp_wrench_kernel_in<N, XW>), dim3(1), dim3(SL::BT), ldsl, st, ai, in);
                         HIP_TRY(h, hipGetLastError());
                         return SRBDQP_OK;
@@ -865,6 +910,8 @@ int srbdqp_create(const srbdqp_config* cfg, srbdqp_handle** out) {
 int srbdqp_destroy(srbdqp_handle* h) {
     if (!h) return SRBDQP_OK;
     (void)hipSetDevice(h->cfg.device);
+    delete h->aql;                                 // (waits for its last kernel)
+    h->aql = nullptr;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
     for (auto& sl : h->slots) {
@@ -888,6 +935,14 @@ const char* srbdqp_last_error(const srbdqp_handle* h) { return h ? h->err.c_str(
 
 const char* srbdqp_kernel_name(const srbdqp_handle* h) { return h ? h->kname : "none"; }
 
+const char* srbdqp_batch1_launch_path(const srbdqp_handle* h) {
+    if (!h || !h->aql_tried) return "undecided";
+    if (h->aql) return "aql";
+    static thread_local std::string s;
+    s = "hip: " + h->aql_why;
+    return s.c_str();
+}
+
 int srbdqp_stage_ptrs(srbdqp_handle* h, srbdqp_stage* out) {
     if (!h || !out) return SRBDQP_E_INVALID;
     *out = h->stage_h;
@@ -898,6 +953,10 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     if (!h) return SRBDQP_E_INVALID;
     if (B < 0 || B > h->stage_h.capacity) { h->err = "staged batch exceeds the staging capacity"; return SRBDQP_E_INVALID; }
     if (B == 0) return SRBDQP_OK;
+    {   // (the kernel of the call before this one published its completion word before it ended)
+        const int rq = aql_quiesce(h);
+        if (rq != SRBDQP_OK) return rq;
+    }
     const srbdqp_stage& d = h->stage_d;
     h->staged_neff = 0;
     h->staged_call = true;
@@ -928,6 +987,8 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
             while (*h->done_host != h->done_seq) {
                 if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
                     // slow or failed launch: hand over to the runtime (reports a fault, or returns once the kernel is done)
+                    const int rq = aql_quiesce(h);
+                    if (rq != SRBDQP_OK) return rq;
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                     break;
                 }
@@ -1020,6 +1081,10 @@ int srbdqp_prepare_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom) {
     if (B < 0 || B > h->stage_h.capacity) { h->err = "staged batch exceeds the staging capacity"; return SRBDQP_E_INVALID; }
     if (B == 0) return SRBDQP_OK;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    {
+        const int rq = aql_quiesce(h);
+        if (rq != SRBDQP_OK) return rq;
+    }
     const int maxs = staged_maxs(h, B);
     KArgs a = staged_args(h, B, use_pcom != 0, true, false);
     const int rc = launch_two_phase_any(h, a, h->stream, maxs, 0);
@@ -1093,6 +1158,8 @@ int srbdqp_synchronize(srbdqp_handle* h) {
         if (sl.last_tail) { HIP_TRY(h, hipStreamWaitEvent(sl.st, sl.last_tail, 0)); sl.last_tail = nullptr; }
         if (sl.tail_live) { const int rc = flush_slot(h, &sl, sl.st); if (rc != SRBDQP_OK) return rc; }
     }
+    const int rq = aql_quiesce(h);
+    if (rq != SRBDQP_OK) return rq;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SRBDQP_OK;
 }
@@ -1177,6 +1244,10 @@ int solve_device_impl(srbdqp_handle* h, int32_t B, const void* x0, const void* x
                       int32_t* status, int32_t* iters, void* stream) {
     if (B < 0 || (B > 0 && (!x0 || !x_ref || !foot || !contact || !u_out))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->staged_call) {
+        const int rq = aql_quiesce(h);
+        if (rq != SRBDQP_OK) return rq;
+    }
     KArgs a;
     std::memset(&a, 0, sizeof(a));
     fill_args(h->cfg, a);
@@ -1256,6 +1327,10 @@ int solve_host_impl(srbdqp_handle* h, int32_t B, size_t esz, const void* x0, con
     if (B < 0 || (B > 0 && (!x0 || !x_ref || !foot || !contact || !u_out))) { h->err = "null input/output pointer"; return SRBDQP_E_INVALID; }
     if (B == 0) return SRBDQP_OK;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    {
+        const int rq = aql_quiesce(h);
+        if (rq != SRBDQP_OK) return rq;
+    }
     const size_t N = (size_t)h->cfg.horizon, n = 12 * N, m = 20 * N, b = (size_t)B;
     Carver sz(nullptr);
     auto carve = [&](Carver& c, char*& dx0, char*& dxr, char*& dft, uint8_t*& dct, char*& dpc, char*& dwu,

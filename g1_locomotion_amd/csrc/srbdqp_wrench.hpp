@@ -1802,6 +1802,9 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         double e_prim_last = kInf * 1.0e10;
         float lastv0 = 0.0f, lastv1 = 0.0f, lastv2 = 0.0f, lastv3 = 0.0f;   // maxima of the last full check (restart rule)
         WADMM_DECL;
+        // the low-latency instantiation runs alone on its CU: what its loop costs depends on where its first instruction falls in a 64-byte fetch
+        // line (1467 ... 1494 cycles per iteration over five placements, profiles/r05_loop_alignment.txt), so the placement is pinned
+        if constexpr (XW == 2) asm volatile(".p2align 6");
         for (int k = 1; k <= a.max_iter + 1 && !done; ++k) {
             WADMM_T(0);
             R* vb = vbuf + (k & 1) * S::VB;

@@ -324,6 +324,10 @@ class BatchMPC:
     def kernel_name(self) -> str:
         return self._lib.srbdqp_kernel_name(self._h).decode()
 
+    def batch1_launch_path(self) -> str:
+        """"aql" (the library's own HSA queue) or "hip: <why>" for the staged one-QP call; "undecided" before the first one."""
+        return self._lib.srbdqp_batch1_launch_path(self._h).decode()
+
 
 class RaggedMPC:
     """Mixed-horizon batches (BASELINE.json configs[4]) over srbdqp_solve_ragged_*: QPs in any order, each with its own

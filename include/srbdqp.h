@@ -346,6 +346,12 @@ int srbdqp_last_kernel_parts_ms(srbdqp_handle* h, double* setup_ms, double* admm
 /* Name of the kernel variant the last solve launched ("wave_f64_n10_s2", "compact_f64_n10_s4", "wrench_f32_n20", ...). */
 const char* srbdqp_kernel_name(const srbdqp_handle* h);
 
+/* How the staged one-QP call (srbdqp_update_f64, srbdqp_solve_staged_f64 with B = 1) reaches the GPU on this handle: "aql" -- dispatch packets
+ * the library writes into an HSA user-mode queue of its own (csrc/srbdqp_aql.hpp; 1.4 us less per call than the runtime's launch) --, or
+ * "hip: <why not>" -- hipLaunchKernelGGL on the handle's stream, the same kernels (SRBDQP_NO_AQL=1 in the environment, SRBDQP_FLAG_NO_SPIN /
+ * _TIMING / _DEFER_TAIL on the handle, or the queue could not be set up), or "undecided" before the first such call.  Diagnostic. */
+const char* srbdqp_batch1_launch_path(const srbdqp_handle* h);
+
 /* Library version / build string. */
 const char* srbdqp_version(void);
 

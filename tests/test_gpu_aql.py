@@ -1,0 +1,115 @@
+"""The staged one-QP call through the library's own AQL queue (csrc/srbdqp_aql.hpp) against the same call through hipLaunchKernelGGL (SRBDQP_NO_AQL=1): the
+same kernels behind two doors, so every output is bit-equal -- first passes, restart passes queued behind them in the queue, calls interleaved with batch solves
+on HIP streams, and the handles the queue is not for (deferred tails, events, no spinning)."""
+import os
+
+import numpy as np
+import pytest
+
+import srbd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_first():
+    import torch  # load torch's HIP runtime before libsrbdqp.so so both share one
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _pair(N, **kw):
+    """one handle on the AQL queue, one on HIP (the environment variable is read at a handle's first staged one-QP call)"""
+    from g1_locomotion_amd import BatchMPC
+    os.environ.pop("SRBDQP_NO_AQL", None)
+    a = BatchMPC(horizon=N, **kw)
+    b = BatchMPC(horizon=N, **kw)
+    return a, b
+
+
+def _one(eng, x0, xr, ft, ct, N, no_aql):
+    st = eng.stage()
+    st["x0"][0] = x0; st["x_ref"][0] = xr; st["foot"][0] = ft.reshape(N, 12); st["contact"][0] = ct.reshape(N, 4)
+    if no_aql:
+        os.environ["SRBDQP_NO_AQL"] = "1"
+    try:
+        eng.solve_staged(1, want_x=True)
+    finally:
+        os.environ.pop("SRBDQP_NO_AQL", None)
+    return st["u"][0].copy(), st["x"][0].copy(), int(st["status"][0]), int(st["iters"][0])
+
+
+@pytest.mark.parametrize("N,schedule,suffix", [(10, "double", "wrench_f64_n10_lat"), (10, "single", "compact_f64_n10_s2_lat"), (10, "mixed", "wrench_f64_n10_lat"),
+                                               (8, "double", "wrench_f64_n8_lat"), (4, "single", "compact_f64_n4_s2_lat")])
+def test_aql_queue_equals_the_hip_launch(torch_first, built_lib, N, schedule, suffix):
+    B = 48
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=7700 + N, schedule=schedule)
+    a, b = _pair(N)
+    with a, b:
+        batch = a.solve(x0, xr, ft, ct)                       # (a batch solve on the HIP stream before, between and after the queue's kernels)
+        for q in range(B):
+            ra = _one(a, x0[q], xr[q], ft[q], ct[q], N, False)
+            rb = _one(b, x0[q], xr[q], ft[q], ct[q], N, True)
+            assert a.kernel_name() == b.kernel_name() and a.kernel_name().endswith("_lat"), (a.kernel_name(), suffix)
+            assert ra[2] == rb[2] and ra[3] == rb[3]
+            assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+            assert ra[2] == int(batch["status"][q])
+            if q % 16 == 7:
+                again = a.solve(x0, xr, ft, ct)
+                assert np.array_equal(again["u"], batch["u"])
+        assert a.batch1_launch_path() == "aql", a.batch1_launch_path()
+        assert b.batch1_launch_path().startswith("hip: SRBDQP_NO_AQL")
+
+
+def test_restart_passes_queue_behind_the_first_pass(torch_first, built_lib):
+    """QPs that pass the first restart mark: the second (and third) pass are further packets in the same queue, ordered by the barrier bit."""
+    N, B = 10, 4096
+    x0, xr, ft, ct = orc.synthetic_batch(B, N, seed=515, schedule="double")
+    a, b = _pair(N)
+    with a, b:
+        batch = a.solve(x0, xr, ft, ct)
+        slow = np.argsort(-batch["iters"])[:24]
+        assert batch["iters"][slow[-1]] > 55, "the sample holds no QP beyond the first restart mark"
+        for q in slow:
+            ra = _one(a, x0[q], xr[q], ft[q], ct[q], N, False)
+            rb = _one(b, x0[q], xr[q], ft[q], ct[q], N, True)
+            assert ra[2] == rb[2] == int(batch["status"][q]) and ra[3] == rb[3]
+            assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+            assert ra[3] > 55
+        assert a.batch1_launch_path() == "aql"
+
+
+def test_handles_the_queue_is_not_for_stay_on_hip(torch_first, built_lib):
+    from g1_locomotion_amd import BatchMPC, _lib
+    N = 10
+    x0, xr, ft, ct = orc.synthetic_batch(1, N, seed=3, schedule="double")
+    ref = None
+    for flags in (0, _lib.FLAG_DEFER_TAIL, _lib.FLAG_NO_SPIN):
+        with BatchMPC(horizon=N, flags=flags) as eng:
+            assert eng.batch1_launch_path() == "undecided"
+            r = _one(eng, x0[0], xr[0], ft[0], ct[0], N, False)
+            if ref is None:
+                ref = r
+                assert eng.batch1_launch_path() == "aql"
+            else:
+                assert eng.batch1_launch_path() in ("undecided", "aql")      # the queue may exist; these calls did not go through it
+                assert np.abs(r[0] - ref[0]).max() < 1e-4 and r[2] == ref[2]           # (these flags also pick other kernel instantiations)
+    with BatchMPC(horizon=N, timing=True) as eng:
+        r = _one(eng, x0[0], xr[0], ft[0], ct[0], N, False)
+        assert np.abs(r[0] - ref[0]).max() < 1e-4 and eng.last_kernel_ms() > 0.0
+
+
+def test_mpc_update_runs_on_the_queue(torch_first, built_lib):
+    """The reference's own call (run_simulation.py:106) ends up there."""
+    from g1_locomotion_amd import MPC
+    os.environ.pop("SRBDQP_NO_AQL", None)
+    mpc = MPC(dt=0.04)
+    mpc.init_matrices()
+    N = mpc.HORIZON_LENGTH
+    x0, xr, ft, ct = orc.synthetic_batch(1, N, seed=11, schedule="double")
+    mpc.x0[:, 0] = x0[0]; mpc.x_ref_hor[:] = xr[0]
+    u0, x1 = mpc.update(ct[0].reshape(N, 4), ft[0].reshape(N, 12), None, x_current=mpc.x0, one_rollout=True)
+    o = orc.update(orc.params_for(N), x0[0], xr[0], ft[0], ct[0])
+    assert np.abs(np.asarray(u0).reshape(-1) - np.asarray(o["u"]).reshape(-1)[:12]).max() < 2e-3
+    assert mpc._engine.batch1_launch_path() == "aql"
+    mpc.close()
