@@ -84,6 +84,8 @@ struct srbdqp_handle {
     int32_t* done_count = nullptr;
     int32_t done_seq = 0;
     bool signal_next = false;      // set by srbdqp_solve_staged_f64 around its launch
+    bool done_cs = false;          // the last launch publishes its completion word with the checksum of its outputs (KArgs::done_cs): wait_done() verifies it
+    bool done_cs_x = false;        // ... which cover x_out
     bool staged_call = false;      // inside srbdqp_solve_staged_f64 (with or without the completion word)
     int staged_neff = 0;           // ... with the largest number of presolved variables (3 x stance contacts) among its QPs
     bool lazy_restart = false;     // staged path: run only the first pass; the host starts the second one if a status asks for it
@@ -427,6 +429,18 @@ bool aql_launch_in(srbdqp_handle* h, hipStream_t st, const char* kd_format, int 
     return q->launch(k, &a, sizeof(KArgs), &in, sizeof(In), block, (uint32_t)lds);
 }
 
+// the one staged QP of a *_in launch whose host-visible outputs are u, x, status and iters in the staging arrays: completion word with their checksum, no fence
+// (srbdqp_common.hpp signal_done_checksum; SRBDQP_DONE_FENCE=1 in the environment keeps the fence: A/B)
+void staged_done_checksum(srbdqp_handle* h, KArgs& ai) {
+    static const bool off = [] { const char* e = std::getenv("SRBDQP_DONE_FENCE"); return e && e[0] && e[0] != '0'; }();
+    h->done_cs = false;
+    if (off || !ai.done_flag || ai.B != 1 || ai.u_out != h->stage_d.u || ai.status != h->stage_d.status || ai.iters != h->stage_d.iters ||
+        (ai.x_out && ai.x_out != h->stage_d.x) || (ai.y_out && !ai.y_capped_only)) return;
+    ai.done_cs = 1;
+    h->done_cs = true;
+    h->done_cs_x = ai.x_out != nullptr;
+}
+
 // one staged QP whose inputs still sit in the library's own staging arrays: they ride in the kernel-argument segment (srbdqp_common.hpp StagedIn)
 template <int N>
 bool staged_inline_inputs(const srbdqp_handle* h, const KArgs& a, srbdqp::StagedIn<N>& in) {
@@ -473,6 +487,7 @@ int launch_compact(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
                 if (rc1 != SRBDQP_OK) return rc1;
                 KArgs ai = a;
                 ai.inline_in = 1;
+                staged_done_checksum(h, ai);
                 if (aql_launch_in(h, st, "_ZN6srbdqp24srbdqp_compact_kernel_inILi%dELi%dEEEvNS_5KArgsENS_8StagedInIXT_EEE.kd", N, MAXS, ai, in, srbdqp::kThreads, lds1)) return SRBDQP_OK;
                 rc1 = aql_quiesce(h);
                 if (rc1 != SRBDQP_OK) return rc1;
@@ -556,6 +571,7 @@ int launch_wrench_t(srbdqp_handle* h, const KArgs& a, hipStream_t st) {
                         if (rcl != SRBDQP_OK) return rcl;
                         KArgs ai = a;
                         ai.inline_in = 1;
+                        staged_done_checksum(h, ai);
                         if (aql_launch_in(h, st, "_ZN6srbdqp23srbdqp_wrench_kernel_inILi%dELi%dEEEvNS_5KArgsENS_8StagedInIXT_EEE.kd", N, XW, ai, in, SL::BT, ldsl)) return SRBDQP_OK;
                         rcl = aql_quiesce(h);
                         if (rcl != SRBDQP_OK) return rcl;
@@ -960,6 +976,7 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     const srbdqp_stage& d = h->stage_d;
     h->staged_neff = 0;
     h->staged_call = true;
+    h->done_cs = false;            // (set again by a launch that publishes a checksum)
     struct Reset { srbdqp_handle* h; ~Reset() { h->signal_next = false; h->staged_call = false; h->maxs_override = 0; h->staged_neff = 0; } } reset_on_return{h};
     {   // same per-batch kernel choice as the host-buffer API, from the staged contact flags
         int worst = 0;
@@ -980,11 +997,33 @@ int srbdqp_solve_staged_f64(srbdqp_handle* h, int32_t B, int32_t use_pcom, int32
     // spinning on it skips the stream's completion interrupt (~15 us).  Other kernel variants: stream synchronise.
     const int rk = resolve_kernel(h->cfg);
     const bool spin = (rk == SRBDQP_KERNEL_COMPACT || rk == SRBDQP_KERNEL_WRENCH) && !(h->cfg.flags & SRBDQP_FLAG_NO_SPIN);
+    // (a word that came with a checksum -- KArgs::done_cs -- counts once the outputs read back agree with it: they travel without a fence in front of the word)
+    auto outputs_there = [&]() -> bool {
+        if (!h->done_cs) return true;
+        const size_t Nn = (size_t)h->cfg.horizon;
+        const volatile uint64_t* u = reinterpret_cast<const volatile uint64_t*>(h->stage_h.u);
+        uint64_t x = 0;
+        for (size_t i = 0; i < 12 * Nn; ++i) x ^= u[i];
+        if (h->done_cs_x) {
+            const volatile uint64_t* xs = reinterpret_cast<const volatile uint64_t*>(h->stage_h.x);
+            for (size_t i = 0; i < 13 * (Nn + 1); ++i) x ^= xs[i];
+        }
+        x ^= (uint64_t)(uint32_t)*reinterpret_cast<const volatile int32_t*>(h->stage_h.status) | ((uint64_t)(uint32_t)*reinterpret_cast<const volatile int32_t*>(h->stage_h.iters) << 32);
+        // the records: {sequence number, how many records, XOR of one row of 16 lanes} every 16 bytes (srbdqp_common.hpp signal_done_checksum)
+        const volatile int32_t* rec = h->done_host;
+        const int32_t nrec = rec[1];
+        if (nrec < 1 || nrec > 16) return false;
+        for (int32_t r = 0; r < nrec; ++r) {
+            if (rec[4 * r] != h->done_seq || rec[4 * r + 1] != nrec) return false;
+            x ^= (uint64_t)(uint32_t)rec[4 * r + 2] | ((uint64_t)(uint32_t)rec[4 * r + 3] << 32);
+        }
+        return x == 0;
+    };
     auto wait_done = [&]() -> int {
         if (spin) {
             const auto t0 = std::chrono::steady_clock::now();
             unsigned polls = 0;
-            while (*h->done_host != h->done_seq) {
+            while (*h->done_host != h->done_seq || !outputs_there()) {
                 if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
                     // slow or failed launch: hand over to the runtime (reports a fault, or returns once the kernel is done)
                     const int rq = aql_quiesce(h);

@@ -70,6 +70,7 @@ struct KArgs {
     char* tail_lists;        // [3][tail_cap] records of kTailRecDoubles doubles, or null (no deferral)
     int32_t* tail_cnt;       // [3] record counts
     int32_t tail_cap, tail_wgs, tail_iin, tail_iout, tail_izero;
+    int32_t done_cs;         // the *_in kernels: publish the completion word WITH the checksum of the outputs and without a system-scope fence (signal_done_checksum)
     int32_t* done_flag;      // low-latency completion: GPU-mapped host word that receives done_value once every QP of the
     int32_t* done_count;     //   launch has stored its outputs (done_count: device counter of finished workgroups), or null
     int32_t done_value;
@@ -304,6 +305,32 @@ __device__ __forceinline__ void signal_done(const KArgs& a) {
     }
 }
 
+// ... for ONE staged QP (the *_in kernels, KArgs::done_cs): no fence and no barrier.  The completion word goes out right behind the stores and carries a checksum
+// of them: every row of 16 lanes XORs the 64-bit patterns its lanes stored for the host (four DPP steps) and its first lane stores ONE 16-byte record
+// {sequence number, number of records, XOR} at done_flag + 16 * row -- 4 to 16 records, at most the 256 bytes behind the staging arrays.  The host that sees the
+// number in record 0 waits until every record carries it and the XOR of the records equals the XOR of what it reads back from the output arrays (srbdqp.hip
+// wait_done): whatever order the writes arrive in, it never takes outputs that are not all there.  (The fence above is a round trip to the host's memory in front of
+// the word, tools/pcie_probe.hip; a reduction across the workgroup would put a barrier and an LDS round trip there instead.)
+// cs: this thread's share of the XOR.  BT: threads that call this (all of them alive).
+__device__ __forceinline__ unsigned long long done_cs_pack(int status, int iters) { return (unsigned long long)(unsigned)status | ((unsigned long long)(unsigned)iters << 32); }
+__device__ __forceinline__ unsigned dpp_xor_row(unsigned v) {
+    v ^= (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1, 0, 3, 2]
+    v ^= (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2, 3, 0, 1]
+    v ^= (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v ^= (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
+    return v;                                                                               // every lane: the XOR over its row of 16
+}
+template <int BT>
+__device__ __forceinline__ void signal_done_checksum(int32_t* done_flag, int32_t done_value, unsigned long long cs) {
+    static_assert(BT % 16 == 0 && BT / 16 <= 16, "one 16-byte record per row of 16 lanes in 256 bytes");
+    const unsigned lo = dpp_xor_row((unsigned)cs), hi = dpp_xor_row((unsigned)(cs >> 32));
+    if ((threadIdx.x & 15) == 0) {
+        uint4 v;
+        v.x = (unsigned)done_value; v.y = (unsigned)(BT / 16); v.z = lo; v.w = hi;
+        reinterpret_cast<uint4*>(done_flag)[threadIdx.x >> 4] = v;
+    }
+}
+
 template <int N>
 struct Dims {
     static constexpr int n = 12 * N;             // decision variables
@@ -425,12 +452,17 @@ __device__ __forceinline__ void block_max(double (&v)[NV], double* red) {
 // a10: roll the linear model forward with the optimal forces and store u (newtons), x horizon, status.
 // xs (LDS, n doubles) holds the scaled solution u_hat.
 // ---------------------------------------------------------------------------------------------------------
-template <int N, class L, int BT = kThreads>
-__device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_out, int b, double* sm, const double* uh, double* scratch /* >= 12N */) {
+// CS: *cs ^= the 64-bit pattern of every value this thread stores to u_out / x_out (signal_done_checksum)
+template <int N, class L, int BT = kThreads, bool CS = false>
+__device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_out, int b, double* sm, const double* uh, double* scratch /* >= 12N */, unsigned long long* cs = nullptr) {
     using S = L;
     constexpr int n = Dims<N>::n;
     const int t = threadIdx.x;
-    for (int c = t; c < n; c += BT) u_out[(size_t)b * n + c] = a.s * uh[c];
+    for (int c = t; c < n; c += BT) {
+        const double v = a.s * uh[c];
+        u_out[(size_t)b * n + c] = v;
+        if constexpr (CS) *cs ^= (unsigned long long)__double_as_longlong(v);
+    }
     if (a.u_dev) for (int c = t; c < n; c += BT) a.u_dev[(size_t)b * n + c] = a.s * uh[c];
     if (!x_out) return;
     const double* x0 = sm + S::o_x0;
@@ -513,7 +545,9 @@ __device__ void rollout_and_store_to(const KArgs& a, double* u_out, double* x_ou
     for (int idx = t; idx < 13 * (N + 1); idx += BT) {
         const int k = idx / 13, comp = idx % 13;
         const double* src = (k == 0 || comp == 12) ? (x0 + comp) : ((comp >= 6) ? (scratch + (k - 1) * 6 + comp - 6) : (pa + (k - 1) * 6 + comp));
-        xo[idx] = *src;
+        const double v = *src;
+        xo[idx] = v;
+        if constexpr (CS) *cs ^= (unsigned long long)__double_as_longlong(v);
     }
 }
 template <int N, class L, int BT = kThreads>

@@ -358,6 +358,23 @@ __device__ __forceinline__ void admm_wave_iterations(const KArgs& a, const QpIo&
 // TAIL1 (the staged batch-1 instantiation, compiled for one workgroup's worth of registers): the four waves set the problem up, then wave 0 alone runs the
 // one-wave iteration (a K^-1 row per lane, no LDS operation and no barrier in the loop: 0.36 us per iteration against 0.52 for the 4-wave loop at batch 1,
 // tools/batch1_kernel_probe.py) while the others wait at the barrier in front of the roll-out, which all four share again.
+// roll-out, stores and the completion word of a QP whose status / iteration count thread 0 has already stored; CS (the batch-1 instantiations): with the checksum of
+// the outputs instead of a system-scope fence when the launch asks for it (KArgs::done_cs, srbdqp_common.hpp signal_done_checksum)
+template <int N, class S, bool CS>
+__device__ __forceinline__ void rollout_store_signal(const KArgs& a, int b, double* sm, int status, int iters_total) {
+    if constexpr (CS) {
+        if (a.done_cs) {
+            unsigned long long cs = 0;
+            rollout_and_store_to<N, S, kThreads, true>(a, a.u_out, a.x_out, b, sm, sm + S::o_xs, sm + S::o_rhs, &cs);
+            if (threadIdx.x == 0) cs ^= done_cs_pack(status, iters_total);
+            signal_done_checksum<kThreads>(a.done_flag, a.done_value, cs);
+            return;
+        }
+    }
+    rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
+    signal_done(a);
+}
+
 template <int N, int MAXS, bool SPLIT = false, bool DUMP = false, bool TAIL1 = false>
 __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* sm) {
     using S = CompactSmem<N, MAXS>;
@@ -443,6 +460,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
             if (a.iters) a.iters[b] = 0;
         }
         __syncthreads();
+        if constexpr (TAIL1) { rollout_store_signal<N, S, true>(a, b, sm, (imisc[1] != 0) ? kStatusContactBound : 1, 0); return; }
         rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
         if constexpr (SPLIT) { if (t == 0) a.ws[(size_t)b * SplitWs<N, MAXS>::doubles + S::o_misc + 1] = 1.0; }
         signal_done(a);
@@ -827,8 +845,7 @@ __device__ __forceinline__ void compact_qp(const KArgs& a, const int b, double* 
             if (a.iters) a.iters[b] = iters + a.iters_base;
         }
         SRBDQP_STAMP(a, b, 10);
-        rollout_and_store<N, S>(a, b, sm, sm + S::o_xs, sm + S::o_rhs);
-        signal_done(a);
+        rollout_store_signal<N, S, true>(a, b, sm, status, iters + a.iters_base);
         SRBDQP_STAMP(a, b, 11);
         if (a.stamps && t == 0) a.stamps[(size_t)b * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();
         return;

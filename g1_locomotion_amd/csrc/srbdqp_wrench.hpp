@@ -637,6 +637,8 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     const double rho_b = unis(SRBDQP_RHO_OF(a, b));   // (per-QP values are wave-uniform: scalar registers, see uni())
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr bool CSUM = XW > 0 && sizeof(TIO) == 8 && MODE == 0 && S::LT <= 256;   // the low-latency instantiations: the completion word may carry a checksum (KArgs::done_cs)
+    unsigned long long cs_host = 0;                                  // XOR of the 64-bit patterns this thread stores for the host
     int mcol = lane & 15, kq = lane >> 4;
     TT* T = reinterpret_cast<TT*>(sm + S::o_T);
     int* igsz = reinterpret_cast<int*>(sm + S::o_int);            // gsz[N]
@@ -765,7 +767,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     if (na == 0) {   // nothing to solve: all forces 0
         for (int c = t; c < n; c += BT) sm[S::o_xs + c] = 0.0;
         if (a.y_out) for (int i = t; i < m; i += BT) reinterpret_cast<TIO*>(a.y_out)[row0 * 20 + i] = TIO(0);
-        if (t == 0) { if (a.status) a.status[b] = 1; if (a.iters) a.iters[b] = 0; }
+        if (t == 0) { if (a.status) a.status[b] = 1; if (a.iters) a.iters[b] = 0; cs_host = done_cs_pack(1, 0); }
         __syncthreads();
     } else {
 
@@ -1234,7 +1236,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     if (sm[S::o_misc] != 0.0) {   // degenerate contact geometry: report, return zero forces
         for (int c = t; c < n; c += BT) sm[S::o_xs + c] = 0.0;
         if (a.y_out) for (int i = t; i < m; i += BT) reinterpret_cast<TIO*>(a.y_out)[row0 * 20 + i] = TIO(0);
-        if (t == 0) { if (a.status) a.status[b] = -1; if (a.iters) a.iters[b] = 0; }
+        if (t == 0) { if (a.status) a.status[b] = -1; if (a.iters) a.iters[b] = 0; cs_host = done_cs_pack(-1, 0); }
         __syncthreads();
     } else {
     SRBDQP_STAMP(a, b, 2);
@@ -1937,6 +1939,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
     if (t == 0) {
         if (a.status) a.status[b] = status;
         if (a.iters) a.iters[b] = iters + a.iters_base;
+        cs_host = done_cs_pack(status, iters + a.iters_base);
     }
     __syncthreads();
     }   // MODE
@@ -1951,12 +1954,25 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
         const size_t row0 = a.row_off ? (size_t)a.row_off[b] : (size_t)b * N;
         TIO* uo = reinterpret_cast<TIO*>(a.u_out) + row0 * 12;
         ESTAMP(a, 4);
-        for (int c = t; c < n; c += LT) uo[c] = (TIO)(a.s * uh[c]);
+        for (int c = t; c < n; c += LT) {
+            const TIO v = (TIO)(a.s * uh[c]);
+            uo[c] = v;
+            if constexpr (CSUM) cs_host ^= (unsigned long long)__double_as_longlong((double)v);
+        }
         ESTAMP(a, 5);
         if constexpr (sizeof(TIO) == 8) { if (a.u_dev) for (int c = t; c < n; c += LT) a.u_dev[row0 * 12 + c] = a.s * uh[c]; }
+        // (the completion word's address and value in scalar registers now: left to the end, their loads from the argument segment are two more round trips)
+        int32_t* dflag = a.done_flag;
+        int32_t dval = a.done_value, dcs = a.done_cs;
+        if constexpr (CSUM) asm volatile("" : "+s"(dflag), "+s"(dval), "+s"(dcs));
         if (a.x_out) {
             const double* x0 = sm + S::o_x0;
             double* sj = scratch + 6 * N;
+            // the rows of x, laid out as they go out, where u_hat was (dead behind the first barrier) -- every stage below writes its entries in place and the
+            // store loop is a plain copy.  (Until round 5 the store loop formed Euler angles and positions entry by entry inside a five-way branch over
+            // (k, component) -- 4.1 k of the roll-out's 6.5 k cycles at batch 1 --, then gathered them from three arrays through a divergent address select.)
+            double* xrow = sm + S::o_xs;
+            static_assert(13 * (N + 1) <= n + 6 * N, "the rows of x end in front of the per-step sums");
             for (int idx = t; idx < 6 * N; idx += LT) {
                 const int j = idx / 6, comp = idx % 6;
                 const double* u = uh + 12 * j;
@@ -1973,6 +1989,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             }
             __syncthreads();
             ESTAMP(a, 6);
+            // angular and linear velocities of the steps 1 .. N; row 0 (= x0) and the gravity column from the far end of the workgroup
             for (int idx = t; idx < 6 * N; idx += LT) {
                 const int k = idx / 6 + 1, comp = idx % 6;
                 double acc2 = 0.0;   // (all N steps, the later ones adding exact zeros: the reads of all trips in flight together, srbdqp_common.hpp rollout_and_store_to)
@@ -1984,54 +2001,54 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 }
                 double v = x0[6 + comp] + a.dt * a.s * acc2;
                 if (comp == 5) v += (double)k * a.dt * x0[12];
-                scratch[idx] = v;
+                xrow[13 * k + 6 + comp] = v;
             }
+            for (int e = LT - 1 - t; e < 13 + N; e += LT) xrow[e < 13 ? e : 13 * (e - 12) + 12] = x0[e < 13 ? e : 12];
             __syncthreads();
             ESTAMP(a, 7);
-            // Euler angles and CoM positions of the steps 1 .. N as ONE more prefix stage (6 N entries, a lane each, the reads of every trip in flight) and the rows
-            // of x as a plain gather behind it.  Until round 5 the store loop formed them entry by entry inside a five-way branch over (k, component) -- two trips
-            // of divergent arms with up to 60 dependent LDS reads each: 4.1 k of the roll-out's 6.5 k cycles at batch 1.
-            double* pa = sj;                                             // (the per-step sums are dead behind the stage above)
-            // (the two kinds of entries on different waves where the workgroup has more than one: no divergent arms)
+            // Euler angles and CoM positions of the steps 1 .. N as ONE more prefix stage (6 N entries, a lane each, the reads of every trip in flight; the two
+            // kinds of entries on different waves where the workgroup has more than one: no divergent arms)
             constexpr int PA_OFF = (64 * ((3 * N + 63) / 64) + 3 * N <= LT) ? 64 * ((3 * N + 63) / 64) : 3 * N;
-            static_assert(PA_OFF + 3 * N <= LT, "one pass over the angle and position entries");
-            if (t < 3 * N || (t >= PA_OFF && t < PA_OFF + 3 * N)) {
-                const bool posn = t >= PA_OFF;
-                const int e = posn ? t - PA_OFF : t;
-                const int k = e / 3 + 1, comp = e % 3 + (posn ? 3 : 0), idx = 6 * (k - 1) + comp;
-                double acc2;
-                if (posn) {                                              // position: x0 + dt (v_0 + ... + v_{k-1})
-                    acc2 = x0[6 + comp];
-                    if constexpr (N <= 12) {
+            for (int tt = t; tt < PA_OFF + 3 * N; tt += LT) {
+                if (tt < 3 * N || tt >= PA_OFF) {
+                    const bool posn = tt >= PA_OFF;
+                    const int e = posn ? tt - PA_OFF : tt;
+                    const int k = e / 3 + 1, c3 = e % 3;
+                    double acc2 = 0.0;
+                    if (posn) {                                              // position: p_0 + dt (v_0 + ... + v_{k-1})
+                        if constexpr (N <= 12) {
 #pragma unroll
-                        for (int l = 1; l < N; ++l) { const double sv = scratch[(l - 1) * 6 + comp]; acc2 += (l < k) ? sv : 0.0; }
-                    } else {
-                        for (int l = 1; l < k; ++l) acc2 += scratch[(l - 1) * 6 + comp];
-                    }
-                } else {                                                 // Euler angles: x0 + dt sum_{l < k} Rz(psi_l)' omega_l
-                    acc2 = 0.0;
-                    auto term_of = [&](int l) {
-                        const double* Tm = sm + S::o_tm + l * 9 + comp * 3;
-                        const double* wv2 = (l == 0) ? (x0 + 6) : (scratch + (l - 1) * 6);
-                        return Tm[0] * wv2[0] + Tm[1] * wv2[1] + Tm[2] * wv2[2];
-                    };
-                    if constexpr (N <= 12) {
+                            for (int l = 0; l < N; ++l) { const double sv = xrow[13 * l + 9 + c3]; acc2 += (l < k) ? sv : 0.0; }
+                        } else {
+                            for (int l = 0; l < k; ++l) acc2 += xrow[13 * l + 9 + c3];
+                        }
+                    } else {                                                 // Euler angles: theta_0 + dt sum_{l < k} Rz(psi_l)' omega_l
+                        auto term_of = [&](int l) {
+                            const double* Tm = sm + S::o_tm + l * 9 + c3 * 3;
+                            const double* wv2 = xrow + 13 * l + 6;
+                            return Tm[0] * wv2[0] + Tm[1] * wv2[1] + Tm[2] * wv2[2];
+                        };
+                        if constexpr (N <= 12) {
 #pragma unroll
-                        for (int l = 0; l < N; ++l) { const double term = term_of(l); acc2 += (l < k) ? term : 0.0; }
-                    } else {
-                        for (int l = 0; l < k; ++l) acc2 += term_of(l);
+                            for (int l = 0; l < N; ++l) { const double term = term_of(l); acc2 += (l < k) ? term : 0.0; }
+                        } else {
+                            for (int l = 0; l < k; ++l) acc2 += term_of(l);
+                        }
                     }
+                    const int comp = c3 + (posn ? 3 : 0);
+                    xrow[13 * k + comp] = x0[comp] + a.dt * acc2;
                 }
-                pa[idx] = x0[comp] + a.dt * acc2;
             }
             __syncthreads();
             TIO* xo = reinterpret_cast<TIO*>(a.x_out) + (row0 + (size_t)b) * 13;      // N + 1 rows per QP
             for (int idx = t; idx < 13 * (N + 1); idx += LT) {
-                const int k = idx / 13, comp = idx % 13;
-                const double* src = (k == 0 || comp == 12) ? (x0 + comp) : ((comp >= 6) ? (scratch + (k - 1) * 6 + comp - 6) : (pa + (k - 1) * 6 + comp));
-                xo[idx] = (TIO)(*src);
+                const TIO v = (TIO)xrow[idx];
+                xo[idx] = v;
+                if constexpr (CSUM) cs_host ^= (unsigned long long)__double_as_longlong((double)v);
             }
         }
+        // the one staged QP: the completion word with the checksum of what went to the host, no fence (srbdqp_common.hpp signal_done_checksum)
+        if constexpr (CSUM) { if (dcs) signal_done_checksum<LT>(dflag, dval, cs_host); }
     }
     SRBDQP_STAMP(a, b, 9);
 }
@@ -2052,7 +2069,7 @@ __global__ __launch_bounds__((WrenchSmem<N, 8, SPW, XW>::BT), WPS) void srbdqp_w
     // hoist the body's lane-index expressions out of it and spill them (750 bytes of scratch per lane at N = 20)
     if ((!a.count_ptr || (int)blockIdx.x < *a.count_ptr) && !SRBDQP_RESTART_SKIP(a, SRBDQP_QP_INDEX(a)))
         wrench_qp<N, R, TIO, MODE, TT, SPW, XW>(a, SRBDQP_QP_INDEX(a), sm);
-    signal_done(a);   // staged path: every workgroup of the launch reports once, with or without work
+    signal_done(a);   // staged path: every workgroup of the launch reports once, with or without work (done_cs is for the *_in kernels only)
 }
 
 // ... the low-latency instantiation with the QP's inputs in the kernel-argument segment (StagedIn, srbdqp_common.hpp): one staged QP, first pass
@@ -2061,7 +2078,7 @@ __global__ __launch_bounds__((WrenchSmem<N, 8, 5, XW>::BT), 1) void srbdqp_wrenc
     extern __shared__ __attribute__((aligned(16))) double sm[];
     (void)in;                                            // (read through staged_in_base(): a.inline_in is set)
     wrench_qp<N, double, double, 0, double, 5, XW>(a, 0, sm);
-    signal_done(a);
+    if (!(XW > 0 && a.done_cs)) signal_done(a);
 }
 
 }  // namespace srbdqp

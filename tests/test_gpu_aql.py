@@ -113,3 +113,27 @@ def test_mpc_update_runs_on_the_queue(torch_first, built_lib):
     assert np.abs(np.asarray(u0).reshape(-1) - np.asarray(o["u"]).reshape(-1)[:12]).max() < 2e-3
     assert mpc._engine.batch1_launch_path() == "aql"
     mpc.close()
+
+
+@pytest.mark.parametrize("schedule", ["double", "single"])
+def test_completion_word_with_checksum_never_hands_over_partial_outputs(torch_first, built_lib, schedule):
+    """The one staged QP's completion word leaves the GPU right behind its outputs, without a fence, and carries their XOR; the host takes the outputs only once what it
+    reads agrees with it (srbdqp_common.hpp signal_done_checksum, srbdqp.hip wait_done).  Three different QPs in turn, 4000 calls: every call returns exactly what
+    the first call for its QP returned -- an output array that still held the previous call's values would show."""
+    from g1_locomotion_amd import BatchMPC
+    N = 10
+    x0, xr, ft, ct = orc.synthetic_batch(3, N, seed=909, schedule=schedule)
+    os.environ.pop("SRBDQP_NO_AQL", None)
+    with BatchMPC(horizon=N) as eng:
+        first = [None, None, None]
+        for i in range(4000):
+            q = i % 3
+            r = _one(eng, x0[q], xr[q], ft[q], ct[q], N, False)
+            if first[q] is None:
+                first[q] = r
+                o = orc.update(orc.params_for(N), x0[q], xr[q], ft[q], ct[q])
+                assert r[2] == o["status"] and np.abs(r[0] - o["u"]).max() < 2e-3 and np.abs(r[1] - o["x"]).max() < 1e-4
+            else:
+                assert r[2] == first[q][2] and r[3] == first[q][3], i
+                assert np.array_equal(r[0], first[q][0]) and np.array_equal(r[1], first[q][1]), i
+        assert not np.array_equal(first[0][0], first[1][0]) and not np.array_equal(first[1][0], first[2][0])
