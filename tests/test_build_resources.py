@@ -22,7 +22,7 @@ KNOWN = {
     "srbdqp_wrench_kernel<12, float, float, 0, 3, double, 5, 0>": 116,
     "srbdqp_wrench_kernel<16, float, float, 0, 3, double, 5, 0>": 228,
     "srbdqp_wrench_kernel<10, float, float, 0, 3, float, 5, 0>": 28,
-    "srbdqp_wrench_kernel<24, float, float, 0, 3, float, 5, 0>": 48,
+    "srbdqp_wrench_kernel<24, float, float, 0, 3, float, 5, 0>": 64,
     "srbdqp_wrench_kernel<24, float, float, 0, 2, double, 5, 3>": 92,
     "srbdqp_wrench_kernel<24, double, double, 0, 1, double, 5, 3>": 20,
 }
