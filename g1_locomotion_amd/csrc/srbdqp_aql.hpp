@@ -208,8 +208,12 @@ public:
     bool launch(const AqlKernel& k, const void* a0, size_t n0, const void* a1, size_t n1, uint32_t block, uint32_t dynamic_lds) {
         if (!k.ok || n0 + n1 != k.kernarg_bytes || n0 + n1 > kSlotBytes) return false;
         char* ka = kbuf_ + (size_t)(slot_++ % kSlots) * kSlotBytes;
-        std::memcpy(ka, a0, n0);
-        std::memcpy(ka + n0, a1, n1);
+        // (through the write-combining mapping of the BAR: whole 32-byte non-temporal stores leave the core in half the time of memcpy()'s -- 0.18 against
+        //  0.36 us for 2944 bytes, tools/wc_copy_probe.cpp)
+        alignas(64) char img[kSlotBytes];
+        std::memcpy(img, a0, n0);
+        std::memcpy(img + n0, a1, n1);
+        stream_out(ka, img, n0 + n1);
         _mm_sfence();                                                  // the write-combining buffers drain before anything below leaves the core
         if (d_->hdp_flush) *d_->hdp_flush = 1u;                        // (posted, ahead of the doorbell on the same link)
         hsa_signal_add_relaxed(sig_, 1);                                // one per packet in flight: a restart pass may be queued behind a first pass still ending
@@ -246,6 +250,15 @@ public:
 
 private:
     AqlQueue() = default;
+    __attribute__((target("avx2"))) static void stream_out_avx2(char* d, const char* s, size_t n) {
+        size_t i = 0;
+        for (; i + 32 <= n; i += 32) _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i), _mm256_load_si256(reinterpret_cast<const __m256i*>(s + i)));
+        for (; i + 8 <= n; i += 8) _mm_stream_si64(reinterpret_cast<long long*>(d + i), *reinterpret_cast<const long long*>(s + i));
+    }
+    static void stream_out(char* d, const char* s, size_t n) {          // d, s 32-byte aligned, n a multiple of 8
+        static const bool avx2 = __builtin_cpu_supports("avx2");
+        if (avx2) stream_out_avx2(d, s, n); else std::memcpy(d, s, n);
+    }
     AqlDevice* d_ = nullptr;
     hsa_queue_t* q_ = nullptr;
     char* kbuf_ = nullptr;
