@@ -34,7 +34,7 @@ EXPORTS = (
     "srbdqp_assemble_f64", "srbdqp_assemble_wrench_f64",
     "srbdqp_ragged_create", "srbdqp_ragged_destroy", "srbdqp_ragged_last_error", "srbdqp_ragged_flush", "srbdqp_solve_ragged_device_f64", "srbdqp_solve_ragged_f64",
     "srbdqp_solve_ragged_device_f32", "srbdqp_solve_ragged_f32", "srbdqp_solve_ragged_warm_device_f64", "srbdqp_solve_ragged_warm_device_f32",
-    "srbdqp_set_schedule_hint", "srbdqp_flush", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_update_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_batch1_launch_path", "srbdqp_version",
+    "srbdqp_set_schedule_hint", "srbdqp_flush", "srbdqp_shard_range", "srbdqp_gather_u0_f64", "srbdqp_stage_ptrs", "srbdqp_solve_staged_f64", "srbdqp_update_f64", "srbdqp_prepare_staged_f64", "srbdqp_solve_prepared_f64", "srbdqp_set_stamp_buffer", "srbdqp_synchronize", "srbdqp_last_kernel_ms", "srbdqp_last_kernel_parts_ms", "srbdqp_kernel_name", "srbdqp_batch1_launch_path", "srbdqp_version",
     # include/srbdqp_cascade.h
     "srbdqp_swing_f64", "srbdqp_swing_device_f64", "srbdqp_wbid_reference_f64", "srbdqp_wbid_reference_device_f64",
     "srbdqp_mpc_inputs_f64", "srbdqp_mpc_inputs_device_f64",
@@ -154,6 +154,10 @@ def load():
     lib.srbdqp_set_schedule_hint.restype = C.c_int
     lib.srbdqp_flush.argtypes = [H, C.c_void_p]
     lib.srbdqp_flush.restype = C.c_int
+    lib.srbdqp_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.srbdqp_shard_range.restype = C.c_int
+    lib.srbdqp_gather_u0_f64.argtypes = [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.srbdqp_gather_u0_f64.restype = C.c_int
     lib.srbdqp_stage_ptrs.argtypes = [H, C.POINTER(Stage)]
     lib.srbdqp_stage_ptrs.restype = C.c_int
     lib.srbdqp_solve_staged_f64.argtypes = [H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]

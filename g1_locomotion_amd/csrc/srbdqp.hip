@@ -1175,6 +1175,52 @@ int srbdqp_set_stamp_buffer(srbdqp_handle* h, void* device_ptr) {
     return SRBDQP_OK;
 }
 
+int srbdqp_shard_range(int64_t total, int32_t world, int32_t rank, int64_t* first, int64_t* count) {
+    if (world < 1 || rank < 0 || rank >= world || total < 0 || !first || !count) return SRBDQP_E_INVALID;
+    const int64_t base = total / world, rem = total % world;
+    *first = rank * base + (rank < rem ? rank : rem);
+    *count = base + (rank < rem ? 1 : 0);
+    return SRBDQP_OK;
+}
+
+int srbdqp_gather_u0_f64(srbdqp_handle* h, const double* u_local, int64_t B_local, double* u0_all, void* rccl_comm, void* stream) {
+    if (!h) return SRBDQP_E_INVALID;
+    if (!u_local || !u0_all || !rccl_comm || B_local < 0) { h->err = "srbdqp_gather_u0_f64: null pointer or negative count"; return SRBDQP_E_INVALID; }
+    // RCCL by name, once per process: the library does not link it (a single-GPU consumer never needs it)
+    struct Rccl {
+        int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+        int (*user_rank)(void*, int*) = nullptr;
+        int (*count)(void*, int*) = nullptr;
+        const char* (*error_string)(int) = nullptr;
+        bool ok = false;
+        Rccl() {
+            void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) return;
+            all_gather = reinterpret_cast<decltype(all_gather)>(dlsym(lib, "ncclAllGather"));
+            user_rank = reinterpret_cast<decltype(user_rank)>(dlsym(lib, "ncclCommUserRank"));
+            count = reinterpret_cast<decltype(count)>(dlsym(lib, "ncclCommCount"));
+            error_string = reinterpret_cast<decltype(error_string)>(dlsym(lib, "ncclGetErrorString"));
+            ok = all_gather && user_rank && count;
+        }
+    };
+    static const Rccl rccl;
+    if (!rccl.ok) { h->err = "srbdqp_gather_u0_f64: librccl.so.1 (ncclAllGather, ncclCommUserRank, ncclCommCount) is not loadable"; return SRBDQP_E_HIP; }
+    auto fail = [&](const char* what, int rc) { h->err = std::string("srbdqp_gather_u0_f64: ") + what + ": " + (rccl.error_string ? rccl.error_string(rc) : "RCCL error"); return SRBDQP_E_HIP; };
+    int rank = 0, world = 0, rc;
+    if ((rc = rccl.user_rank(rccl_comm, &rank)) != 0) return fail("ncclCommUserRank", rc);
+    if ((rc = rccl.count(rccl_comm, &world)) != 0) return fail("ncclCommCount", rc);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+    if (B_local == 0) return SRBDQP_OK;
+    double* slot = u0_all + (size_t)rank * (size_t)B_local * 12;
+    const long long items = (long long)B_local * 12;
+    hipLaunchKernelGGL(srbdqp::srbdqp_pack_u0_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, u_local, slot, items, h->cfg.horizon);
+    HIP_TRY(h, hipGetLastError());
+    if ((rc = rccl.all_gather(slot, u0_all, (size_t)items, /* ncclDouble */ 8, rccl_comm, st)) != 0) return fail("ncclAllGather", rc);
+    return SRBDQP_OK;
+}
+
 int srbdqp_flush(srbdqp_handle* h, void* stream) {
     if (!h) return SRBDQP_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->cfg.device));

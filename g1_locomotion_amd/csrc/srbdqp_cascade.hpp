@@ -227,4 +227,10 @@ __global__ __launch_bounds__(256) void srbdqp_mpc_inputs_kernel(MpcInputsArgs a)
     }
 }
 
+// u_opt0 of every QP of a solve, packed for the all-gather across GPUs (srbdqp_gather_u0_f64): out[b][c] = u[b][0][c], 12 doubles of the N x 12 a QP's plan holds
+__global__ __launch_bounds__(256) void srbdqp_pack_u0_kernel(const double* __restrict__ u, double* __restrict__ out, long long items, int N) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < items) out[i] = u[(i / 12) * (12LL * N) + (i % 12)];
+}
+
 }  // namespace srbdqp

@@ -287,6 +287,17 @@ int srbdqp_set_schedule_hint(srbdqp_handle* h, const int32_t* device_iters_prev,
  * A no-op without the flag or with nothing pending.  srbdqp_synchronize() flushes the handle's own stream first. */
 int srbdqp_flush(srbdqp_handle* h, void* stream);
 
+/* Multi-GPU without torch.distributed (SURVEY row e; one process per GPU).  The path shards by robots: QPs are independent, so a fleet of `total` QPs is cut
+ * into contiguous per-rank ranges -- srbdqp_shard_range: rank r of `world` owns [*first, *first + *count), the first total % world ranks one QP more (the
+ * same rule as g1_locomotion_amd/shard.py) -- and nothing crosses GPUs while they solve.  The one exchange is what the MPC's consumer reads from every robot,
+ * the first-step forces u_opt0 (g1_mujoco_sim/src/ros_run_simulation.py:214-215): srbdqp_gather_u0_f64 packs u_local[b][0][0..12) of this rank's B_local
+ * QPs (device memory, the u_out of a solve, [B_local][N][12]) into its slot of u0_all (device memory, [world * B_local][12], rank-major) and all-gathers the
+ * slots over RCCL, in place, on `stream` (a hipStream_t; NULL = the handle's) -- 96 bytes per QP over xGMI.  rccl_comm is an ncclComm_t the caller made
+ * (ncclCommInitRank with the id it distributed itself); B_local must be the same on every rank, as for any all-gather.  The library finds RCCL at the first call
+ * (dlopen of librccl.so.1: not a link-time dependency); SRBDQP_E_HIP with a message if it is not there or a call fails.  Does not synchronise. */
+int srbdqp_shard_range(int64_t total, int32_t world, int32_t rank, int64_t* first, int64_t* count);
+int srbdqp_gather_u0_f64(srbdqp_handle* h, const double* u_local, int64_t B_local, double* u0_all, void* rccl_comm, void* stream);
+
 /* Low-latency path for small batches (the single-robot control loop, B = 1): the library owns pinned, GPU-mapped host
  * staging arrays; the caller fills the inputs in place, calls srbdqp_solve_staged_f64 (one kernel launch that reads and
  * writes the staging memory directly over PCIe -- no hipMemcpy calls), and reads the outputs in place.  Shapes as in

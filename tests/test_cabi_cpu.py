@@ -162,3 +162,23 @@ def test_default_config_refuses_a_struct_of_another_size(built_lib):
     cfg.contents.struct_size = C.sizeof(_lib.Config)
     assert built_lib.srbdqp_default_config(cfg) == _lib.OK
     assert bytes(buf)[C.sizeof(_lib.Config):] == b"\x5a" * 64
+
+
+def test_shard_range_equals_the_python_rule(built_lib):
+    lib = built_lib
+    """srbdqp_shard_range (the C consumer's view of SURVEY row e) cuts a fleet exactly as g1_locomotion_amd.shard.shard_bounds does; bad requests are refused."""
+    import ctypes as C
+    from g1_locomotion_amd.shard import shard_bounds
+    first, count = C.c_int64(), C.c_int64()
+    for total in (0, 1, 7, 4096, 524288, 524291):
+        for world in (1, 2, 3, 8):
+            covered = 0
+            for rank in range(world):
+                assert lib.srbdqp_shard_range(total, world, rank, C.byref(first), C.byref(count)) == 0
+                lo, hi = shard_bounds(total, rank, world)
+                assert (first.value, first.value + count.value) == (lo, hi)
+                covered += count.value
+            assert covered == total
+    assert lib.srbdqp_shard_range(10, 0, 0, C.byref(first), C.byref(count)) != 0
+    assert lib.srbdqp_shard_range(10, 2, 2, C.byref(first), C.byref(count)) != 0
+    assert lib.srbdqp_shard_range(-1, 2, 0, C.byref(first), C.byref(count)) != 0
