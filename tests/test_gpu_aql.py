@@ -137,3 +137,23 @@ def test_completion_word_with_checksum_never_hands_over_partial_outputs(torch_fi
                 assert r[2] == first[q][2] and r[3] == first[q][3], i
                 assert np.array_equal(r[0], first[q][0]) and np.array_equal(r[1], first[q][1]), i
         assert not np.array_equal(first[0][0], first[1][0]) and not np.array_equal(first[1][0], first[2][0])
+
+
+def test_early_exits_report_through_the_completion_records_too(torch_first, built_lib):
+    """A flight phase (no stance contact anywhere: status 1, zero forces, the roll-out of x0 under gravity) leaves the batch-1 kernels before the set-up; its
+    completion goes through the same records.  Alternating with ordinary QPs, single- and double-support instantiations."""
+    from g1_locomotion_amd import BatchMPC
+    N = 10
+    os.environ.pop("SRBDQP_NO_AQL", None)
+    for schedule in ("single", "double"):
+        x0, xr, ft, ct = orc.synthetic_batch(2, N, seed=31, schedule=schedule)
+        flight = np.zeros_like(ct[0])
+        with BatchMPC(horizon=N) as eng:
+            ref = _one(eng, x0[0], xr[0], ft[0], ct[0], N, False)
+            for i in range(200):
+                f = _one(eng, x0[1], xr[1], ft[1], flight, N, False)
+                assert f[2] == 1 and f[3] == 0 and not f[0].any(), i
+                assert np.allclose(f[1][0], x0[1]) and f[1][N, 5] < x0[1][5]            # falling
+                r = _one(eng, x0[0], xr[0], ft[0], ct[0], N, False)
+                assert r[2] == ref[2] and r[3] == ref[3] and np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]), i
+            assert eng.batch1_launch_path() == "aql"
