@@ -168,6 +168,12 @@ struct WrenchSmem {
 
 // diagnostic builds (-DSRBDQP_PROFILE_WADMM): s_memtime stamps inside the ADMM iteration of the general kernel, summed per
 // segment by thread 0 and written to the second row of the stamp buffer of a B = 1 solve (tools/wrench_stamps_staged.py prints them)
+// diagnostic builds (-DSRBDQP_XQ_STAMPS): stamps 10 / 11 / 12 inside "fragments + x_q" (tools/wrench_stamps.py prints them): behind the half rows, behind x_q, behind G'(G x_q)
+#ifdef SRBDQP_XQ_STAMPS
+#define XQSTAMP(a, b, i) SRBDQP_STAMP(a, b, i)
+#else
+#define XQSTAMP(a, b, i) do { } while (0)
+#endif
 #ifdef SRBDQP_PROFILE_WADMM
 #define WADMM_T(i) do { if (wadmm_t) { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); wadmm_t[i] = (long long)t_; } } while (0)
 #define WADMM_DECL long long wadmm_tt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wadmm_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long* wadmm_t = wadmm_tt
@@ -1642,6 +1648,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             kin64[cc] = ok ? v : TT(0);
         }
     }
+    XQSTAMP(a, b, 10);
     const bool failed = sm[S::o_misc] != 0.0;
     const int vsoff = stepok ? igoff[js] : 0;                         // the step's own v = V w inside the v buffer
     __syncthreads();   // tiles are dead; region R becomes the ADMM vectors
@@ -1694,6 +1701,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
             }
             xq = active_u ? xq : 0.0;
             __syncthreads();
+            XQSTAMP(a, b, 11);
             if constexpr (sizeof(TT) == 4) {
                 // fp32 tiles: T^-1 is good to ~1e-4 only.  One step of iterative refinement with the fp64 residual
                 // r = K x_q + q = G'(G x_q) + D x_q + q (closed form, as the warm start's P x^0) takes the large gradient
@@ -1709,6 +1717,7 @@ __device__ __forceinline__ void wrench_qp(const KArgs& a, const int b, double* s
                 const double rres = active_u ? fma(dl, xq, gtg + qv) : 0.0;
                 for (int i = t; i < 2 * S::VB; i += LT) vb[i] = 0.0;
                 __syncthreads();
+                XQSTAMP(a, b, 12);
                 double dxq;
                 if constexpr (VPARK) dxq = apply_kinv<double, CHMAX, CHMAX, true>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {}, nullptr, n, vpr, vpc);
                 else dxq = apply_kinv<double, CHMAX>(-rres, wbw, tbw, vb, lane, sg, ul, active_g, Rrow, CH, kin64, vrd, vcd, bjv, vsoff, vssel, [] {});
