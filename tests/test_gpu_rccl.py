@@ -65,7 +65,10 @@ def test_c_abi_gather_over_an_rccl_communicator_of_the_callers(built_lib):
     from g1_locomotion_amd import BatchMPC, _lib
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+    try:
+        rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        pytest.skip("no librccl.so.1 to make a communicator with (%s)" % e)
 
     class UniqueId(C.Structure):
         _fields_ = [("internal", C.c_char * 128)]
