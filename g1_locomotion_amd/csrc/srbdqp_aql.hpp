@@ -217,6 +217,7 @@ public:
         _mm_sfence();                                                  // the write-combining buffers drain before anything below leaves the core
         if (d_->hdp_flush) *d_->hdp_flush = 1u;                        // (posted, ahead of the doorbell on the same link)
         hsa_signal_add_relaxed(sig_, 1);                                // one per packet in flight: a restart pass may be queued behind a first pass still ending
+        // (no wait for a free slot: a staged call is synchronous, so the queue never holds more than the passes of ONE solve -- at most four of its 64 packets)
         const uint64_t wi = hsa_queue_add_write_index_relaxed(q_, 1);
         auto* pk = static_cast<hsa_kernel_dispatch_packet_t*>(q_->base_address) + (wi & (q_->size - 1));
         pk->workgroup_size_x = (uint16_t)block; pk->workgroup_size_y = 1; pk->workgroup_size_z = 1;
